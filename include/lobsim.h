@@ -1,0 +1,214 @@
+/* lobsim.h - C-ABI of the MI355X-native limit-order-book simulation step.
+ *
+ * Drop-in boundary for the hot path of JJJerome/rl4mm (reference paths are relative to /root/reference):
+ *   rl4mm/gym/HistoricalOrderbookEnvironment.py:147-178  reset() / step()          -> lobsim_reset / lobsim_step
+ *   rl4mm/simulation/OrderbookSimulator.py:55-135        reset_episode / forward_step / update_outer_levels
+ *   rl4mm/orderbook/Exchange.py:58-247                   process_order and the matching engine
+ *   rl4mm/features/Features.py, rl4mm/rewards/RewardFunctions.py  observation + reward reductions
+ * Everything is plain pointers and sizes: no torch / numpy / C++ types cross this boundary.  The Python host
+ * side (rl4mm_amd/) binds it with ctypes; INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Threading: one handle per GPU; calls on one handle must be serialised by the caller (the reference env is
+ * single-threaded as well, rl4mm/gym/utils.py:242-246).  All functions return 0 on success, a negative
+ * lobsim_error otherwise; lobsim_last_error() gives the message.
+ *
+ * oracle/lobsim_oracle.c exports the same entry points with an `oracle_` prefix (CPU restatement, test
+ * infrastructure only).
+ */
+#ifndef LOBSIM_H
+#define LOBSIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LOBSIM_MAX_FEATURES 16
+#define LOBSIM_MAX_ACTION_DIM 5
+#define LOBSIM_MSG_WORDS 4 /* packed message = 4 x int64, see rl4mm_amd/stream.py */
+
+/* message word 3: volume | type << 48 | side << 52 */
+#define LOBSIM_TYPE_SHIFT 48
+#define LOBSIM_SIDE_SHIFT 52
+#define LOBSIM_VOL_MASK ((1ll << 48) - 1)
+
+enum lobsim_order_type { /* LOBSTER event types = rl4mm/database/database_population_helpers.py:151-160 */
+    LOBSIM_LIMIT = 1,
+    LOBSIM_CANCELLATION = 2,
+    LOBSIM_DELETION = 3,
+    LOBSIM_MARKET = 4,
+    LOBSIM_HIDDEN = 5,
+    LOBSIM_CROSS_TRADE = 6,
+    LOBSIM_TRADING_HALT = 7
+};
+enum lobsim_side { LOBSIM_BUY = 0, LOBSIM_SELL = 1 };
+
+enum lobsim_error {
+    LOBSIM_OK = 0,
+    LOBSIM_ERR_ARG = -1,
+    LOBSIM_ERR_HIP = -2,
+    LOBSIM_ERR_STATE = -3,
+    LOBSIM_ERR_NOMEM = -4
+};
+
+/* Per-env status bits (sticky until the env is reset).  They stand in for the Python exceptions the reference
+ * raises on the same conditions; an env with any bit set reports done=1 and stops advancing. */
+enum lobsim_status {
+    LOBSIM_ST_EMPTY_BOOK = 1,      /* EmptyOrderbookError, rl4mm/orderbook/Exchange.py:180-186 */
+    LOBSIM_ST_BAD_MESSAGE = 2,     /* cross_trade assert / trading_halt crash, HistoricalOrderGenerator.py:54-56 */
+    LOBSIM_ST_LEVEL_OVERFLOW = 4,  /* more price levels on one side than the build holds */
+    LOBSIM_ST_QUEUE_OVERFLOW = 8,  /* more live orders at one price than the build holds */
+    LOBSIM_ST_AGENT_OVERFLOW = 16, /* more live agent orders than the build holds */
+    LOBSIM_ST_STREAM_END = 32,     /* stepped past the end of the loaded stream */
+    LOBSIM_ST_ASSERT = 64,         /* `assert order.volume > 0` (Exchange.py:59-60) and similar */
+    LOBSIM_ST_NOT_RESET = 128
+};
+
+enum lobsim_feature_kind { /* rl4mm/features/Features.py */
+    LOBSIM_F_SPREAD = 1,                    /* :113 */
+    LOBSIM_F_PRICE_MOVE = 2,                /* :151 */
+    LOBSIM_F_VOLATILITY = 3,                /* :203 */
+    LOBSIM_F_INVENTORY = 4,                 /* :474 */
+    LOBSIM_F_EPISODE_PROPORTION = 5,        /* :493 */
+    LOBSIM_F_TIME_OF_DAY = 6,               /* :515 */
+    LOBSIM_F_TRADE_DIRECTION_IMBALANCE = 7, /* :351 */
+    LOBSIM_F_TRADE_VOLUME_IMBALANCE = 8,    /* :410 */
+    LOBSIM_F_BOOK_IMBALANCE = 9,            /* :132 */
+    LOBSIM_F_PRICE_RANGE = 10,              /* :178 */
+    LOBSIM_F_PRICE = 11                     /* :327 */
+};
+
+typedef struct lobsim_feature {
+    int32_t kind;      /* lobsim_feature_kind */
+    int32_t lookback;  /* lookback_periods (0 for book/agent features) */
+    int64_t update_us; /* update_frequency in microseconds */
+    double min_value, max_value;
+    double dparam;  /* EpisodeProportion: update_frequency / episode_length (Features.py:505) */
+    int64_t iparam; /* TimeOfDay: bucket size in us (Features.py:528); n_buckets - 1 is max_value */
+} lobsim_feature;
+
+enum lobsim_reward_kind { LOBSIM_R_PNL = 1 /* RewardFunctions.py:97 */, LOBSIM_R_INVENTORY_ADJUSTED = 2 /* :107 */ };
+
+typedef struct lobsim_reward {
+    int32_t kind;
+    int32_t asymmetrically_dampened;
+    double inventory_aversion;
+} lobsim_reward;
+
+/* Mirrors the constructor arguments of HistoricalOrderbookEnvironment (HistoricalOrderbookEnvironment.py:54-81)
+ * and OrderbookSimulator (OrderbookSimulator.py:24-35) that reach the step. */
+typedef struct lobsim_cfg {
+    int32_t n_envs;
+    int32_t n_levels;        /* book levels per side in the snapshot rows (simulator n_levels) */
+    int32_t tick_size;       /* Exchange.tick_size, 100 */
+    int32_t outer_levels;    /* OrderbookSimulator.outer_levels, 20 */
+    int32_t min_quote_level; /* quotes sit min..max-1 ticks behind the best price */
+    int32_t max_quote_level;
+    int32_t action_dim;            /* 4; 2 with concentration; +1 with market_order_clearing */
+    int32_t use_concentration;     /* BetaOrderDistributor(concentration=...) */
+    int32_t market_order_clearing;
+    int32_t enter_spread;
+    int32_t inc_prev_action_in_obs;
+    int32_t n_features;
+    int32_t device_id; /* HIP device ordinal (ignored by the oracle) */
+    int32_t reserved0;
+    int64_t step_us;    /* step_size */
+    int64_t episode_us; /* episode_length */
+    int64_t warmup_us;  /* max feature window (whole seconds) */
+    double concentration;
+    double market_order_fraction_of_inventory;
+    lobsim_reward per_step_reward;
+    lobsim_reward terminal_reward;
+    lobsim_feature features[LOBSIM_MAX_FEATURES];
+} lobsim_cfg;
+
+typedef struct lobsim_env_state {
+    int64_t now_us;        /* simulator clock, microseconds since midnight */
+    int64_t terminal_us;   /* episode start + episode length */
+    int64_t inventory;
+    int64_t cash;          /* integer-valued, kept exact */
+    double price;          /* state.price (microprice) after the last step */
+    int64_t best_buy, best_sell;
+    int64_t min_buy_price, max_sell_price;       /* outer-level resync bookkeeping, OrderbookSimulator.py:185-188 */
+    int64_t initial_buy_range, initial_sell_range;
+    int32_t n_buy_levels, n_sell_levels;
+    int32_t n_agent_orders;
+    int32_t status;
+    int32_t stream_id;
+    int32_t n_resyncs; /* update_outer_levels calls since reset */
+    /* fills of the last step (a19 / Q10): agent fills by the agent's side; external fills by the resting side */
+    int64_t agent_fill_count, agent_buy_volume, agent_sell_volume;
+    int64_t ext_buy_count, ext_sell_count, ext_buy_volume, ext_sell_volume;
+} lobsim_env_state;
+
+/* One order of the central book as seen from outside (FIFO position = array index). */
+typedef struct lobsim_order_view {
+    int64_t id;      /* tracked external order: external id; agent order: FIFO rank among the agent's own orders at
+                        this price (0 = oldest); snapshot aggregate: -1 */
+    int64_t volume;
+    int32_t kind;    /* 0 tracked external, 1 agent, 2 snapshot aggregate (internal_id == -1) */
+    int32_t reserved;
+} lobsim_order_view;
+
+typedef struct lobsim lobsim_t;
+
+int lobsim_create(const lobsim_cfg* cfg, lobsim_t** out);
+void lobsim_destroy(lobsim_t* h);
+const char* lobsim_last_error(const lobsim_t* h);
+
+/* Launch everything on this hipStream_t (0 = the handle's own stream).  Lets a torch caller time with
+ * torch.cuda.Event on torch's current stream. */
+int lobsim_set_stream(lobsim_t* h, void* hip_stream);
+
+/* Upload one packed (ticker, day) stream (host pointers; copied to HBM).  Returns the stream id >= 0.
+ * Replaces HistoricalDatabase.get_messages / get_last_snapshot (rl4mm/database/HistoricalDatabase.py:46,103). */
+int lobsim_add_stream(lobsim_t* h, const int64_t* msgs, int64_t n_msgs, const int64_t* snaps, int64_t n_snaps);
+
+/* Portfolio carried by each env (HistoricalOrderbookEnvironment.initial_portfolio, :104).  The reference does NOT
+ * reset it between episodes; neither does lobsim_reset. */
+int lobsim_set_portfolio(lobsim_t* h, const int32_t* env_ids, int32_t n, const int64_t* inventory, const int64_t* cash);
+
+/* env.reset() for n envs: snapshot at (episode_start - warmup), warm-up replay without agent orders, first
+ * observation.  episode_start_us must be whole seconds.  obs (host, [n][obs_dim] f64) may be NULL. */
+int lobsim_reset(lobsim_t* h, const int32_t* env_ids, int32_t n, const int32_t* stream_ids,
+                 const int64_t* episode_start_us, double* obs);
+
+/* env.step(action) for every env with active[i] != 0 (active == NULL: all).  Host pointers:
+ * actions [n_envs][action_dim] f64 -> obs [n_envs][obs_dim] f64, reward [n_envs] f64, done [n_envs] u8. */
+int lobsim_step(lobsim_t* h, const double* actions, const uint8_t* active, double* obs, double* reward, uint8_t* done);
+
+/* Same with DEVICE pointers, asynchronous on the handle's stream (no host sync).  obs_f32 (device, may be NULL)
+ * additionally receives the observation as float32, the dtype of observation_space (:131-135). */
+int lobsim_step_device(lobsim_t* h, const double* d_actions, const uint8_t* d_active, double* d_obs, float* d_obs_f32,
+                       double* d_reward, uint8_t* d_done);
+int lobsim_sync(lobsim_t* h);
+
+int lobsim_obs_dim(const lobsim_t* h);
+
+/* --- inspection (parity tests, info dicts) ---------------------------------------------------------------- */
+int lobsim_get_env_state(lobsim_t* h, int32_t env, lobsim_env_state* out);
+/* Device-side bulk read of (inventory, cash, price) for all envs into host arrays (any may be NULL). */
+int lobsim_get_portfolios(lobsim_t* h, int64_t* inventory, int64_t* cash, double* price);
+/* Central book, best level first: prices/volumes/order counts of up to max_levels levels of one side. */
+int lobsim_get_book(lobsim_t* h, int32_t env, int32_t side, int64_t* prices, int64_t* volumes, int32_t* n_orders,
+                    int32_t max_levels, int32_t* n_levels_out);
+/* FIFO queue at one price. */
+int lobsim_get_level_orders(lobsim_t* h, int32_t env, int32_t side, int64_t price, lobsim_order_view* out,
+                            int32_t max_orders, int32_t* n_out);
+
+/* --- engine-level entry (unit parity of Exchange.process_order, Exchange.py:58) ---------------------------- */
+/* Start env from an explicit snapshot row [4 * n_levels] (sell_p, sell_v, buy_p, buy_v per level; pass NULL for an
+ * empty book) at time now_us, without a stream. */
+int lobsim_debug_set_book(lobsim_t* h, int32_t env, const int64_t* snapshot_row, int64_t now_us); /* price 0 = absent level */
+/* Process orders [n][6] = {type, side, price, volume (-1 = None), id, is_external} in sequence.  For agent
+ * cancellations/deletions `id` is the FIFO rank of the target among the agent's orders at that price (as in
+ * lobsim_order_view.id; a rank that does not exist addresses no order).  fills_out [8] (may be
+ * NULL) receives the aggregate fills {agent_fill_count, agent_buy_vol, agent_sell_vol, ext_buy_count,
+ * ext_sell_count, ext_buy_vol, ext_sell_vol, cash_delta}. */
+int lobsim_debug_process_orders(lobsim_t* h, int32_t env, const int64_t* orders, int32_t n, int64_t* fills_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOBSIM_H */

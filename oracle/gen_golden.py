@@ -1,0 +1,530 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by running the upstream reference itself (build container only).
+
+Run:  PYTHONPATH=oracle/refshim:/root/reference PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+
+The reference (pure Python, /root/reference, read-only) is imported through the stubs in oracle/refshim
+(SURVEY.md Appendix A).  Nothing of it travels: only the *vectors* written here (inputs and the reference's
+outputs) are committed, as .npz fixtures under tests/golden/, together with this script.
+
+Fixtures:
+  msft_*.csv(.gz)     G0  the reference's own 1000-row MSFT LOBSTER test slice (data file of its tests)
+  beta_table.npz      G5  scipy Beta-pdf -> integer volumes (OrderDistributors.py:39-56)
+  engine_cases.npz    G1  testExchange scenarios + seeded random order sequences through Exchange.process_order
+  replay_msft.npz     G2  OrderbookSimulator replay of the slice, no agent (testOrderbookSimulator.py:46-75)
+  resync_msft.npz     G8  update_outer_levels with internal orders (testOrderbookSimulator.py:77-108)
+  traj_*.npz          G3/G4/G7 full env.reset()/env.step() trajectories (MSFT slice and synthetic streams)
+"""
+import gzip
+import json
+import os
+import shutil
+import sys
+import tempfile
+import warnings
+from copy import deepcopy
+from datetime import datetime, timedelta
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+
+warnings.simplefilter("ignore")
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
+GOLD = REPO / "tests" / "golden"
+REF_DATA = Path("/root/reference/test_data")
+
+from sqlalchemy import create_engine  # noqa: E402
+
+from rl4mm.agents.baseline_agents import FixedActionAgent, Teradactyl  # noqa: E402
+from rl4mm.database.HistoricalDatabase import HistoricalDatabase  # noqa: E402
+from rl4mm.database.populate_database import populate_database  # noqa: E402
+from rl4mm.features.Features import (  # noqa: E402
+    BookImbalance, EpisodeProportion, Inventory, Portfolio, Price, PriceMove, PriceRange, Spread, TimeOfDay,
+    TradeDirectionImbalance, TradeVolumeImbalance, Volatility,
+)
+from rl4mm.gym.HistoricalOrderbookEnvironment import HistoricalOrderbookEnvironment  # noqa: E402
+from rl4mm.gym.action_interpretation.OrderDistributors import BetaOrderDistributor  # noqa: E402
+from rl4mm.gym.utils import get_reward_function  # noqa: E402
+from rl4mm.orderbook.Exchange import Exchange  # noqa: E402
+from rl4mm.orderbook.models import Cancellation, Deletion, LimitOrder, MarketOrder  # noqa: E402
+from rl4mm.simulation.HistoricalOrderGenerator import HistoricalOrderGenerator  # noqa: E402
+from rl4mm.simulation.OrderbookSimulator import OrderbookSimulator  # noqa: E402
+
+from rl4mm_amd.stream import pack_lobster  # noqa: E402
+from rl4mm_amd.synth import generate_lobster, write_lobster_csv  # noqa: E402
+
+T0 = datetime(2012, 6, 21, 12, 0)
+TYPE = {LimitOrder: 1, Cancellation: 2, Deletion: 3, MarketOrder: 4}
+SIDE = {"buy": 0, "sell": 1}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# dumps of reference state
+# ---------------------------------------------------------------------------------------------------------------
+def dump_queues(exchange):
+    """-> int64 [n, 5] rows (side, price, kind, id, volume) in book order (best level first, FIFO inside)."""
+    rows = []
+    for side in ("buy", "sell"):
+        book_side = getattr(exchange.central_orderbook, side)
+        prices = list(reversed(book_side)) if side == "buy" else list(book_side)
+        for price in prices:
+            rank = 0
+            for order in book_side[price]:
+                if order.internal_id == -1:
+                    kind, oid = 2, -1
+                elif order.is_external:
+                    kind, oid = 0, int(order.external_id)
+                else:
+                    kind, oid = 1, rank
+                    rank += 1
+                rows.append((SIDE[side], int(price), kind, oid, int(order.volume)))
+    return np.array(rows, dtype=np.int64).reshape(-1, 5)
+
+
+def dump_top(exchange, k):
+    """-> int64 [2, k, 3] (price, volume, n_orders), missing levels = 0."""
+    out = np.zeros((2, k, 3), dtype=np.int64)
+    for side in ("buy", "sell"):
+        book_side = getattr(exchange.central_orderbook, side)
+        prices = list(reversed(book_side)) if side == "buy" else list(book_side)
+        for i, price in enumerate(prices[:k]):
+            out[SIDE[side], i] = (int(price), sum(int(o.volume) for o in book_side[price]), len(book_side[price]))
+    return out
+
+
+def fills_rows(filled):
+    rows = []
+    if filled is not None:
+        for o in filled.internal:
+            rows.append((0, SIDE[o.direction], int(o.price), int(o.volume)))
+        for o in filled.external:
+            rows.append((1, SIDE[o.direction], int(o.price), int(o.volume)))
+    return rows
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# G5 beta table
+# ---------------------------------------------------------------------------------------------------------------
+def gen_beta_table():
+    rng = np.random.Generator(np.random.PCG64(5))
+    out = {}
+    for q in (10, 20, 5):
+        dist = BetaOrderDistributor(quote_levels=q)
+        acts = rng.uniform(0.0, 10.0, size=(4000, 4))
+        acts[:8] = [[1, 1, 1, 1], [1, 2, 1, 2], [0, 0, 0, 0], [10, 10, 10, 10], [0, 10, 10, 0], [2, 5, 5, 2], [0.5, 0.5, 3, 3], [1, 1, 2, 2]]
+        buy = np.zeros((len(acts), q), dtype=np.int64)
+        sell = np.zeros((len(acts), q), dtype=np.int64)
+        for i, a in enumerate(acts):
+            r = dist.convert_action(a)
+            buy[i], sell[i] = r["buy"], r["sell"]
+        out[f"actions_q{q}"], out[f"buy_q{q}"], out[f"sell_q{q}"] = acts, buy, sell
+    # concentration variant (2-dim action, OrderDistributors.py:44-45)
+    conc = 12.0
+    dist = BetaOrderDistributor(quote_levels=10, concentration=conc)
+    acts = rng.uniform(0.0, 10.0, size=(2000, 2))
+    buy = np.zeros((len(acts), 10), dtype=np.int64)
+    sell = np.zeros((len(acts), 10), dtype=np.int64)
+    for i, a in enumerate(acts):
+        r = dist.convert_action(a)
+        buy[i], sell[i] = r["buy"], r["sell"]
+    out["actions_conc"], out["buy_conc"], out["sell_conc"], out["concentration"] = acts, buy, sell, np.array(conc)
+    np.savez_compressed(GOLD / "beta_table.npz", **out)
+    print("beta_table", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# G1 engine cases
+# ---------------------------------------------------------------------------------------------------------------
+def mk(order_type, side, price, volume, ext_id, is_external, internal_id=None):
+    kw = dict(timestamp=T0, direction=side, ticker="MSFT", internal_id=internal_id, external_id=ext_id, is_external=is_external)
+    if order_type == 4:
+        return MarketOrder(volume=volume, **kw)
+    cls = {1: LimitOrder, 2: Cancellation, 3: Deletion}[order_type]
+    return cls(price=price, volume=volume, **kw)
+
+
+def run_engine_case(snapshot, ops):
+    """ops rows: (type, side, price, volume(-1 None), id, is_external).  For agent cancels/deletions id = FIFO rank
+    of the target within the internal book level.  Returns per-op queue dumps, fills, status."""
+    ex = Exchange("MSFT")
+    if snapshot is not None:
+        orders = []
+        for side, price, vol in snapshot:
+            orders.append(LimitOrder(timestamp=T0, price=price, volume=vol, direction=side, ticker="MSFT", internal_id=-1, external_id=None, is_external=True))
+        ex.central_orderbook = ex.get_initial_orderbook_from_orders(orders)
+    dumps, dump_off, fills, fill_off, status = [], [0], [], [0], []
+    names = ["buy", "sell"]
+    for t, s, p, v, oid, is_ext in ops:
+        side = names[s]
+        vol = None if v < 0 else int(v)
+        st = 0
+        try:
+            if is_ext:
+                order = mk(t, side, int(p), vol, int(oid), True)
+            elif t in (2, 3):
+                level = getattr(ex.internal_orderbook, side).get(int(p))
+                iid = level[int(oid)].internal_id if level is not None and 0 <= oid < len(level) else 10**9
+                order = mk(t, side, int(p), vol, None, False, internal_id=iid)
+            else:
+                order = mk(t, side, int(p), vol, None, False)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                filled = ex.process_order(order)
+        except Exception as exc:  # EmptyOrderbookError / AssertionError
+            filled = None
+            st = 1 if type(exc).__name__ == "EmptyOrderbookError" else 64
+        fr = fills_rows(filled)
+        fills += fr
+        fill_off.append(len(fills))
+        d = dump_queues(ex)
+        dumps.append(d)
+        dump_off.append(dump_off[-1] + len(d))
+        status.append(st)
+        if st:
+            break
+    return dict(
+        dumps=np.concatenate(dumps) if dumps else np.zeros((0, 5), np.int64),
+        dump_off=np.array(dump_off), fills=np.array(fills, dtype=np.int64).reshape(-1, 4), fill_off=np.array(fill_off),
+        status=np.array(status),
+    )  # fmt: skip
+
+
+def gen_engine_cases():
+    P = 301000
+    cases = []
+    # --- the reference's own testExchange scenarios (rl4mm/orderbook/tests/testExchange.py, mock_orders.py) ---
+    L1 = (1, 0, P, 1000, 50, 1); L2 = (1, 0, P, 200, 100, 1); L3 = (1, 0, P + 1000, 200, 110, 1)  # noqa: E702
+    L4 = (1, 1, P + 2000, 200, 0, 0); L5 = (1, 1, P + 1000, 300, 0, 0)  # noqa: E702
+    cases.append(("submit_basic", None, [L1, L2, L3, L4]))
+    cases.append(("market_sweep", None, [L1, L2, L3, L4, (4, 1, 0, 1000, 50, 0), (4, 1, 0, 200, 100, 1), (4, 0, 0, 200, 110, 1)]))
+    cases.append(("cancel_basic", None, [L1, (2, 0, P, 200, 50, 1)]))
+    cases.append(("cancel_too_large", None, [L1, (2, 0, P, 200, 50, 1), (2, 0, P, 1100, 50, 1)]))
+    cases.append(("delete_basic", None, [L1, (3, 0, P, 1000, 50, 1)]))
+    cases.append(("delete_internal", None, [L1, L4, (3, 1, P + 2000, -1, 0, 0)]))
+    cases.append(("delete_no_volume", None, [L2, (3, 0, P, -1, 100, 1)]))
+    cases.append(("limit_crossing", None, [L1, L2, L3, L4, L5]))
+    # --- extra hand-written edge cases ---
+    snap = [("buy", P, 500), ("buy", P - 100, 700), ("sell", P + 100, 400), ("sell", P + 200, 900)]
+    cases.append(("unknown_id_hits_snapshot", snap, [(3, 0, P, 200, 999, 1), (2, 0, P, 1000, 998, 1), (3, 0, P - 100, 100, 997, 1), (3, 0, P - 500, 100, 996, 1)]))
+    cases.append(("agent_vs_agent", snap, [(1, 0, P, 50, 0, 0), (1, 0, P + 100, 30, 0, 0)]))
+    cases.append(("agent_self_cross", None, [(1, 0, P, 50, 0, 0), (1, 0, P, 20, 0, 0), (1, 1, P + 300, 10, 1, 1), (1, 1, P, 100, 0, 0)]))
+    cases.append(("ext_hits_agent", snap, [(1, 1, P + 100, 60, 0, 0), (1, 1, P + 100, 100, 7, 1), (4, 0, 0, 450, 8, 1), (4, 0, 0, 100, 9, 1)]))
+    cases.append(("empty_side_market", None, [L1, (4, 0, 0, 100, 5, 1)]))
+    cases.append(("ext_limit_cross_remainder", snap, [(1, 0, P + 150, 1000, 77, 1), (3, 0, P + 150, 600, 77, 1)]))
+    cases.append(("agent_cancel_newest", snap, [(1, 0, P, 10, 0, 0), (1, 0, P, 20, 0, 0), (1, 0, P, 30, 0, 0), (2, 0, P, 25, 2, 0), (2, 0, P, 20, 1, 0), (4, 1, 0, 520, 3, 1)]))
+    cases.append(("zero_volume_assert", snap, [(1, 0, P, 0, 5, 1)]))
+
+    # --- seeded random sequences on a small price grid ---
+    rng = np.random.Generator(np.random.PCG64(11))
+    for c in range(60):
+        mid = 300000
+        snapshot = None
+        if c % 3 != 0:
+            snapshot = [("buy", mid - 100 * (i + 1), int(rng.integers(1, 8)) * 100) for i in range(5)] + [
+                ("sell", mid + 100 * (i + 1), int(rng.integers(1, 8)) * 100) for i in range(5)
+            ]
+        ops, live_ext, next_id = [], [], 1000
+        agent_live = {0: {}, 1: {}}  # side -> price -> count (approximate; ranks may miss, which is a valid case)
+        for _ in range(int(rng.integers(40, 160))):
+            u = rng.random()
+            s = int(rng.integers(0, 2))
+            if u < 0.35:  # external limit, sometimes crossing
+                off = int(rng.integers(-2, 7))
+                p = mid - 100 * off if s == 0 else mid + 100 * off
+                ops.append((1, s, p, int(rng.integers(1, 6)) * 50, next_id, 1))
+                live_ext.append((next_id, s, p))
+                next_id += 1
+            elif u < 0.50 and live_ext:  # external cancel / delete of a (maybe already gone) order
+                oid, so, po = live_ext[int(rng.integers(0, len(live_ext)))]
+                t = 2 if rng.random() < 0.4 else 3
+                ops.append((t, so, po, int(rng.integers(1, 6)) * 50, oid, 1))
+            elif u < 0.58:  # delete of an unknown id at a random level
+                p = mid - 100 * int(rng.integers(1, 6)) if s == 0 else mid + 100 * int(rng.integers(1, 6))
+                ops.append((3, s, p, int(rng.integers(1, 4)) * 100, 5, 1))
+            elif u < 0.68:  # external market
+                ops.append((4, s, 0, int(rng.integers(1, 8)) * 50, 7, 1))
+            elif u < 0.88:  # agent limit, sometimes crossing
+                off = int(rng.integers(-1, 6))
+                p = mid - 100 * off if s == 0 else mid + 100 * off
+                ops.append((1, s, p, int(rng.integers(1, 30)), 0, 0))
+                agent_live[s][p] = agent_live[s].get(p, 0) + 1
+            elif u < 0.97:  # agent cancel by rank
+                if agent_live[s]:
+                    p = list(agent_live[s])[int(rng.integers(0, len(agent_live[s])))]
+                    ops.append((2, s, p, int(rng.integers(1, 30)), int(rng.integers(0, 3)), 0))
+            else:  # agent market
+                ops.append((4, s, 0, int(rng.integers(1, 100)), 0, 0))
+        cases.append((f"fuzz_{c}", snapshot, ops))
+
+    out = {"names": np.array([c[0] for c in cases])}
+    for name, snapshot, ops in cases:
+        r = run_engine_case(snapshot, ops)
+        snap_arr = np.zeros((0, 3), np.int64) if snapshot is None else np.array([(SIDE[s], p, v) for s, p, v in snapshot], dtype=np.int64)
+        out[f"{name}/snapshot"] = snap_arr
+        out[f"{name}/has_snapshot"] = np.array(snapshot is not None)
+        out[f"{name}/ops"] = np.array(ops, dtype=np.int64).reshape(-1, 6)
+        for k, v in r.items():
+            out[f"{name}/{k}"] = v
+    np.savez_compressed(GOLD / "engine_cases.npz", **out)
+    print("engine_cases", len(cases), "cases")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# reference DB / env construction
+# ---------------------------------------------------------------------------------------------------------------
+def make_db(data_dir, ticker, date, n_levels, freq, max_rows=99999999999, batch_size=1000000):
+    db = HistoricalDatabase(engine=create_engine("sqlite:///:memory:"))
+    populate_database((ticker,), (date,), n_levels=n_levels, database=db, path_to_lobster_data=str(data_dir), book_snapshot_freq=freq, max_rows=max_rows, batch_size=batch_size)
+    return db
+
+
+FEATURE_KINDS = {
+    "Spread": 1, "PriceMove": 2, "Volatility": 3, "Inventory": 4, "EpisodeProportion": 5, "TimeOfDay": 6,
+    "TradeDirectionImbalance": 7, "TradeVolumeImbalance": 8, "BookImbalance": 9, "PriceRange": 10, "Price": 11,
+}  # fmt: skip
+
+
+def feature_desc(f):
+    d = dict(
+        kind=FEATURE_KINDS[type(f).__name__], lookback=int(f.lookback_periods), update_us=int(f.update_frequency / timedelta(microseconds=1)),
+        min_value=float(f.min_value), max_value=float(f.max_value), dparam=0.0, iparam=0,
+    )  # fmt: skip
+    if isinstance(f, EpisodeProportion):
+        d["dparam"] = float(f.step_size)
+    if isinstance(f, TimeOfDay):
+        d["iparam"] = int(f.bucket_size / timedelta(microseconds=1))
+    return d
+
+
+def run_trajectory(name, db, ticker, date, n_levels, features, agent_fn, n_episodes, starts, episode_s, step_s=0.1,
+                   step_reward="PnL", terminal_reward="PnL", enter_spread=False, inc_prev=False, moc=False, mofi=0.0,
+                   concentration=None, minq=0, maxq=10, initial=(0, 1000), outer_levels=20, top_k=12, stream_file=None):  # fmt: skip
+    step = timedelta(seconds=step_s)
+    episode = timedelta(seconds=episode_s)
+    warm = max(f.window_size for f in features)
+    gen = HistoricalOrderGenerator(ticker, db, True)
+    sim = OrderbookSimulator(ticker=ticker, order_generators=[gen], n_levels=n_levels, database=db, preload_orders=True,
+                             episode_length=episode, warm_up=warm, outer_levels=outer_levels)  # fmt: skip
+    env = HistoricalOrderbookEnvironment(
+        features=features, ticker=ticker, step_size=step, episode_length=episode,
+        initial_portfolio=Portfolio(inventory=initial[0], cash=initial[1]), min_quote_level=minq, max_quote_level=maxq,
+        min_date=date, max_date=date, simulator=sim, market_order_clearing=moc, inc_prev_action_in_obs=inc_prev,
+        per_step_reward_function=get_reward_function(step_reward), terminal_reward_function=get_reward_function(terminal_reward),
+        concentration=concentration, market_order_fraction_of_inventory=mofi, enter_spread=enter_spread, n_levels=n_levels,
+    )  # fmt: skip
+    captured = {}
+    orig_convert = env.convert_action_to_orders
+
+    def convert(action):
+        orders = orig_convert(action)
+        captured["orders"] = [(TYPE[type(o)], SIDE[o.direction], -1 if getattr(o, "price", None) is None else int(o.price), int(o.volume)) for o in orders]
+        return orders
+
+    env.convert_action_to_orders = convert
+    A = env.action_space.shape[0]
+    rec = dict(obs=[], reward=[], done=[], inventory=[], cash=[], price=[], now_us=[], top=[], actions=[], n_agent=[],
+               episode=[], fills=[], fill_off=[0], orders=[], order_off=[0], reset_obs=[], queues=[], queue_off=[0], n_resyncs=[])  # fmt: skip
+    day0 = datetime(date.year, date.month, date.day)
+    resyncs = {"n": 0}
+    orig_uol = sim.update_outer_levels
+
+    def uol():
+        resyncs["n"] += 1
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            orig_uol()
+
+    sim.update_outer_levels = uol
+    for ep in range(n_episodes):
+        start = starts[ep]
+        env.min_start_timedelta = timedelta(seconds=start)
+        env.max_end_timedelta = timedelta(seconds=start) + episode
+        resyncs["n"] = 0
+        obs = env.reset()
+        rec["reset_obs"].append(np.asarray(obs, dtype=np.float64))
+        agent = agent_fn(env, ep)
+        while True:
+            action = np.asarray(agent(obs), dtype=np.float64)
+            try:
+                obs, reward, done, info = env.step(action)
+            except (AssertionError, Exception) as exc:  # the reference crashes here; pin where and why
+                rec["crash"] = (len(rec["reward"]), type(exc).__name__)
+                rec["crash_action"] = action
+                break
+            rec["actions"].append(action)
+            rec["obs"].append(np.asarray(obs, dtype=np.float64))
+            rec["reward"].append(float(reward))
+            rec["done"].append(bool(done))
+            rec["inventory"].append(int(env.state.portfolio.inventory))
+            rec["cash"].append(int(env.state.portfolio.cash))
+            rec["price"].append(float(env.state.price))
+            rec["now_us"].append(int((env.state.now_is - day0) / timedelta(microseconds=1)))
+            rec["top"].append(dump_top(sim.exchange, top_k))
+            rec["n_agent"].append(sum(len(q) for s in ("buy", "sell") for q in getattr(sim.exchange.internal_orderbook, s).values()))
+            rec["episode"].append(ep)
+            rec["n_resyncs"].append(resyncs["n"])
+            rec["fills"] += fills_rows(env.state.filled_orders)
+            rec["fill_off"].append(len(rec["fills"]))
+            rec["orders"] += captured["orders"]
+            rec["order_off"].append(len(rec["orders"]))
+            if done:
+                break
+        q = dump_queues(sim.exchange)
+        rec["queues"].append(q)
+        rec["queue_off"].append(rec["queue_off"][-1] + len(q))
+    cfg = dict(
+        name=name, ticker=ticker, date=date.strftime("%Y-%m-%d"), n_levels=n_levels, tick_size=100, outer_levels=outer_levels,
+        min_quote_level=minq, max_quote_level=maxq, action_dim=A, use_concentration=concentration is not None,
+        concentration=0.0 if concentration is None else float(concentration), market_order_clearing=bool(moc),
+        market_order_fraction_of_inventory=float(mofi), enter_spread=bool(enter_spread), inc_prev_action_in_obs=bool(inc_prev),
+        step_us=int(step / timedelta(microseconds=1)), episode_us=int(episode / timedelta(microseconds=1)),
+        warmup_us=int(warm / timedelta(microseconds=1)), features=[feature_desc(f) for f in features],
+        per_step_reward=step_reward, terminal_reward=terminal_reward, initial_inventory=initial[0], initial_cash=initial[1],
+        starts_us=[int(s * 10**6) for s in starts[:n_episodes]], stream_file=stream_file, top_k=top_k,
+    )  # fmt: skip
+    out = dict(
+        cfg=np.array(json.dumps(cfg)), obs=np.array(rec["obs"]), reward=np.array(rec["reward"]), done=np.array(rec["done"]),
+        inventory=np.array(rec["inventory"], dtype=np.int64), cash=np.array(rec["cash"], dtype=np.int64), price=np.array(rec["price"]),
+        now_us=np.array(rec["now_us"], dtype=np.int64), top=np.array(rec["top"], dtype=np.int64), actions=np.array(rec["actions"]),
+        n_agent=np.array(rec["n_agent"]), episode=np.array(rec["episode"]), n_resyncs=np.array(rec["n_resyncs"]),
+        fills=np.array(rec["fills"], dtype=np.int64).reshape(-1, 4), fill_off=np.array(rec["fill_off"]),
+        orders=np.array(rec["orders"], dtype=np.int64).reshape(-1, 4), order_off=np.array(rec["order_off"]),
+        reset_obs=np.array(rec["reset_obs"]), queues=np.concatenate(rec["queues"]), queue_off=np.array(rec["queue_off"]),
+        crash_step=np.array(rec["crash"][0] if "crash" in rec else -1), crash_type=np.array(rec["crash"][1] if "crash" in rec else ""),
+        crash_action=np.array(rec.get("crash_action", np.zeros(A))),
+    )  # fmt: skip
+    np.savez_compressed(GOLD / f"traj_{name}.npz", **out)
+    print(f"traj_{name}: {len(rec['reward'])} steps, final inv {rec['inventory'][-1]} cash {rec['cash'][-1]}, "
+          f"{len(rec['fills'])} fills, resyncs {rec['n_resyncs'][-1]}, max agent orders {max(rec['n_agent'])}")  # fmt: skip
+
+
+def fixed_agent(action):
+    return lambda env, ep: FixedActionAgent(np.array(action, dtype=float)).get_action
+
+
+def random_agent(seed, high=10.0):
+    def make(env, ep):
+        rng = np.random.Generator(np.random.PCG64(seed + ep))
+        low, hi = env.action_space.low, np.minimum(env.action_space.high, high if env.action_space.shape[0] <= 4 else np.inf)
+        return lambda obs: rng.uniform(low, hi)
+
+    return make
+
+
+def teradactyl_agent(inventory_index, **kw):
+    return lambda env, ep: Teradactyl(inventory_index=inventory_index, **kw).get_action
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# G2 / G8 simulator-level goldens on the MSFT slice
+# ---------------------------------------------------------------------------------------------------------------
+def gen_replay_msft(db):
+    ticker, L = "MSFT", 50
+    gen = HistoricalOrderGenerator(ticker, db, preload_orders=False)
+    sim = OrderbookSimulator(ticker, Exchange(ticker), [gen], L, db, preload_orders=False, outer_levels=48)
+    day0 = datetime(2012, 6, 21)
+    start = datetime(2012, 6, 21, 10, 0, 0)
+    sim.reset_episode(start)
+    tops, times, ext_fills, fill_off = [dump_top(sim.exchange, L + 5)], [36000 * 10**6], [], [0]
+    t = start
+    import contextlib, io
+    for k in range(27):  # 100 ms steps to 10:00:02.7
+        t = t + timedelta(milliseconds=100)
+        with warnings.catch_warnings(), contextlib.redirect_stdout(io.StringIO()):
+            warnings.simplefilter("ignore")
+            filled = sim.forward_step(t)
+        tops.append(dump_top(sim.exchange, L + 5))
+        times.append(int((t - day0) / timedelta(microseconds=1)))
+        ext_fills += fills_rows(filled)
+        fill_off.append(len(ext_fills))
+    np.savez_compressed(
+        GOLD / "replay_msft.npz", tops=np.array(tops), times=np.array(times), fills=np.array(ext_fills, dtype=np.int64).reshape(-1, 4),
+        fill_off=np.array(fill_off), queues=dump_queues(sim.exchange), min_buy=np.array(sim.min_buy_price), max_sell=np.array(sim.max_sell_price),
+    )  # fmt: skip
+    print("replay_msft", len(times), "checkpoints", len(ext_fills), "fills")
+
+
+def gen_resync_msft(db):
+    """testOrderbookSimulator.test_update_outer_levels_with_internal_orders, with state dumps."""
+    ticker, L = "MSFT", 50
+    gen = HistoricalOrderGenerator(ticker, db, preload_orders=False)
+    sim = OrderbookSimulator(ticker, Exchange(ticker), [gen], L, db, preload_orders=False, outer_levels=48)
+    start = datetime(2012, 6, 21, 10, 0, 0)
+    sim.reset_episode(start)
+    ob = sim.exchange.central_orderbook
+    wb, ws = min(ob.buy.keys()), max(ob.sell.keys())
+    internal_buy = LimitOrder(timestamp=start, price=wb - 100, volume=100, direction="buy", ticker=ticker, internal_id=None, external_id=None, is_external=False)
+    internal_sell = LimitOrder(timestamp=start, price=ws, volume=200, direction="sell", ticker=ticker, internal_id=None, external_id=None, is_external=False)
+    import contextlib, io
+    with warnings.catch_warnings(), contextlib.redirect_stdout(io.StringIO()):
+        warnings.simplefilter("ignore")
+        sim.forward_step(start + timedelta(seconds=1), internal_orders=[internal_buy, internal_sell])
+    np.savez_compressed(
+        GOLD / "resync_msft.npz", agent_orders=np.array([[1, 0, wb - 100, 100, 0, 0], [1, 1, ws, 200, 0, 0]], dtype=np.int64),
+        queues=dump_queues(sim.exchange), min_buy=np.array(sim.min_buy_price), max_sell=np.array(sim.max_sell_price),
+        start_us=np.array(36000 * 10**6), until_us=np.array(36001 * 10**6),
+    )  # fmt: skip
+    print("resync_msft min_buy", sim.min_buy_price, "max_sell", sim.max_sell_price)
+
+
+def main():
+    GOLD.mkdir(parents=True, exist_ok=True)
+    # G0: the reference's own data file, kept as a test fixture (gzip for the wide orderbook file)
+    msg = REF_DATA / "MSFT_2012-06-21_34200000_37800000_message_50.csv"
+    book = REF_DATA / "MSFT_2012-06-21_34200000_37800000_orderbook_50.csv"
+    shutil.copyfile(msg, GOLD / "msft_message_50.csv")
+    with open(book, "rb") as f, gzip.GzipFile(GOLD / "msft_orderbook_50.csv.gz", "wb", mtime=0) as g:
+        g.write(f.read())
+
+    gen_beta_table()
+    gen_engine_cases()
+
+    date = datetime(2012, 6, 21)
+    db_all = make_db(REF_DATA, "MSFT", date, 50, None, max_rows=1000, batch_size=1000)
+    gen_replay_msft(db_all)
+    gen_resync_msft(db_all)
+
+    test_feats = lambda: [Inventory(), Spread(), PriceMove(lookback_periods=1), PriceRange(lookback_periods=1)]  # noqa: E731
+    run_trajectory("msft_fixed", db_all, "MSFT", date, 50, test_feats(), fixed_agent([1, 2, 1, 2]), 2, [36001, 36001], 1.0, stream_file="msft")
+    run_trajectory("msft_teradactyl_ad", db_all, "MSFT", date, 50, test_feats(), teradactyl_agent(0, max_inventory=100, default_kappa=7.0, max_kappa=9.0), 1, [36001], 1.0,
+                   step_reward="AD", terminal_reward="AD", stream_file="msft")  # fmt: skip
+    more_feats = [Spread(), BookImbalance(), Price(update_frequency=timedelta(seconds=0.1)), PriceMove(name="pm", update_frequency=timedelta(seconds=0.2), lookback_periods=3),
+                  PriceRange(update_frequency=timedelta(seconds=0.1), lookback_periods=10), Volatility(update_frequency=timedelta(seconds=0.1), lookback_periods=5),
+                  TradeDirectionImbalance(update_frequency=timedelta(seconds=0.1), lookback_periods=4), TradeVolumeImbalance(update_frequency=timedelta(seconds=0.1), lookback_periods=4),
+                  Inventory(), EpisodeProportion(update_frequency=timedelta(seconds=0.1), episode_length=timedelta(seconds=1))]  # fmt: skip
+    run_trajectory("msft_random_allfeat", db_all, "MSFT", date, 50, more_feats, random_agent(3), 1, [36001], 1.0, step_reward="SD", terminal_reward="PnL",
+                   inc_prev=True, stream_file="msft")  # fmt: skip
+
+    # synthetic SPY-shaped stream, 10 levels, 1 s snapshots: same bytes go to the reference (CSV -> sqlite) and,
+    # packed, to the oracle / HIP tests
+    tmp = Path(tempfile.mkdtemp(prefix="golden_synth_"))
+    try:
+        sdate = datetime(2018, 2, 21)
+        g = generate_lobster(20180221, 10, 200.0, 9.5 * 3600 + 1490, 9.5 * 3600 + 1490 + 420)  # 09:54:50 - 10:01:50
+        mpath, bpath = write_lobster_csv(g, tmp, "SYN", "2018-02-21", 10)
+        ps = pack_lobster(mpath, bpath, "SYN", "2018-02-21", 10, "S")
+        ps.save(GOLD / "synth_small.npz")
+        print("synth_small", ps.n_msgs, "msgs", ps.n_snaps, "snaps")
+        db_s = make_db(tmp, "SYN", sdate, 10, "S")
+        default = lambda ep_s: HistoricalOrderbookEnvironment.get_default_features(timedelta(seconds=0.1), timedelta(seconds=ep_s))  # noqa: E731
+        # default full_state features (5 min warm-up), random Beta-policy actions, two episodes on one env (Q7)
+        run_trajectory("synth_default_random", db_s, "SYN", sdate, 10, default(30), random_agent(42), 2, [36000, 36040], 30.0, stream_file="synth_small")
+        short = lambda: [Spread(), PriceMove(name="pm1", update_frequency=timedelta(seconds=0.1), lookback_periods=1), Volatility(name="v", update_frequency=timedelta(seconds=0.1), lookback_periods=20),  # noqa: E731
+                         Inventory(), EpisodeProportion(update_frequency=timedelta(seconds=0.1), episode_length=timedelta(seconds=20)), TimeOfDay(),
+                         TradeDirectionImbalance(update_frequency=timedelta(seconds=0.1), lookback_periods=30), TradeVolumeImbalance(update_frequency=timedelta(seconds=0.1), lookback_periods=30)]  # fmt: skip
+        run_trajectory("synth_teradactyl_ad_spread", db_s, "SYN", sdate, 10, short(), teradactyl_agent(3, max_inventory=300), 1, [35920], 20.0,
+                       step_reward="AD", terminal_reward="AD", enter_spread=True, inc_prev=True, stream_file="synth_small")  # fmt: skip
+        run_trajectory("synth_moc_conc", db_s, "SYN", sdate, 10, short(), random_agent(9, high=40.0), 1, [35960], 20.0, step_reward="SD", terminal_reward="PnL",
+                       moc=True, mofi=1.0, concentration=12.0, initial=(0, 10**12), stream_file="synth_small")  # fmt: skip
+        # market_order_fraction 0.5 rounds a 1-share inventory to a 0-volume market order: the reference asserts
+        run_trajectory("synth_moc_crash", db_s, "SYN", sdate, 10, short(), random_agent(9, high=40.0), 1, [35960], 20.0, step_reward="SD", terminal_reward="PnL",
+                       moc=True, mofi=0.5, concentration=12.0, initial=(0, 10**12), stream_file="synth_small")  # fmt: skip
+        run_trajectory("synth_q5_fixed", db_s, "SYN", sdate, 10, short(), fixed_agent([2, 5, 5, 2]), 1, [36010], 20.0, minq=2, maxq=7, stream_file="synth_small")
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

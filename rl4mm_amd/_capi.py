@@ -1,0 +1,345 @@
+"""ctypes view of include/lobsim.h: struct layouts, function prototypes and a thin numpy-facing wrapper.
+
+The binding is parameterised by (shared library, symbol prefix) so the parity tests can drive the CPU oracle
+(``oracle_*`` symbols of oracle/liblobsim_oracle.so, loaded only from tests/ and bench.py's cpu_baseline) through
+exactly the same calls as the product library (``lobsim_*`` symbols of rl4mm_amd/csrc/liblobsim.so).  Nothing in
+this package ever opens the oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+MAX_FEATURES = 16
+MAX_ACTION_DIM = 5
+
+# status bits (include/lobsim.h: enum lobsim_status)
+ST_EMPTY_BOOK, ST_BAD_MESSAGE, ST_LEVEL_OVERFLOW, ST_QUEUE_OVERFLOW = 1, 2, 4, 8
+ST_AGENT_OVERFLOW, ST_STREAM_END, ST_ASSERT, ST_NOT_RESET = 16, 32, 64, 128
+
+F_SPREAD, F_PRICE_MOVE, F_VOLATILITY, F_INVENTORY, F_EPISODE_PROPORTION, F_TIME_OF_DAY = 1, 2, 3, 4, 5, 6
+F_TRADE_DIRECTION_IMBALANCE, F_TRADE_VOLUME_IMBALANCE, F_BOOK_IMBALANCE, F_PRICE_RANGE, F_PRICE = 7, 8, 9, 10, 11
+R_PNL, R_INVENTORY_ADJUSTED = 1, 2
+
+
+class FeatureDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("lookback", C.c_int32),
+        ("update_us", C.c_int64),
+        ("min_value", C.c_double),
+        ("max_value", C.c_double),
+        ("dparam", C.c_double),
+        ("iparam", C.c_int64),
+    ]
+
+
+class RewardDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("asymmetrically_dampened", C.c_int32), ("inventory_aversion", C.c_double)]
+
+
+class Cfg(C.Structure):
+    _fields_ = [
+        ("n_envs", C.c_int32),
+        ("n_levels", C.c_int32),
+        ("tick_size", C.c_int32),
+        ("outer_levels", C.c_int32),
+        ("min_quote_level", C.c_int32),
+        ("max_quote_level", C.c_int32),
+        ("action_dim", C.c_int32),
+        ("use_concentration", C.c_int32),
+        ("market_order_clearing", C.c_int32),
+        ("enter_spread", C.c_int32),
+        ("inc_prev_action_in_obs", C.c_int32),
+        ("n_features", C.c_int32),
+        ("device_id", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("step_us", C.c_int64),
+        ("episode_us", C.c_int64),
+        ("warmup_us", C.c_int64),
+        ("concentration", C.c_double),
+        ("market_order_fraction_of_inventory", C.c_double),
+        ("per_step_reward", RewardDesc),
+        ("terminal_reward", RewardDesc),
+        ("features", FeatureDesc * MAX_FEATURES),
+    ]
+
+
+class EnvState(C.Structure):
+    _fields_ = [
+        ("now_us", C.c_int64),
+        ("terminal_us", C.c_int64),
+        ("inventory", C.c_int64),
+        ("cash", C.c_int64),
+        ("price", C.c_double),
+        ("best_buy", C.c_int64),
+        ("best_sell", C.c_int64),
+        ("min_buy_price", C.c_int64),
+        ("max_sell_price", C.c_int64),
+        ("initial_buy_range", C.c_int64),
+        ("initial_sell_range", C.c_int64),
+        ("n_buy_levels", C.c_int32),
+        ("n_sell_levels", C.c_int32),
+        ("n_agent_orders", C.c_int32),
+        ("status", C.c_int32),
+        ("stream_id", C.c_int32),
+        ("n_resyncs", C.c_int32),
+        ("agent_fill_count", C.c_int64),
+        ("agent_buy_volume", C.c_int64),
+        ("agent_sell_volume", C.c_int64),
+        ("ext_buy_count", C.c_int64),
+        ("ext_sell_count", C.c_int64),
+        ("ext_buy_volume", C.c_int64),
+        ("ext_sell_volume", C.c_int64),
+    ]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class OrderView(C.Structure):
+    _fields_ = [("id", C.c_int64), ("volume", C.c_int64), ("kind", C.c_int32), ("reserved", C.c_int32)]
+
+
+ORDER_VIEW_DTYPE = np.dtype([("id", "<i8"), ("volume", "<i8"), ("kind", "<i4"), ("reserved", "<i4")])
+
+_P64 = C.POINTER(C.c_int64)
+_P32 = C.POINTER(C.c_int32)
+_PD = C.POINTER(C.c_double)
+_PF = C.POINTER(C.c_float)
+_PU8 = C.POINTER(C.c_uint8)
+
+# name -> (restype, argtypes); every symbol include/lobsim.h declares
+PROTOTYPES = {
+    "create": (C.c_int, [C.POINTER(Cfg), C.POINTER(C.c_void_p)]),
+    "destroy": (None, [C.c_void_p]),
+    "last_error": (C.c_char_p, [C.c_void_p]),
+    "set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "add_stream": (C.c_int, [C.c_void_p, _P64, C.c_int64, _P64, C.c_int64]),
+    "set_portfolio": (C.c_int, [C.c_void_p, _P32, C.c_int32, _P64, _P64]),
+    "reset": (C.c_int, [C.c_void_p, _P32, C.c_int32, _P32, _P64, _PD]),
+    "step": (C.c_int, [C.c_void_p, _PD, _PU8, _PD, _PD, _PU8]),
+    "step_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sync": (C.c_int, [C.c_void_p]),
+    "obs_dim": (C.c_int, [C.c_void_p]),
+    "get_env_state": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(EnvState)]),
+    "get_portfolios": (C.c_int, [C.c_void_p, _P64, _P64, _PD]),
+    "get_book": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _P64, _P64, _P32, C.c_int32, _P32]),
+    "get_level_orders": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(OrderView), C.c_int32, _P32]),
+    "debug_set_book": (C.c_int, [C.c_void_p, C.c_int32, _P64, C.c_int64]),
+    "debug_process_orders": (C.c_int, [C.c_void_p, C.c_int32, _P64, C.c_int32, _P64]),
+}
+# the oracle has no device entry points
+ORACLE_SKIP = {"set_stream", "step_device", "sync"}
+
+
+def _ptr(a: Optional[np.ndarray], typ):
+    return None if a is None else a.ctypes.data_as(typ)
+
+
+class LobsimError(RuntimeError):
+    pass
+
+
+class Binding:
+    """Function table of one shared library."""
+
+    def __init__(self, path: str, prefix: str = "lobsim_", skip: Sequence[str] = ()):
+        self.path = str(path)
+        self.prefix = prefix
+        self.lib = C.CDLL(self.path)
+        self.fn = {}
+        for name, (res, args) in PROTOTYPES.items():
+            if name in skip:
+                continue
+            f = getattr(self.lib, prefix + name)  # AttributeError if the library lacks a declared symbol
+            f.restype = res
+            f.argtypes = args
+            self.fn[name] = f
+
+
+def make_feature(kind, lookback=0, update_us=100_000, min_value=0.0, max_value=0.0, dparam=0.0, iparam=0) -> FeatureDesc:
+    return FeatureDesc(int(kind), int(lookback), int(update_us), float(min_value), float(max_value), float(dparam), int(iparam))
+
+
+def make_cfg(
+    n_envs: int,
+    n_levels: int,
+    features: Sequence[FeatureDesc],
+    step_us: int = 100_000,
+    episode_us: int = 1_800_000_000,
+    warmup_us: Optional[int] = None,
+    tick_size: int = 100,
+    outer_levels: int = 20,
+    min_quote_level: int = 0,
+    max_quote_level: int = 10,
+    concentration: Optional[float] = None,
+    market_order_clearing: bool = False,
+    market_order_fraction_of_inventory: float = 0.0,
+    enter_spread: bool = False,
+    inc_prev_action_in_obs: bool = False,
+    per_step_reward=(R_PNL, 0, 0.0),
+    terminal_reward=(R_PNL, 0, 0.0),
+    device_id: int = 0,
+) -> Cfg:
+    cfg = Cfg()
+    cfg.n_envs, cfg.n_levels, cfg.tick_size, cfg.outer_levels = n_envs, n_levels, tick_size, outer_levels
+    cfg.min_quote_level, cfg.max_quote_level = min_quote_level, max_quote_level
+    cfg.use_concentration = int(concentration is not None)
+    cfg.concentration = float(concentration or 0.0)
+    cfg.action_dim = (2 if concentration is not None else 4) + int(bool(market_order_clearing))
+    cfg.market_order_clearing = int(bool(market_order_clearing))
+    cfg.market_order_fraction_of_inventory = float(market_order_fraction_of_inventory)
+    cfg.enter_spread = int(bool(enter_spread))
+    cfg.inc_prev_action_in_obs = int(bool(inc_prev_action_in_obs))
+    assert len(features) <= MAX_FEATURES
+    cfg.n_features = len(features)
+    for i, f in enumerate(features):
+        cfg.features[i] = f
+    cfg.step_us, cfg.episode_us = int(step_us), int(episode_us)
+    if warmup_us is None:
+        warmup_us = max([f.lookback * f.update_us for f in features] + [0])
+    cfg.warmup_us = int(warmup_us)
+    cfg.per_step_reward = RewardDesc(*per_step_reward)
+    cfg.terminal_reward = RewardDesc(*terminal_reward)
+    cfg.device_id = device_id
+    return cfg
+
+
+class Sim:
+    """One simulator handle behind a :class:`Binding` (numpy in, numpy out)."""
+
+    def __init__(self, binding: Binding, cfg: Cfg):
+        self.b = binding
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        rc = binding.fn["create"](C.byref(cfg), C.byref(self.h))
+        if rc != 0 or not self.h:
+            raise LobsimError(f"{binding.prefix}create failed with code {rc}")
+        self.n_envs = cfg.n_envs
+        self.action_dim = cfg.action_dim
+        self.obs_dim = binding.fn["obs_dim"](self.h)
+        self._streams = []
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.b.fn["last_error"](self.h)
+            raise LobsimError(f"{self.b.prefix}{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def close(self):
+        if self.h:
+            self.b.fn["destroy"](self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- data -----------------------------------------------------------------------------------------------
+    def add_stream(self, stream) -> int:
+        assert stream.n_levels == self.cfg.n_levels, "stream depth must equal cfg.n_levels"
+        msgs = np.ascontiguousarray(stream.msgs, dtype=np.int64)
+        snaps = np.ascontiguousarray(stream.snaps, dtype=np.int64)
+        sid = self.b.fn["add_stream"](self.h, _ptr(msgs, _P64), msgs.shape[0], _ptr(snaps, _P64), snaps.shape[0])
+        if sid < 0:
+            self._check(sid, "add_stream")
+        self._streams.append(stream)
+        return sid
+
+    def set_portfolio(self, inventory, cash, env_ids=None):
+        ids = np.arange(self.n_envs, dtype=np.int32) if env_ids is None else np.ascontiguousarray(env_ids, dtype=np.int32)
+        inv = np.ascontiguousarray(np.broadcast_to(np.asarray(inventory, dtype=np.int64), ids.shape))
+        csh = np.ascontiguousarray(np.broadcast_to(np.asarray(cash, dtype=np.int64), ids.shape))
+        self._check(self.b.fn["set_portfolio"](self.h, _ptr(ids, _P32), len(ids), _ptr(inv, _P64), _ptr(csh, _P64)), "set_portfolio")
+
+    # ---- env API ---------------------------------------------------------------------------------------------
+    def reset(self, episode_start_us, stream_ids=0, env_ids=None) -> np.ndarray:
+        ids = np.arange(self.n_envs, dtype=np.int32) if env_ids is None else np.ascontiguousarray(env_ids, dtype=np.int32)
+        sids = np.ascontiguousarray(np.broadcast_to(np.asarray(stream_ids, dtype=np.int32), ids.shape))
+        starts = np.ascontiguousarray(np.broadcast_to(np.asarray(episode_start_us, dtype=np.int64), ids.shape))
+        obs = np.zeros((len(ids), self.obs_dim), dtype=np.float64)
+        self._check(self.b.fn["reset"](self.h, _ptr(ids, _P32), len(ids), _ptr(sids, _P32), _ptr(starts, _P64), _ptr(obs, _PD)), "reset")
+        return obs
+
+    def step(self, actions, active=None):
+        actions = np.ascontiguousarray(actions, dtype=np.float64).reshape(self.n_envs, self.action_dim)
+        act = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
+        obs = np.zeros((self.n_envs, self.obs_dim), dtype=np.float64)
+        reward = np.zeros(self.n_envs, dtype=np.float64)
+        done = np.zeros(self.n_envs, dtype=np.uint8)
+        self._check(self.b.fn["step"](self.h, _ptr(actions, _PD), _ptr(act, _PU8), _ptr(obs, _PD), _ptr(reward, _PD), _ptr(done, _PU8)), "step")
+        return obs, reward, done
+
+    def step_device(self, d_actions: int, d_active: int, d_obs: int, d_obs_f32: int, d_reward: int, d_done: int):
+        self._check(self.b.fn["step_device"](self.h, d_actions, d_active, d_obs, d_obs_f32, d_reward, d_done), "step_device")
+
+    def sync(self):
+        self._check(self.b.fn["sync"](self.h), "sync")
+
+    def set_stream(self, hip_stream: int):
+        self._check(self.b.fn["set_stream"](self.h, hip_stream), "set_stream")
+
+    # ---- inspection ------------------------------------------------------------------------------------------
+    def env_state(self, env: int) -> dict:
+        st = EnvState()
+        self._check(self.b.fn["get_env_state"](self.h, env, C.byref(st)), "get_env_state")
+        return st.as_dict()
+
+    def portfolios(self):
+        inv = np.zeros(self.n_envs, dtype=np.int64)
+        cash = np.zeros(self.n_envs, dtype=np.int64)
+        price = np.zeros(self.n_envs, dtype=np.float64)
+        self._check(self.b.fn["get_portfolios"](self.h, _ptr(inv, _P64), _ptr(cash, _P64), _ptr(price, _PD)), "get_portfolios")
+        return inv, cash, price
+
+    def book(self, env: int, side: int, max_levels: int = 256):
+        prices = np.zeros(max_levels, dtype=np.int64)
+        vols = np.zeros(max_levels, dtype=np.int64)
+        cnt = np.zeros(max_levels, dtype=np.int32)
+        n = C.c_int32(0)
+        self._check(self.b.fn["get_book"](self.h, env, side, _ptr(prices, _P64), _ptr(vols, _P64), _ptr(cnt, _P32), max_levels, C.byref(n)), "get_book")
+        return prices[: n.value], vols[: n.value], cnt[: n.value]
+
+    def level_orders(self, env: int, side: int, price: int, max_orders: int = 1024) -> np.ndarray:
+        out = np.zeros(max_orders, dtype=ORDER_VIEW_DTYPE)
+        n = C.c_int32(0)
+        self._check(
+            self.b.fn["get_level_orders"](self.h, env, side, int(price), out.ctypes.data_as(C.POINTER(OrderView)), max_orders, C.byref(n)),
+            "get_level_orders",
+        )
+        return out[: n.value]
+
+    def queues(self, env: int) -> np.ndarray:
+        """Whole central book as int64 rows (side, price, kind, id, volume), best level first, FIFO inside - the
+        format of oracle/gen_golden.py:dump_queues."""
+        rows = []
+        for side in (0, 1):
+            prices, _, _ = self.book(env, side, 1024)
+            for p in prices:
+                for o in self.level_orders(env, side, int(p)):
+                    rows.append((side, int(p), int(o["kind"]), int(o["id"]), int(o["volume"])))
+        return np.array(rows, dtype=np.int64).reshape(-1, 5)
+
+    def top(self, env: int, k: int) -> np.ndarray:
+        out = np.zeros((2, k, 3), dtype=np.int64)
+        for side in (0, 1):
+            p, v, c = self.book(env, side, k)
+            out[side, : len(p), 0], out[side, : len(p), 1], out[side, : len(p), 2] = p, v, c
+        return out
+
+    # ---- engine-level ----------------------------------------------------------------------------------------
+    def debug_set_book(self, env: int, snapshot_row: Optional[np.ndarray], now_us: int = 0):
+        row = None if snapshot_row is None else np.ascontiguousarray(snapshot_row, dtype=np.int64)
+        if row is not None:
+            assert row.size == 4 * self.cfg.n_levels
+        self._check(self.b.fn["debug_set_book"](self.h, env, _ptr(row, _P64), int(now_us)), "debug_set_book")
+
+    def debug_process_orders(self, env: int, orders) -> np.ndarray:
+        orders = np.ascontiguousarray(orders, dtype=np.int64).reshape(-1, 6)
+        fills = np.zeros(8, dtype=np.int64)
+        self._check(self.b.fn["debug_process_orders"](self.h, env, _ptr(orders, _P64), orders.shape[0], _ptr(fills, _P64)), "debug_process_orders")
+        return fills

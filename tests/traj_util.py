@@ -1,0 +1,63 @@
+"""Replay a golden trajectory (oracle/gen_golden.py format) through any Sim (oracle or HIP) and compare."""
+import numpy as np
+
+
+def replay_and_check(sim, g, z, stream_id, obs_rtol=0.0, obs_atol=0.0, check_fills=None, label=""):
+    """Drives env 0 of `sim` with the golden actions.  Integers must match exactly; floats within
+    (rtol, atol) - 0/0 means bit-exact."""
+    top_k = g["top_k"]
+    k = 0
+    n_steps = len(z["reward"])
+    crash_step = int(z["crash_step"])
+    sim.set_portfolio(g["initial_inventory"], g["initial_cash"])
+    n_eps = len(g["starts_us"])
+    for ep in range(n_eps):
+        if k >= n_steps and crash_step < 0:
+            break
+        obs0 = sim.reset(g["starts_us"][ep], stream_id)
+        _close(obs0[0], z["reset_obs"][ep], obs_rtol, obs_atol, f"{label} reset obs ep {ep}")
+        while True:
+            if k == crash_step:  # the reference raised here: we must flag the env instead
+                obs, reward, done = sim.step(z["crash_action"][None, :])
+                st = sim.env_state(0)
+                assert done[0] == 1 and st["status"] != 0, f"{label}: reference crashed ({z['crash_type']}) at step {k}, status {st['status']}"
+                return
+            obs, reward, done = sim.step(z["actions"][k][None, :])
+            st = sim.env_state(0)
+            ctx = f"{label} step {k} (episode {ep})"
+            assert st["status"] == 0, f"{ctx}: status {st['status']}"
+            assert st["inventory"] == z["inventory"][k], f"{ctx}: inventory {st['inventory']} != {z['inventory'][k]}"
+            assert st["cash"] == z["cash"][k], f"{ctx}: cash {st['cash']} != {z['cash'][k]}"
+            assert st["now_us"] == z["now_us"][k], ctx
+            assert st["n_agent_orders"] == z["n_agent"][k], f"{ctx}: agent orders {st['n_agent_orders']} != {z['n_agent'][k]}"
+            assert st["n_resyncs"] == z["n_resyncs"][k], f"{ctx}: resyncs {st['n_resyncs']} != {z['n_resyncs'][k]}"
+            fl = z["fills"][z["fill_off"][k] : z["fill_off"][k + 1]]
+            agent, ext = fl[fl[:, 0] == 0], fl[fl[:, 0] == 1]
+            assert st["agent_fill_count"] == len(agent), f"{ctx}: agent fills {st['agent_fill_count']} != {len(agent)}"
+            assert st["agent_buy_volume"] == agent[agent[:, 1] == 0][:, 3].sum(), ctx
+            assert st["agent_sell_volume"] == agent[agent[:, 1] == 1][:, 3].sum(), ctx
+            assert st["ext_buy_count"] == (ext[:, 1] == 0).sum() and st["ext_sell_count"] == (ext[:, 1] == 1).sum(), f"{ctx}: ext fill counts"
+            assert st["ext_buy_volume"] == ext[ext[:, 1] == 0][:, 3].sum() and st["ext_sell_volume"] == ext[ext[:, 1] == 1][:, 3].sum(), f"{ctx}: ext fill volumes"
+            if check_fills is not None:
+                check_fills(k, fl)
+            top = sim.top(0, top_k)
+            assert np.array_equal(top, z["top"][k]), f"{ctx}: top of book differs\n{top[:, :4]}\n{z['top'][k][:, :4]}"
+            _close(st["price"], z["price"][k], obs_rtol, obs_atol, f"{ctx} price")
+            _close(obs[0], z["obs"][k], obs_rtol, obs_atol, f"{ctx} obs")
+            _close(reward[0], z["reward"][k], 0.0, max(obs_atol, 1e-9) if obs_atol or obs_rtol else 0.0, f"{ctx} reward")
+            assert bool(done[0]) == bool(z["done"][k]), f"{ctx}: done"
+            k += 1
+            if done[0]:
+                break
+        q = sim.queues(0)
+        qe = z["queues"][z["queue_off"][ep] : z["queue_off"][ep + 1]]
+        assert np.array_equal(q, qe), f"{label}: full queue dump differs at end of episode {ep}"
+    assert k == n_steps
+
+
+def _close(a, b, rtol, atol, what):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    if rtol == 0.0 and atol == 0.0:
+        assert np.array_equal(a, b), f"{what}: {a} != {b} (diff {a - b})"
+    else:
+        assert np.allclose(a, b, rtol=rtol, atol=atol), f"{what}: {a} !~ {b} (diff {a - b})"
