@@ -1,0 +1,55 @@
+"""Loader of the product library rl4mm_amd/csrc/liblobsim.so (HIP kernels + C-ABI of include/lobsim.h).
+
+There is no CPU fallback: if the library cannot be built or loaded this raises, and ``lobsim_create`` itself
+fails when no GPU is visible.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+from . import _capi
+
+CSRC = Path(__file__).resolve().parent / "csrc"
+LIB_PATH = CSRC / "liblobsim.so"
+SOURCES = [CSRC / "lobsim_kernels.hip", CSRC / "lobsim_host.inc", CSRC / "lobsim_layout.h", CSRC.parent.parent / "include" / "lobsim.h"]
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+
+_binding = None
+
+
+def _stale() -> bool:
+    if not LIB_PATH.exists():
+        return True
+    t = LIB_PATH.stat().st_mtime
+    return any(s.exists() and s.stat().st_mtime > t for s in SOURCES)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """hipcc --offload-arch=gfx950 -> liblobsim.so (in-tree, so it travels with the repo snapshot)."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("liblobsim.so is missing or stale and hipcc was not found: cannot build the HIP library")
+    cmd = [hipcc, *HIPCC_FLAGS, "-o", str(LIB_PATH), str(SOURCES[0])]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    subprocess.check_call(cmd, cwd=str(CSRC))
+    return LIB_PATH
+
+
+def binding() -> _capi.Binding:
+    global _binding
+    if _binding is None:
+        if _stale():
+            build()
+        _binding = _capi.Binding(LIB_PATH, prefix="lobsim_")
+    return _binding
+
+
+def new_sim(cfg) -> _capi.Sim:
+    """lobsim_create on the HIP library; raises LobsimError when no GPU is available."""
+    return _capi.Sim(binding(), cfg)

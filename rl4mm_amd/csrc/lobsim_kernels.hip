@@ -1,0 +1,1153 @@
+// lobsim_kernels.hip - CDNA4 (gfx950) kernels of the LOB simulation step: one wavefront per env.
+//
+// What runs here (reference file:line, paths relative to /root/reference):
+//   matching engine     rl4mm/orderbook/Exchange.py:58-247            -> submit_limit / execute / remove_order
+//   simulator step      rl4mm/simulation/OrderbookSimulator.py:70-135  -> advance_one_step / resync_outer_levels
+//   episode reset       OrderbookSimulator.py:55-68,156-188            -> load_snapshot_book
+//   action -> orders    rl4mm/gym/HistoricalOrderbookEnvironment.py:206-331,
+//                       rl4mm/gym/action_interpretation/OrderDistributors.py:39-56 -> build_agent_ops
+//   features, rewards   rl4mm/features/Features.py, rl4mm/rewards/RewardFunctions.py -> feature_apply / reward_of
+//
+// Execution model: blockDim = 64 = one wave = one env.  The price ladder (sorted, best first), the agent's live
+// orders and the agent op list are staged in LDS for the launch; each price level's FIFO queue is a fixed slab
+// of 16-byte slots in HBM read 1 KiB per wave-instruction.  Lookup by id, "is the head a snapshot order",
+// queue compaction and sweeping a level with a market order are ballot / prefix-sum operations over that slab.
+// All arithmetic that the reference does on Python ints is int32/int64 here; everything it does on Python floats
+// is f64 in the same operation order (compile with -ffp-contract=off).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lobsim_layout.h"
+
+namespace lobk {
+
+#define DI __device__ __forceinline__
+
+struct Lds {
+    int64_t price[2][LV];
+    int64_t vol[2][LV];
+    uint16_t slab[2][LV];
+    uint16_t head[2][LV];
+    uint16_t tail[2][LV];
+    uint16_t live[2][LV];
+    AgentOrd agent[NA];
+    Op ops[OPS_MAX];
+    int32_t cur[2][QMAX];
+    double pdf[2][QMAX];
+};
+
+// wave-uniform scalars of the env being advanced (kept in registers)
+template <typename T>
+struct Pair {  // two wave-uniform values selected by side; kept as two registers (no dynamic register indexing)
+    T a, b;
+    DI T operator[](int i) const { return i ? b : a; }
+    DI void set(int i, T v) { if (i) b = v; else a = v; }
+    DI void add(int i, T v) { if (i) b += v; else a += v; }
+};
+template <int N>
+struct Mask {  // N x 64-bit mask with uniform bit access through unrolled selects
+    uint64_t w[N];
+    DI void fill(uint64_t v) {
+#pragma unroll
+        for (int i = 0; i < N; i++) w[i] = v;
+    }
+    DI void set(int bit) {
+#pragma unroll
+        for (int i = 0; i < N; i++) if ((bit >> 6) == i) w[i] |= 1ull << (bit & 63);
+    }
+    DI int take_first() {  // clears and returns the lowest set bit, -1 if empty
+        int r = -1;
+#pragma unroll
+        for (int i = 0; i < N; i++)
+            if (r < 0 && w[i]) { int b = __ffsll((unsigned long long)w[i]) - 1; w[i] &= ~(1ull << b); r = i * 64 + b; }
+        return r;
+    }
+};
+struct Scal {
+    Pair<int32_t> n_lv;
+    int32_t status;
+    int32_t n_ops;
+    int64_t inv, cash;
+    int64_t ag_cnt;
+    Pair<int64_t> ag_vol, ext_cnt, ext_vol;
+    uint32_t agent_seq;
+    Mask<NSLAB / 64> slab_free;
+    Mask<NA / 64> agent_free;
+    Mask<NA / 64> agent_pending;  // entries freed during this step: not reused before the step ends
+    Slot* slots;                  // this env's slabs
+};
+
+DI int lane() { return (int)threadIdx.x; }
+DI void wsync() { __syncthreads(); }  // block == one wave: orders LDS + global accesses between lanes
+
+DI int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+DI int32_t rl32(int32_t v, int src) { return __builtin_amdgcn_readlane(v, src); }
+DI int64_t rl64(int64_t v, int src) {
+    int32_t lo = __builtin_amdgcn_readlane((int32_t)(v & 0xffffffffll), src);
+    int32_t hi = __builtin_amdgcn_readlane((int32_t)(v >> 32), src);
+    return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+DI double rld(double v, int src) { return __longlong_as_double(rl64(__double_as_longlong(v), src)); }
+DI int64_t uni64(int64_t v) {
+    int32_t lo = uni((int32_t)(v & 0xffffffffll)), hi = uni((int32_t)(v >> 32));
+    return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+
+DI int32_t wave_incl_scan(int32_t v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int32_t t = __shfl_up(v, d, 64);
+        if (lane() >= d) v += t;
+    }
+    return v;
+}
+DI int32_t wave_sum(int32_t v) { return rl32(wave_incl_scan(v), 63); }
+DI int popc64(uint64_t m) { return __popcll(m); }
+DI int ffs64(uint64_t m) { return __ffsll((unsigned long long)m) - 1; }     // lowest set bit, -1 if none
+DI int fls64(uint64_t m) { return m ? 63 - __clzll((long long)m) : -1; }   // highest set bit
+
+// ---------------------------------------------------------------------------------------------------------------
+// price ladder (LDS): sorted best first; SortedDict of rl4mm/orderbook/models.py:64-69
+// ---------------------------------------------------------------------------------------------------------------
+DI int find_level(const Lds& L, const Scal& S, int side, int64_t price) {
+    int n = S.n_lv[side], ln = lane();
+    bool m0 = ln < n && L.price[side][ln] == price;
+    bool m1 = ln + 64 < n && L.price[side][ln + 64] == price;
+    uint64_t b0 = __ballot(m0), b1 = __ballot(m1);
+    if (b0) return ffs64(b0);
+    if (b1) return 64 + ffs64(b1);
+    return -1;
+}
+
+DI int insert_pos(const Lds& L, const Scal& S, int side, int64_t price) {
+    int n = S.n_lv[side], ln = lane();
+    bool m0 = ln < n && (side == LOBSIM_BUY ? L.price[side][ln] > price : L.price[side][ln] < price);
+    bool m1 = ln + 64 < n && (side == LOBSIM_BUY ? L.price[side][ln + 64] > price : L.price[side][ln + 64] < price);
+    return popc64(__ballot(m0)) + popc64(__ballot(m1));
+}
+
+// open an empty level at sorted position pos; returns false on overflow
+DI bool ladder_insert(Lds& L, Scal& S, int side, int pos, int64_t price) {
+    int n = S.n_lv[side], ln = lane();
+    if (n >= LV) { S.status |= LOBSIM_ST_LEVEL_OVERFLOW; return false; }
+    int slab = S.slab_free.take_first();
+    int64_t p[2], v[2]; uint16_t sl[2], hd[2], tl[2], lv[2]; bool take[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        int i = ln + 64 * r;
+        take[r] = i > pos && i <= n;
+        if (take[r]) { p[r] = L.price[side][i - 1]; v[r] = L.vol[side][i - 1]; sl[r] = L.slab[side][i - 1]; hd[r] = L.head[side][i - 1]; tl[r] = L.tail[side][i - 1]; lv[r] = L.live[side][i - 1]; }
+    }
+    wsync();
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        int i = ln + 64 * r;
+        if (take[r]) { L.price[side][i] = p[r]; L.vol[side][i] = v[r]; L.slab[side][i] = sl[r]; L.head[side][i] = hd[r]; L.tail[side][i] = tl[r]; L.live[side][i] = lv[r]; }
+    }
+    if (ln == 0) { L.price[side][pos] = price; L.vol[side][pos] = 0; L.slab[side][pos] = (uint16_t)slab; L.head[side][pos] = 0; L.tail[side][pos] = 0; L.live[side][pos] = 0; }
+    S.n_lv.set(side, n + 1);
+    wsync();
+    return true;
+}
+
+DI void ladder_remove(Lds& L, Scal& S, int side, int pos) {
+    int n = S.n_lv[side], ln = lane();
+    int slab = L.slab[side][pos];
+    slab = uni(slab);
+    S.slab_free.set(slab);
+    int64_t p[2], v[2]; uint16_t sl[2], hd[2], tl[2], lv[2]; bool take[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        int i = ln + 64 * r;
+        take[r] = i >= pos && i < n - 1;
+        if (take[r]) { p[r] = L.price[side][i + 1]; v[r] = L.vol[side][i + 1]; sl[r] = L.slab[side][i + 1]; hd[r] = L.head[side][i + 1]; tl[r] = L.tail[side][i + 1]; lv[r] = L.live[side][i + 1]; }
+    }
+    wsync();
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        int i = ln + 64 * r;
+        if (take[r]) { L.price[side][i] = p[r]; L.vol[side][i] = v[r]; L.slab[side][i] = sl[r]; L.head[side][i] = hd[r]; L.tail[side][i] = tl[r]; L.live[side][i] = lv[r]; }
+    }
+    S.n_lv.set(side, n - 1);
+    wsync();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// level queues (HBM slabs): deque of rl4mm/orderbook/models.py:66
+// ---------------------------------------------------------------------------------------------------------------
+DI Slot dead_slot() { Slot s; s.id = 0; s.vol = 0; s.kind = K_DEAD; return s; }
+
+DI Slot load_slot(const Slot* sl, int i, int head, int tail) {
+    if (i >= head && i < tail) return sl[i];
+    return dead_slot();
+}
+
+// squeeze tombstones out of a full slab (FIFO order kept)
+DI void compact_level(Lds& L, Scal& S, int side, int idx) {
+    int ln = lane();
+    int slab = uni(L.slab[side][idx]), head = uni(L.head[side][idx]), tail = uni(L.tail[side][idx]);
+    Slot* sl = S.slots + (size_t)slab * SLOTS;
+    Slot s0 = load_slot(sl, ln, head, tail), s1 = load_slot(sl, ln + 64, head, tail);
+    uint64_t b0 = __ballot(s0.kind != K_DEAD), b1 = __ballot(s1.kind != K_DEAD);
+    uint64_t below = (1ull << ln) - 1;
+    int n0 = popc64(b0);
+    wsync();  // all loads done before any store
+    if (s0.kind != K_DEAD) sl[popc64(b0 & below)] = s0;
+    if (s1.kind != K_DEAD) sl[n0 + popc64(b1 & below)] = s1;
+    if (ln == 0) { L.head[side][idx] = 0; L.tail[side][idx] = (uint16_t)(n0 + popc64(b1)); }
+    wsync();
+}
+
+DI void level_append(Lds& L, Scal& S, int side, int idx, int64_t id, int32_t vol, int32_t kind) {
+    int tail = uni(L.tail[side][idx]);
+    if (tail == SLOTS) {
+        compact_level(L, S, side, idx);
+        tail = uni(L.tail[side][idx]);
+        if (tail == SLOTS) { S.status |= LOBSIM_ST_QUEUE_OVERFLOW; return; }
+    }
+    if (lane() == 0) {
+        int slab = L.slab[side][idx];
+        Slot s; s.id = id; s.vol = vol; s.kind = kind;
+        S.slots[(size_t)slab * SLOTS + tail] = s;
+        if (L.live[side][idx] == 0) L.head[side][idx] = (uint16_t)tail;
+        L.tail[side][idx] = (uint16_t)(tail + 1);
+        L.live[side][idx] += 1;
+        L.vol[side][idx] += vol;
+    }
+    wsync();
+}
+
+DI int alloc_agent(Scal& S) {
+    int a = S.agent_free.take_first();
+    if (a < 0) S.status |= LOBSIM_ST_AGENT_OVERFLOW;
+    return a;
+}
+
+// Take `rv` shares off slot `pos` of level idx (slots already in registers as s0/s1): the tail of
+// _reduce_order_with_queue_position + _clear_empty_orders_and_prices (Exchange.py:219-247).
+DI void reduce_slot(Lds& L, Scal& S, int side, int idx, int pos, int32_t rv, Slot s0, Slot s1) {
+    int ln = lane();
+    int head = uni(L.head[side][idx]), tail = uni(L.tail[side][idx]), slab = uni(L.slab[side][idx]);
+    Slot* sl = S.slots + (size_t)slab * SLOTS;
+    Slot mine = pos < 64 ? s0 : s1;
+    int src = pos & 63;
+    int32_t pv = rl32(mine.vol, src), pk = rl32(mine.kind, src);
+    int64_t pid = rl64(mine.id, src);
+    int32_t nv = pv - rv;
+    bool gone = nv == 0;
+    if (ln == src) {
+        Slot w = mine; w.vol = nv; if (gone) w.kind = K_DEAD;
+        sl[pos] = w;
+        if (pk == K_AGENT) L.agent[pid].vol = nv;
+    }
+    if (gone && pk == K_AGENT) S.agent_pending.set((int)pid);
+    int live = uni(L.live[side][idx]) - (gone ? 1 : 0);
+    if (gone && live == 0) { wsync(); ladder_remove(L, S, side, idx); return; }
+    int new_head = head;
+    if (gone && pos == head) {  // next live slot after pos
+        uint64_t a0 = __ballot(s0.kind != K_DEAD && ln > pos), a1 = __ballot(s1.kind != K_DEAD && ln + 64 > pos);
+        new_head = a0 ? ffs64(a0) : (a1 ? 64 + ffs64(a1) : tail);
+    }
+    if (ln == 0) { L.vol[side][idx] -= rv; L.live[side][idx] = (uint16_t)live; L.head[side][idx] = (uint16_t)new_head; }
+    wsync();
+}
+
+// remove_order + _find_queue_position (Exchange.py:122-147,196-217) on the central book.  kind/id name the target:
+// (K_EXT, external id) for historical messages, (K_AGENT, agent index) for the agent's own cancellations.
+// vol < 0 means "Deletion without volume".
+DI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, int64_t id, int32_t vol) {
+    int idx = find_level(L, S, side, price);
+    if (idx < 0) return;  // warn + KeyError -> continue
+    int ln = lane();
+    int head = uni(L.head[side][idx]), tail = uni(L.tail[side][idx]), slab = uni(L.slab[side][idx]);
+    const Slot* sl = S.slots + (size_t)slab * SLOTS;
+    Slot s0 = load_slot(sl, ln, head, tail), s1 = tail > 64 ? load_slot(sl, ln + 64, head, tail) : dead_slot();
+    uint64_t b0 = __ballot(s0.kind == kind && s0.id == id), b1 = __ballot(s1.kind == kind && s1.id == id);
+    int pos = b1 ? 64 + fls64(b1) : fls64(b0);
+    if (pos < 0) {
+        // unknown id: if the head is a snapshot order (internal_id == -1) it absorbs the removal (:133-137)
+        int32_t hk = head < 64 ? rl32(s0.kind, head & 63) : rl32(s1.kind, head & 63);
+        if (hk != K_SNAP) return;
+        if (vol < 0) { S.status |= LOBSIM_ST_ASSERT; return; }
+        pos = head;
+    }
+    int32_t pv = pos < 64 ? rl32(s0.vol, pos & 63) : rl32(s1.vol, pos & 63);
+    int32_t rv = vol < 0 ? pv : (vol > pv ? pv : vol);  // CancellationVolumeExceededError -> whole remainder (:144-146)
+    reduce_slot(L, S, side, idx, pos, rv, s0, s1);
+}
+
+// execute_order (Exchange.py:85-120): the aggressor (side, limit price or market) sweeps the opposite side level by
+// level; inside a level all FIFO slots are matched at once with a prefix sum of the volume ahead.  Returns the
+// unfilled remainder.
+DI int32_t execute(Lds& L, Scal& S, int side, bool is_agent, bool is_market, int64_t price, int32_t rem) {
+    const int opp = side ^ 1;
+    int ln = lane();
+    while (rem > 0) {
+        if (S.n_lv[opp] == 0) {
+            if (is_market) S.status |= LOBSIM_ST_EMPTY_BOOK;  // EmptyOrderbookError (:180-186); a limit just stops crossing
+            break;
+        }
+        int64_t bp = uni64(L.price[opp][0]);
+        if (!is_market && !(side == LOBSIM_BUY ? price >= bp : price <= bp)) break;
+        int head = uni(L.head[opp][0]), tail = uni(L.tail[opp][0]), slab = uni(L.slab[opp][0]);
+        Slot* sl = S.slots + (size_t)slab * SLOTS;
+        int32_t carry = 0, exec_ext = 0, exec_agent = 0, deleted_agent_vol = 0, n_ext = 0, n_agent = 0, n_removed = 0;
+        int first_survivor = tail;
+        for (int r = 0; r < 2; r++) {
+            if (r * 64 >= tail) break;
+            if (head >= 64 * (r + 1)) continue;
+            int i = ln + 64 * r;
+            Slot s = load_slot(sl, i, head, tail);
+            bool live = s.kind != K_DEAD;
+            bool own = is_agent && s.kind == K_AGENT;  // the agent cannot fill its own order: it is deleted (:91-94)
+            int32_t contrib = (live && !own) ? s.vol : 0;
+            int32_t incl = wave_incl_scan(contrib);
+            int32_t ahead = incl - contrib + carry;
+            bool reached = live && ahead < rem;
+            int32_t ex = (reached && !own) ? min(s.vol, rem - ahead) : 0;
+            int32_t nv = reached ? (own ? 0 : s.vol - ex) : s.vol;
+            bool gone = reached && nv == 0;
+            if (reached) {
+                Slot w = s; w.vol = nv; if (gone) w.kind = K_DEAD;
+                sl[i] = w;
+                if (s.kind == K_AGENT) L.agent[s.id].vol = nv;
+            }
+            uint64_t gone_agent = __ballot(gone && s.kind == K_AGENT);
+            // freed agent entries (uniform bookkeeping): ids live in lanes, gather them
+            while (gone_agent) {
+                int b = ffs64(gone_agent);
+                gone_agent &= gone_agent - 1;
+                int64_t aid = rl64(s.id, b);
+                S.agent_pending.set((int)aid);
+            }
+            bool ext_fill = reached && !own && s.kind != K_AGENT;
+            bool ag_fill = reached && !own && s.kind == K_AGENT;
+            n_ext += popc64(__ballot(ext_fill));
+            n_agent += popc64(__ballot(ag_fill));
+            n_removed += popc64(__ballot(gone));
+            exec_ext += wave_sum(ext_fill ? ex : 0);
+            exec_agent += wave_sum(ag_fill ? ex : 0);
+            deleted_agent_vol += wave_sum((reached && own) ? s.vol : 0);
+            carry += rl32(incl, 63);
+            uint64_t surv = __ballot(live && !gone);
+            if (surv && first_survivor == tail) first_survivor = 64 * r + ffs64(surv);
+        }
+        int32_t E = exec_ext + exec_agent;
+        rem -= E;
+        // fills: resting side = opp (Q10: external fills are counted by the resting order's direction)
+        S.ext_cnt.add(opp, n_ext); S.ext_vol.add(opp, exec_ext);
+        if (n_agent) {  // an external aggressor hit resting agent orders (executed_internal_orders, :107-109)
+            S.ag_cnt += n_agent; S.ag_vol.add(opp, exec_agent);
+            if (opp == LOBSIM_SELL) { S.inv -= exec_agent; S.cash += (int64_t)exec_agent * bp; }
+            else { S.inv += exec_agent; S.cash -= (int64_t)exec_agent * bp; }
+        }
+        if (is_agent) {  // the agent's own aggressing fills, one MarketOrder copy per resting fill (:110-115)
+            S.ag_cnt += n_ext; S.ag_vol.add(side, exec_ext);
+            if (side == LOBSIM_SELL) { S.inv -= exec_ext; S.cash += (int64_t)exec_ext * bp; }
+            else { S.inv += exec_ext; S.cash -= (int64_t)exec_ext * bp; }
+        }
+        int live_left = uni(L.live[opp][0]) - n_removed;
+        wsync();
+        if (live_left == 0) { ladder_remove(L, S, opp, 0); continue; }
+        if (ln == 0) { L.vol[opp][0] -= (int64_t)E + deleted_agent_vol; L.live[opp][0] = (uint16_t)live_left; L.head[opp][0] = (uint16_t)first_survivor; }
+        wsync();
+        if (S.status) break;
+    }
+    return rem;
+}
+
+// submit_order (Exchange.py:71-83): cross -> execute, remainder rests at the back of its level's queue
+DI void submit_limit(Lds& L, Scal& S, int side, int64_t price, int32_t vol, bool is_agent, int64_t ext_id) {
+    const int opp = side ^ 1;
+    bool cross = false;
+    if (S.n_lv[opp] > 0) { int64_t bp = uni64(L.price[opp][0]); cross = side == LOBSIM_BUY ? price >= bp : price <= bp; }
+    if (cross) {
+        vol = execute(L, S, side, is_agent, false, price, vol);
+        if (S.status || vol <= 0) return;
+    }
+    int idx = find_level(L, S, side, price);
+    if (idx < 0) {
+        idx = insert_pos(L, S, side, price);
+        if (!ladder_insert(L, S, side, idx, price)) return;
+    }
+    int64_t id = ext_id;
+    if (is_agent) {
+        int a = alloc_agent(S);
+        if (a < 0) return;
+        if (lane() == 0) { AgentOrd o; o.price = price; o.vol = vol; o.seq_side = (S.agent_seq & 0x7fffffffu) | ((uint32_t)side << 31); L.agent[a] = o; }
+        S.agent_seq++;
+        id = a;
+    }
+    level_append(L, S, side, idx, id, vol, is_agent ? K_AGENT : K_EXT);
+}
+
+// process_order (Exchange.py:58-69) for one historical message
+DI void process_message(Lds& L, Scal& S, int type, int side, int64_t price, int64_t vol64, int64_t ext_id) {
+    if (!(vol64 > 0)) { S.status |= LOBSIM_ST_ASSERT; return; }  // assert order.volume > 0
+    int32_t vol = vol64 > 0x7fffffffll ? 0x7fffffff : (int32_t)vol64;
+    switch (type) {
+    case LOBSIM_LIMIT: submit_limit(L, S, side, price, vol, false, ext_id); break;
+    case LOBSIM_MARKET: execute(L, S, side, false, true, 0, vol); break;
+    case LOBSIM_CANCELLATION:
+    case LOBSIM_DELETION: remove_order(L, S, side, price, K_EXT, ext_id, vol); break;
+    default: S.status |= LOBSIM_ST_BAD_MESSAGE; break;  // cross_trade / trading_halt (HistoricalOrderGenerator.py:54-56)
+    }
+}
+
+DI void process_op(Lds& L, Scal& S, Op op) {
+    int type = op.code & 0xf, side = (op.code >> 4) & 1, aidx = op.code >> 8;
+    if (!(op.vol > 0)) { S.status |= LOBSIM_ST_ASSERT; return; }
+    if (type == LOBSIM_LIMIT) submit_limit(L, S, side, op.price, op.vol, true, 0);
+    else if (type == LOBSIM_MARKET) execute(L, S, side, true, true, 0, op.vol);
+    else remove_order(L, S, side, op.price, K_AGENT, aidx, op.vol);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// action -> agent order list (HistoricalOrderbookEnvironment.py:206-331)
+// ---------------------------------------------------------------------------------------------------------------
+DI double np_pairwise_sum(const double* a, int n) {  // numpy add.reduce order for n <= 128
+    if (n < 8) { double r = 0.; for (int i = 0; i < n; i++) r += a[i]; return r; }
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) { r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3]; r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7]; }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+
+DI double act_at(const double* a, int i) {  // register-array read with a runtime index, as selects
+    double r = a[0];
+#pragma unroll
+    for (int k = 1; k < LOBSIM_MAX_ACTION_DIM; k++) r = i == k ? a[k] : r;
+    return r;
+}
+
+DI void push_op(Lds& L, Scal& S, int type, int side, int aidx, int64_t price, int32_t vol) {
+    if (lane() == 0 && S.n_ops < OPS_MAX) { Op o; o.price = price; o.vol = vol; o.code = type | (side << 4) | (aidx << 8); L.ops[S.n_ops] = o; }
+    S.n_ops++;
+}
+
+// Builds L.ops from the action and the PRE-step book; nothing is mutated (the reference computes the whole
+// order list first and only then hands it to the simulator).
+DI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const double* action) {
+    const lobsim_cfg& c = C.c;
+    const int Q = C.Q, ln = lane();
+    const int64_t tick = c.tick_size;
+    S.n_ops = 0;
+    // ---- BetaOrderDistributor.convert_action (OrderDistributors.py:23-25,39-56); lane = side * Q + k
+    const double EPS = 0.000001;
+    int my_side = ln / Q, my_k = ln - my_side * Q;
+    bool quoting = ln < 2 * Q;
+    if (quoting) {
+        double a, b;
+        if (c.use_concentration) { a = act_at(action, my_side) + EPS; b = c.concentration - a + EPS; }
+        else { a = act_at(action, 2 * my_side) + EPS; b = act_at(action, 2 * my_side + 1) + EPS; }
+        double x = 1.0 / Q * (my_k + 0.5);
+        L.pdf[my_side][my_k] = pow(x, a - 1.0) * pow(1.0 - x, b - 1.0);  // beta.pdf up to the 1/B(a,b) that cancels below
+    }
+    if (ln < 2 * QMAX) L.cur[ln / QMAX][ln % QMAX] = 0;
+    wsync();
+    int32_t desired = 0;
+    if (quoting) {
+        double s = np_pairwise_sum(L.pdf[my_side], Q);
+        desired = (int32_t)rint(L.pdf[my_side][my_k] / s * 100.0);  // np.round(dist * active_volume).astype(int)
+    }
+    int64_t abs_inv = S.inv < 0 ? -S.inv : S.inv;
+    bool clearing = c.market_order_clearing && (double)abs_inv > act_at(action, c.action_dim - 1);
+    if (clearing) desired = 0;
+    // ---- _get_best_prices (:298-322)
+    if (S.n_lv[LOBSIM_SELL] == 0) { S.status |= LOBSIM_ST_EMPTY_BOOK; return; }  // np.arange(inf) raises
+    int64_t best_buy = S.n_lv[LOBSIM_BUY] ? uni64(L.price[LOBSIM_BUY][0]) : 0, best_sell = uni64(L.price[LOBSIM_SELL][0]);
+    if (c.enter_spread) {
+        double mid = ((double)best_sell + (double)best_buy) / 2;
+        best_buy = (int64_t)(floor(mid / (double)tick) * (double)tick);
+        best_sell = (int64_t)(ceil(mid / (double)tick) * (double)tick);
+    }
+    // ---- current agent volume per quoted level (_get_current_internal_order_volumes, :291-296); each agent entry
+    // finds its quote level (or "wide")
+    int ek[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        AgentOrd o = L.agent[ln + 64 * r];
+        ek[r] = -2;  // free entry
+        if (o.vol > 0) {
+            int s = o.seq_side >> 31;
+            int64_t d = s == LOBSIM_BUY ? best_buy - o.price : o.price - best_sell;
+            int64_t kk = d / tick - c.min_quote_level;
+            ek[r] = (d % tick == 0 && kk >= 0 && kk < Q) ? (int)kk : -1;
+            if (ek[r] >= 0) atomicAdd(&L.cur[s][ek[r]], o.vol);
+        }
+    }
+    wsync();
+    int32_t diff = quoting ? desired - L.cur[my_side][my_k] : 0;
+    uint64_t todo = __ballot(diff != 0);
+    for (int side = 0; side < 2; side++) {
+        uint64_t m = todo & (((1ull << Q) - 1) << (side * Q));
+        while (m) {
+            int j = ffs64(m);
+            m &= m - 1;
+            int k = j - side * Q;
+            int32_t d = rl32(diff, j);
+            int64_t price = side == LOBSIM_BUY ? best_buy - (c.min_quote_level + k) * tick : best_sell + (c.min_quote_level + k) * tick;
+            if (d > 0) { push_op(L, S, LOBSIM_LIMIT, side, 0, price, d); continue; }
+            // cancel from the agent's NEWEST order at this price backwards (:240-249)
+            int32_t need = -d;
+            AgentOrd o0 = L.agent[ln], o1 = L.agent[ln + 64];
+            bool m0 = ek[0] == k && (int)(o0.seq_side >> 31) == side, m1 = ek[1] == k && (int)(o1.seq_side >> 31) == side;
+            uint64_t b0 = __ballot(m0), b1 = __ballot(m1);
+            uint32_t q0 = o0.seq_side & 0x7fffffffu, q1 = o1.seq_side & 0x7fffffffu;
+            int32_t newer0 = 0, newer1 = 0, rank0 = 0, rank1 = 0;  // volume / count of matching orders newer than mine
+            for (int r = 0; r < 2; r++) {
+                uint64_t bb = r ? b1 : b0;
+                while (bb) {
+                    int t = ffs64(bb);
+                    bb &= bb - 1;
+                    uint32_t tq = (uint32_t)rl32((int32_t)(r ? q1 : q0), t);
+                    int32_t tv = rl32(r ? o1.vol : o0.vol, t);
+                    if (m0 && tq > q0) { newer0 += tv; rank0++; }
+                    if (m1 && tq > q1) { newer1 += tv; rank1++; }
+                }
+            }
+            int32_t c0 = m0 && need > newer0 ? min(o0.vol, need - newer0) : 0;
+            int32_t c1 = m1 && need > newer1 ? min(o1.vol, need - newer1) : 0;
+            int base = S.n_ops;
+            if (c0 > 0 && base + rank0 < OPS_MAX) { Op op; op.price = price; op.vol = c0; op.code = LOBSIM_CANCELLATION | (side << 4) | (ln << 8); L.ops[base + rank0] = op; }
+            if (c1 > 0 && base + rank1 < OPS_MAX) { Op op; op.price = price; op.vol = c1; op.code = LOBSIM_CANCELLATION | (side << 4) | ((ln + 64) << 8); L.ops[base + rank1] = op; }
+            S.n_ops += popc64(__ballot(c0 > 0)) + popc64(__ballot(c1 > 0));
+        }
+        // orders resting at prices no longer quoted are cancelled in full (:250-257)
+        for (int r = 0; r < 2; r++) {
+            AgentOrd o = L.agent[ln + 64 * r];
+            bool w = ek[r] == -1 && (int)(o.seq_side >> 31) == side;
+            uint64_t bw = __ballot(w);
+            int at = S.n_ops + popc64(bw & ((1ull << ln) - 1));
+            if (w && at < OPS_MAX) { Op op; op.price = o.price; op.vol = o.vol; op.code = LOBSIM_CANCELLATION | (side << 4) | ((ln + 64 * r) << 8); L.ops[at] = op; }
+            S.n_ops += popc64(bw);
+        }
+    }
+    if (clearing) {  // _get_inventory_clearing_market_order (:260-266)
+        double v = rint((double)abs_inv * c.market_order_fraction_of_inventory);
+        push_op(L, S, LOBSIM_MARKET, S.inv < 0 ? LOBSIM_BUY : LOBSIM_SELL, 0, 0, (int32_t)v);
+    }
+    if (S.n_ops > OPS_MAX) S.status |= LOBSIM_ST_AGENT_OVERFLOW;
+    wsync();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// simulator: snapshot -> book, outer-level resync, message replay
+// ---------------------------------------------------------------------------------------------------------------
+DI void ladder_clear(Lds& L, Scal& S) {
+    S.n_lv.a = S.n_lv.b = 0;
+    S.slab_free.fill(~0ull);
+    S.agent_free.fill(~0ull);
+    S.agent_pending.fill(0);
+    L.agent[lane()].vol = 0;
+    L.agent[lane() + 64].vol = 0;
+    S.agent_seq = 0;
+    wsync();
+}
+
+// book[direction][price] = deque([LimitOrder(internal_id=-1)]) (Exchange.py:172-178, OrderbookSimulator.py:130)
+DI void set_level_to_snapshot(Lds& L, Scal& S, int side, int64_t price, int32_t vol) {
+    int idx = find_level(L, S, side, price);
+    if (idx < 0) {
+        idx = insert_pos(L, S, side, price);
+        if (!ladder_insert(L, S, side, idx, price)) return;
+    }
+    if (lane() == 0) {
+        int slab = L.slab[side][idx];
+        Slot s; s.id = -1; s.vol = vol; s.kind = K_SNAP;
+        S.slots[(size_t)slab * SLOTS] = s;
+        L.head[side][idx] = 0; L.tail[side][idx] = 1; L.live[side][idx] = 1; L.vol[side][idx] = vol;
+    }
+    wsync();
+}
+
+// orderbook_price_range (Exchange.py:158-169): lowest buy price > 0 and highest sell price < 9999999999
+DI bool price_range(const Lds& L, const Scal& S, int64_t& worst_buy, int64_t& worst_sell) {
+    int ln = lane();
+    int nb = S.n_lv[0], ns = S.n_lv[1];
+    uint64_t b0 = __ballot(ln < nb && L.price[0][ln] > 0), b1 = __ballot(ln + 64 < nb && L.price[0][ln + 64] > 0);
+    uint64_t s0 = __ballot(ln < ns && L.price[1][ln] < DUMMY_PRICE), s1 = __ballot(ln + 64 < ns && L.price[1][ln + 64] < DUMMY_PRICE);
+    int ib = b1 ? 64 + fls64(b1) : fls64(b0), is = s1 ? 64 + fls64(s1) : fls64(s0);
+    if (ib < 0 || is < 0) return false;  // StopIteration
+    worst_buy = uni64(L.price[0][ib]);
+    worst_sell = uni64(L.price[1][is]);
+    return true;
+}
+
+DI double best_buy_d(const Lds& L, const Scal& S) { return S.n_lv[0] ? (double)uni64(L.price[0][0]) : 0.0; }
+DI double best_sell_d(const Lds& L, const Scal& S) { return S.n_lv[1] ? (double)uni64(L.price[1][0]) : (double)INFINITY; }
+
+struct alignas(16) I64x2 { int64_t x, y; };
+
+struct Ranges { double min_buy, max_sell, init_buy, init_sell; };
+
+// update_outer_levels (OrderbookSimulator.py:105-135)
+DI void resync_outer_levels(Lds& L, Scal& S, const DevCfg& C, const StreamDev& st, int64_t now_us, Ranges& R) {
+    const int Lv = C.c.n_levels, ln = lane();
+    int64_t sec = now_us / 1000000 - st.first_sec;
+    int32_t si = sec < 0 ? -1 : (sec >= st.n_secs ? (int32_t)st.n_snaps - 1 : st.sec_to_snap[sec]);
+    int n_readd = 0;  // re-add list lives in L.ops[0..): limit ops to be replayed after all levels were replaced
+    if (si >= 0) {
+        const int64_t* row = st.snaps + (int64_t)si * (2 + 4 * Lv) + 2;
+        for (int side = 0; side < 2 && !S.status; side++) {
+            for (int base = 0; base < Lv && !S.status; base += 64) {
+                int l = base + ln;
+                int64_t p = 0; int64_t v = 0; bool pass = false;
+                if (l < Lv) {
+                    p = side == LOBSIM_BUY ? row[4 * l + 2] : row[4 * l];
+                    v = side == LOBSIM_BUY ? row[4 * l + 3] : row[4 * l + 1];
+                    pass = side == LOBSIM_BUY ? (double)p < R.min_buy : (double)p > R.max_sell;  // _initial_prices_filter_function
+                }
+                uint64_t pm = __ballot(pass);
+                while (pm && !S.status) {
+                    int j = ffs64(pm);
+                    pm &= pm - 1;
+                    int64_t price = rl64(p, j);
+                    int32_t vol = (int32_t)rl64(v, j);
+                    // agent orders at this level: cancel them now, re-submit them at the back afterwards (:114-129)
+                    for (int r = 0; r < 2 && !S.status; r++) {
+                        AgentOrd o = L.agent[ln + 64 * r];
+                        bool hit = o.vol > 0 && (int)(o.seq_side >> 31) == side && o.price == price;
+                        uint64_t hm = __ballot(hit);
+                        // process in submission order
+                        while (hm && !S.status) {
+                            uint32_t myq = hit ? (o.seq_side & 0x7fffffffu) : 0xffffffffu;
+                            // lane holding the smallest seq among remaining hits
+                            uint32_t best = 0xffffffffu; int bl = -1;
+                            uint64_t t = hm;
+                            while (t) { int b = ffs64(t); t &= t - 1; uint32_t q = (uint32_t)rl32((int32_t)myq, b); if (q < best) { best = q; bl = b; } }
+                            hm &= ~(1ull << bl);
+                            int32_t ov = rl32(o.vol, bl);
+                            int aidx = bl + 64 * r;
+                            if (ln == 0 && n_readd < OPS_MAX) { Op op; op.price = price; op.vol = ov; op.code = LOBSIM_LIMIT | (side << 4); L.ops[n_readd] = op; }
+                            n_readd++;
+                            remove_order(L, S, side, price, K_AGENT, aidx, ov);
+                        }
+                    }
+                    if (!S.status) set_level_to_snapshot(L, S, side, price, vol);
+                }
+            }
+        }
+    }
+    if (n_readd > OPS_MAX) S.status |= LOBSIM_ST_AGENT_OVERFLOW;
+    wsync();
+    for (int k = 0; k < n_readd && !S.status; k++) process_op(L, S, L.ops[k]);
+    if (S.status) return;
+    int64_t wb, ws;
+    if (!price_range(L, S, wb, ws)) { S.status |= LOBSIM_ST_EMPTY_BOOK; return; }
+    if ((double)wb < R.min_buy) R.min_buy = (double)wb;
+    if ((double)ws > R.max_sell) R.max_sell = (double)ws;
+}
+
+// the window (now, until] of historical messages, in stream order (OrderbookSimulator.py:70-85)
+DI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, int64_t until_us) {
+    int ln = lane();
+    while (!S.status) {
+        int64_t i = cursor + ln;
+        int64_t t = 0, eid = 0, price = 0, meta = 0;
+        bool in = false;
+        if (i < st.n_msgs) {
+            const I64x2* m = reinterpret_cast<const I64x2*>(st.msgs + i * LOBSIM_MSG_WORDS);
+            I64x2 a = m[0], b = m[1];  // 2 x dwordx4, 32 contiguous bytes per lane
+            t = a.x; eid = a.y; price = b.x; meta = b.y;
+            in = t <= until_us;
+        }
+        uint64_t bm = __ballot(in);
+        int cnt = popc64(bm);  // the stream is time-sorted: the in-window lanes are a prefix
+        for (int j = 0; j < cnt && !S.status; j++) {
+            int64_t mm = rl64(meta, j);
+            process_message(L, S, (int)((mm >> LOBSIM_TYPE_SHIFT) & 0xf), (int)((mm >> LOBSIM_SIDE_SHIFT) & 1), rl64(price, j), mm & LOBSIM_VOL_MASK, rl64(eid, j));
+        }
+        cursor += cnt;
+        if (cnt < 64) break;
+    }
+}
+
+// microprice (models.py:80-97)
+DI bool microprice(const Lds& L, const Scal& S, double& out) {
+    if (!S.n_lv[0] || !S.n_lv[1]) return false;
+    int64_t bv = uni64(L.vol[0][0]), av = uni64(L.vol[1][0]);
+    if (bv + av == 0) return false;
+    double imb = (double)(bv - av) / (double)(bv + av);
+    double ask = (double)uni64(L.price[1][0]), bid = (double)uni64(L.price[0][0]);
+    out = (1 + imb) / 2 * ask + (1 - imb) / 2 * bid;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// features (rl4mm/features/Features.py): one lane per feature, O(1) ring updates
+// ---------------------------------------------------------------------------------------------------------------
+struct StepView {  // what Feature._update reads from State
+    double price, spread;
+    int64_t inventory, now_us;
+    int64_t ext_cnt[2], ext_vol[2];
+    int64_t bv, av;
+    bool book_ok;
+};
+
+DI double clampd(double x, double lo, double hi) { double m = x < hi ? x : hi; return m > lo ? m : lo; }
+
+// Feature._update; returns false where the reference would raise
+DI bool feature_raw(const lobsim_feature& d, FeatState& f, int64_t* ring, const StepView& v) {
+    const int lb = d.lookback;
+    double* pr = reinterpret_cast<double*>(ring);
+    switch (d.kind) {
+    case LOBSIM_F_SPREAD: f.current_value = v.spread; return true;
+    case LOBSIM_F_BOOK_IMBALANCE:
+        if (!v.book_ok) return false;
+        f.current_value = (double)(v.bv - v.av) / (double)(v.bv + v.av);
+        return true;
+    case LOBSIM_F_PRICE: f.current_value = v.price; return true;
+    case LOBSIM_F_INVENTORY: f.current_value = (double)v.inventory; return true;
+    case LOBSIM_F_EPISODE_PROPORTION: f.current_value += d.dparam; return true;
+    case LOBSIM_F_TIME_OF_DAY: {
+        int64_t num = v.now_us - 10ll * 3600 * 1000000, den = d.iparam;
+        int64_t q = num / den;
+        if (num % den != 0 && num < 0) q -= 1;
+        f.current_value = (double)(q > 0 ? q : 0);
+        return true;
+    }
+    case LOBSIM_F_PRICE_MOVE:
+    case LOBSIM_F_PRICE_RANGE: {  // deque(maxlen=lookback+1).appendleft(price)
+        const int cap = lb + 1;
+        pr[f.pos] = v.price;
+        if (f.count < cap) f.count++;
+        f.pos = f.pos + 1 == cap ? 0 : f.pos + 1;
+        if (d.kind == LOBSIM_F_PRICE_MOVE) {
+            double oldest = pr[f.count < cap ? 0 : f.pos];
+            f.current_value = v.price - oldest;
+        } else {
+            double mx = v.price, mn = v.price;
+            for (int i = 0; i < f.count; i++) { double x = pr[i]; mx = x > mx ? x : mx; mn = x < mn ? x : mn; }
+            f.current_value = mx - mn;
+        }
+        return true;
+    }
+    case LOBSIM_F_VOLATILITY: {  // Features.py:226-242
+        const int cap = lb + 1;
+        if (f.count < lb || f.count == lb) {
+            bool closing = f.count == lb;
+            pr[f.pos] = v.price;
+            if (f.count == 0) { f.p_first = v.price; f.acc = 0.0; }
+            else { double r = (v.price - f.p_last) / f.p_first; f.acc = f.acc + r * r; }  // sum(pct_returns**2), left to right
+            f.p_last = v.price;
+            f.count++;
+            f.pos = f.pos + 1 == cap ? 0 : f.pos + 1;
+            f.current_value = closing ? f.acc / lb : 0.0;
+        } else {
+            double oldest = pr[f.pos];
+            double next_oldest = pr[f.pos + 1 == cap ? 0 : f.pos + 1];
+            double old_ret = (next_oldest - oldest) / oldest;
+            double new_ret = (v.price - f.p_last) / f.p_last;
+            pr[f.pos] = v.price;
+            f.pos = f.pos + 1 == cap ? 0 : f.pos + 1;
+            f.p_last = v.price;
+            double ss = f.current_value * lb - old_ret * old_ret + new_ret * new_ret;
+            f.current_value = ss / lb;
+        }
+        return true;
+    }
+    case LOBSIM_F_TRADE_DIRECTION_IMBALANCE:
+    case LOBSIM_F_TRADE_VOLUME_IMBALANCE: {  // Features.py:376-403 / 435-462 as running sums over a ring
+        bool dirn = d.kind == LOBSIM_F_TRADE_DIRECTION_IMBALANCE;
+        int64_t nb = dirn ? v.ext_cnt[0] : v.ext_vol[0], ns = dirn ? v.ext_cnt[1] : v.ext_vol[1];
+        if (f.count < lb) {
+            ring[f.pos] = nb; ring[lb + f.pos] = ns;
+            f.total += nb + ns; f.diff += nb - ns;
+            f.count++;
+            f.pos = f.pos + 1 == lb ? 0 : f.pos + 1;
+            f.current_value = 0.0;
+        } else {
+            int64_t ob = ring[f.pos], os = ring[lb + f.pos];
+            ring[f.pos] = nb; ring[lb + f.pos] = ns;
+            f.total += (nb + ns) - (ob + os); f.diff += (nb - ns) - (ob - os);
+            f.pos = f.pos + 1 == lb ? 0 : f.pos + 1;
+            f.current_value = f.total != 0 ? (double)f.diff / (double)f.total : 0.5;
+        }
+        return true;
+    }
+    }
+    return false;
+}
+
+DI bool feature_reset(const lobsim_feature& d, FeatState& f, int64_t* ring, const StepView& v, int64_t first_usage) {  // _reset, :92-96
+    f.count = 0; f.pos = 0; f.total = 0; f.diff = 0; f.acc = 0.0; f.p_first = 0.0; f.p_last = 0.0;
+    f.first_usage_us = first_usage;
+    bool ok = feature_raw(d, f, ring, v);
+    if (d.kind == LOBSIM_F_EPISODE_PROPORTION) f.current_value = 0.0;
+    return ok;
+}
+
+DI bool feature_update(const lobsim_feature& d, FeatState& f, int64_t* ring, const StepView& v) {  // update, :80-86
+    if (v.now_us < f.first_usage_us) return true;
+    if ((v.now_us % 60000000ll) % d.update_us != 0) return true;  // _now_is_multiple_of_update_freq
+    if (!feature_raw(d, f, ring, v)) return false;
+    f.current_value = clampd(f.current_value, d.min_value, d.max_value);
+    return true;
+}
+
+DI double reward_of(const lobsim_reward& r, int64_t inv0, int64_t cash0, double p0, int64_t inv1, int64_t cash1, double p1) {
+    double cur = (double)cash0 + (double)inv0 * p0;  // PnL.calculate, RewardFunctions.py:98-101
+    double nxt = (double)cash1 + (double)inv1 * p1;
+    double pnl = nxt - cur;
+    if (r.kind == LOBSIM_R_PNL) return pnl;
+    double delta = p1 - p0;  // InventoryAdjustedPnL.calculate, :113-118
+    double term = r.inventory_aversion * (double)inv1 * delta;
+    if (r.asymmetrically_dampened) term = term > 0 ? term : 0;
+    return pnl - term;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// env state <-> LDS
+// ---------------------------------------------------------------------------------------------------------------
+DI void load_env(Lds& L, Scal& S, const DevPtrs& P, int env, const EnvHdr& H) {
+    int ln = lane();
+    const Ladder& G = P.ladder[env];
+    S.n_lv.a = H.n_lv[0]; S.n_lv.b = H.n_lv[1];
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+        for (int i = ln; i < S.n_lv[s]; i += 64) {
+            L.price[s][i] = G.price[s][i]; L.vol[s][i] = G.vol[s][i];
+            L.slab[s][i] = G.slab[s][i]; L.head[s][i] = G.head[s][i]; L.tail[s][i] = G.tail[s][i]; L.live[s][i] = G.live[s][i];
+        }
+    const AgentOrd* A = P.agent + (size_t)env * NA;
+    L.agent[ln] = A[ln];
+    L.agent[ln + 64] = A[ln + 64];
+    S.status = H.status; S.inv = H.inventory; S.cash = H.cash; S.agent_seq = H.agent_seq; S.n_ops = 0;
+#pragma unroll
+    for (int w = 0; w < NSLAB / 64; w++) S.slab_free.w[w] = H.slab_free[w];
+#pragma unroll
+    for (int w = 0; w < NA / 64; w++) { S.agent_free.w[w] = H.agent_free[w]; S.agent_pending.w[w] = 0; }
+    S.slots = P.slots + (size_t)env * NSLAB * SLOTS;
+    S.ag_cnt = 0; S.ag_vol.a = S.ag_vol.b = 0; S.ext_cnt.a = S.ext_cnt.b = 0; S.ext_vol.a = S.ext_vol.b = 0;
+    wsync();
+}
+
+DI void store_env(const Lds& L, const Scal& S, const DevPtrs& P, int env, EnvHdr& H) {
+    int ln = lane();
+    wsync();
+    Ladder& G = P.ladder[env];
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+        for (int i = ln; i < S.n_lv[s]; i += 64) {
+            G.price[s][i] = L.price[s][i]; G.vol[s][i] = L.vol[s][i];
+            G.slab[s][i] = L.slab[s][i]; G.head[s][i] = L.head[s][i]; G.tail[s][i] = L.tail[s][i]; G.live[s][i] = L.live[s][i];
+        }
+    AgentOrd* A = P.agent + (size_t)env * NA;
+    A[ln] = L.agent[ln];
+    A[ln + 64] = L.agent[ln + 64];
+    if (ln == 0) {
+        H.n_lv[0] = S.n_lv[0]; H.n_lv[1] = S.n_lv[1];
+        H.status = S.status; H.inventory = S.inv; H.cash = S.cash; H.agent_seq = S.agent_seq;
+#pragma unroll
+        for (int w = 0; w < NSLAB / 64; w++) H.slab_free[w] = S.slab_free.w[w];
+#pragma unroll
+        for (int w = 0; w < NA / 64; w++) H.agent_free[w] = S.agent_free.w[w] | S.agent_pending.w[w];
+        H.agent_fill_count = S.ag_cnt; H.agent_vol[0] = S.ag_vol[0]; H.agent_vol[1] = S.ag_vol[1];
+        H.ext_count[0] = S.ext_cnt[0]; H.ext_count[1] = S.ext_cnt[1]; H.ext_vol[0] = S.ext_vol[0]; H.ext_vol[1] = S.ext_vol[1];
+    }
+}
+
+DI void clear_step_fills(Scal& S) {
+    S.ag_cnt = 0; S.ag_vol.a = S.ag_vol.b = 0; S.ext_cnt.a = S.ext_cnt.b = 0; S.ext_vol.a = S.ext_vol.b = 0;
+#pragma unroll
+    for (int w = 0; w < NA / 64; w++) { S.agent_free.w[w] |= S.agent_pending.w[w]; S.agent_pending.w[w] = 0; }
+}
+
+DI StepView make_view(const Lds& L, const Scal& S, double price, int64_t now_us) {
+    StepView v;
+    v.price = price; v.now_us = now_us; v.inventory = S.inv;
+    v.spread = best_sell_d(L, S) - best_buy_d(L, S);
+    v.ext_cnt[0] = S.ext_cnt[0]; v.ext_cnt[1] = S.ext_cnt[1]; v.ext_vol[0] = S.ext_vol[0]; v.ext_vol[1] = S.ext_vol[1];
+    v.book_ok = S.n_lv[0] && S.n_lv[1];
+    v.bv = v.book_ok ? uni64(L.vol[0][0]) : 0; v.av = v.book_ok ? uni64(L.vol[1][0]) : 0;
+    if (v.bv + v.av == 0) v.book_ok = false;
+    return v;
+}
+
+// OrderbookSimulator.forward_step (:70-88) + update_internal_state (HistoricalOrderbookEnvironment.py:199-204):
+// agent ops first, then the message window, clock, resync check, new price.
+DI void advance_one_step(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, int stream_id, int64_t& cursor, int64_t& now_us,
+                         Ranges& R, int& n_resyncs, double& price, bool with_ops) {
+    if (with_ops)
+        for (int k = 0; k < S.n_ops && !S.status; k++) process_op(L, S, L.ops[k]);
+    int64_t until = now_us + C.c.step_us;
+    if (stream_id >= 0 && !S.status) replay_messages(L, S, P.streams[stream_id], cursor, until);
+    now_us = until;
+    if (S.status) return;
+    if (stream_id >= 0 && now_us % 1000000 == 0) {
+        bool near = best_buy_d(L, S) < R.min_buy + C.outer_prop * R.init_buy || best_sell_d(L, S) > R.max_sell - C.outer_prop * R.init_sell;
+        if (near) { n_resyncs++; resync_outer_levels(L, S, C, P.streams[stream_id], now_us, R); }
+    }
+    if (S.status) return;
+    if (!microprice(L, S, price)) S.status |= LOBSIM_ST_EMPTY_BOOK;
+}
+
+// get_initial_orderbook_from_orders / _get_initial_orders_from_snapshot (Exchange.py:172-178,
+// OrderbookSimulator.py:156-175): buy levels 0..L-1 then sell levels; equal prices overwrite
+DI void load_snapshot_book(Lds& L, Scal& S, const int64_t* row, int Lv, bool skip_zero_price) {
+    int ln = lane();
+    for (int side = 0; side < 2 && !S.status; side++)
+        for (int base = 0; base < Lv && !S.status; base += 64) {
+            int l = base + ln;
+            int64_t p = 0, v = 0;
+            if (l < Lv) { p = side == LOBSIM_BUY ? row[4 * l + 2] : row[4 * l]; v = side == LOBSIM_BUY ? row[4 * l + 3] : row[4 * l + 1]; }
+            int cnt = min(64, Lv - base);
+            for (int j = 0; j < cnt && !S.status; j++) {
+                int64_t price = rl64(p, j);
+                if (skip_zero_price && price == 0) continue;
+                set_level_to_snapshot(L, S, side, price, (int32_t)rl64(v, j));
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------------------
+struct StepArgs {
+    const double* actions;  // [n_envs][A]
+    const uint8_t* active;  // [n_envs] or null
+    double* obs;            // [n_envs][obs_dim] or null
+    float* obs_f32;         // or null
+    double* reward;
+    uint8_t* done;
+};
+
+struct ResetArgs {
+    const int32_t* env_ids;  // [n]
+    const int32_t* stream_ids;
+    const int64_t* start_us;
+    double* obs;  // [n][obs_dim] or null
+};
+
+__global__ __launch_bounds__(64) void lob_step_kernel(DevCfg C, DevPtrs P, StepArgs A) {
+    __shared__ Lds L;
+    const int env = blockIdx.x, ln = lane();
+    if (A.active && !A.active[env]) return;
+    EnvHdr& H = P.hdr[env];
+    const int F = C.c.n_features, AD = C.c.action_dim, D = C.obs_dim;
+    Scal S;
+    load_env(L, S, P, env, H);
+    FeatState fs = FeatState();
+    int64_t* ring = nullptr;
+    if (ln < F) { fs = P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln]; ring = P.rings + (size_t)env * C.ring_words + C.ring_off[ln]; }
+    double act[LOBSIM_MAX_ACTION_DIM];
+#pragma unroll
+    for (int i = 0; i < LOBSIM_MAX_ACTION_DIM; i++) act[i] = i < AD ? A.actions[(size_t)env * AD + i] : 0.0;
+    int64_t now = H.now_us, cursor = H.msg_cursor;
+    int stream_id = H.stream_id;
+    Ranges R = {H.min_buy, H.max_sell, H.init_buy_range, H.init_sell_range};
+    int n_resyncs = H.n_resyncs;
+    double price = H.price, reward = 0.0;
+    int done = 0;
+    if (!S.status) {
+        const int64_t inv0 = S.inv, cash0 = S.cash;
+        const double p0 = price;
+        build_agent_ops(L, S, C, act);  // convert_action_to_orders on the pre-step state
+        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true);
+        if (!S.status) {
+            StepView v = make_view(L, S, price, now);
+            bool ok = true;
+            if (ln < F) ok = feature_update(C.c.features[ln], fs, ring, v);
+            if (__ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
+        }
+        if (!S.status) {
+            reward = reward_of(C.c.per_step_reward, inv0, cash0, p0, S.inv, S.cash, price);
+            if (2 * (H.terminal_us - now) < C.c.step_us) {  // terminal_time - now < step_size / 2 (:172-174)
+                reward = reward_of(C.c.terminal_reward, inv0, cash0, p0, S.inv, S.cash, price);
+                done = 1;
+            }
+        }
+    }
+    if (S.status) { done = 1; reward = 0.0; }
+    // outputs
+    double val = 0.0;
+    if (ln < F) val = fs.current_value;
+    else if (ln < D) val = act_at(act, ln - F);  // inc_prev_action_in_obs: the action just taken
+    if (ln < D) {
+        if (A.obs) A.obs[(size_t)env * D + ln] = val;
+        if (A.obs_f32) A.obs_f32[(size_t)env * D + ln] = (float)val;
+    }
+    if (ln == 0) { A.reward[env] = reward; A.done[env] = (uint8_t)done; }
+    if (ln < F) P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln] = fs;
+    store_env(L, S, P, env, H);
+    if (ln == 0) {
+        H.now_us = now; H.msg_cursor = cursor; H.price = price; H.n_resyncs = n_resyncs;
+        H.min_buy = R.min_buy; H.max_sell = R.max_sell;
+        for (int i = 0; i < LOBSIM_MAX_ACTION_DIM; i++) H.prev_action[i] = act[i];
+    }
+}
+
+// env.reset(): snapshot book at (episode_start - warmup), features reset, warm-up replay without agent orders
+// (HistoricalOrderbookEnvironment.py:147-161)
+__global__ __launch_bounds__(64) void lob_reset_kernel(DevCfg C, DevPtrs P, ResetArgs A) {
+    __shared__ Lds L;
+    const int k = blockIdx.x, ln = lane();
+    const int env = A.env_ids[k];
+    EnvHdr& H = P.hdr[env];
+    const int F = C.c.n_features, D = C.obs_dim, Lv = C.c.n_levels;
+    Scal S;
+    S.slots = P.slots + (size_t)env * NSLAB * SLOTS;
+    S.status = 0; S.inv = H.inventory; S.cash = H.cash; S.n_ops = 0;  // the portfolio is NOT reset (Q7)
+    ladder_clear(L, S);
+    clear_step_fills(S);
+    const int stream_id = A.stream_ids[k];
+    const StreamDev& st = P.streams[stream_id];
+    const int64_t start = A.start_us[k];
+    int64_t now = start - C.c.warmup_us;
+    // get_historical_start_book: last snapshot at or before `now` (whole second)
+    int64_t sec = now / 1000000 - st.first_sec;
+    int32_t si = sec < 0 ? -1 : (sec >= st.n_secs ? (int32_t)st.n_snaps - 1 : st.sec_to_snap[sec]);
+    int64_t cursor = sec < 0 ? 0 : (sec >= st.n_secs ? st.n_msgs : st.sec_to_msg[sec]);
+    Ranges R = {(double)INFINITY, 0.0, (double)INFINITY, (double)INFINITY};
+    double price = 0.0;
+    int n_resyncs = 0;
+    if (si < 0) S.status |= LOBSIM_ST_STREAM_END;
+    if (!S.status) {
+        load_snapshot_book(L, S, st.snaps + (int64_t)si * (2 + 4 * Lv) + 2, Lv, false);
+        int64_t wb, ws;  // _reset_initial_price_ranges (:185-188)
+        if (!S.status && price_range(L, S, wb, ws)) {
+            R.min_buy = (double)wb; R.max_sell = (double)ws;
+            R.init_buy = best_buy_d(L, S) - R.min_buy; R.init_sell = R.max_sell - best_sell_d(L, S);
+        } else S.status |= LOBSIM_ST_EMPTY_BOOK;
+    }
+    if (!S.status && !microprice(L, S, price)) S.status |= LOBSIM_ST_EMPTY_BOOK;
+    FeatState fs = FeatState();
+    int64_t* ring = nullptr;
+    if (ln < F) ring = P.rings + (size_t)env * C.ring_words + C.ring_off[ln];
+    if (!S.status) {
+        StepView v = make_view(L, S, price, now);
+        bool ok = true;
+        if (ln < F) {
+            const lobsim_feature& d = C.c.features[ln];
+            ok = feature_reset(d, fs, ring, v, start - (int64_t)d.lookback * d.update_us);
+        }
+        if (__ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
+    }
+    const int64_t n_warm = C.c.warmup_us / C.c.step_us;
+    for (int64_t s = 0; s < n_warm && !S.status; s++) {
+        clear_step_fills(S);
+        advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, false);
+        if (S.status) break;
+        StepView v = make_view(L, S, price, now);
+        bool ok = true;
+        if (ln < F) ok = feature_update(C.c.features[ln], fs, ring, v);
+        if (__ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
+    }
+    if (ln < D && A.obs) A.obs[(size_t)k * D + ln] = ln < F ? fs.current_value : 0.0;  // zeros for the previous action (:158-159)
+    if (ln < F) P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln] = fs;
+    store_env(L, S, P, env, H);
+    if (ln == 0) {
+        H.now_us = now; H.terminal_us = start + C.c.episode_us; H.episode_start_us = start;
+        H.msg_cursor = cursor; H.stream_id = stream_id; H.price = price; H.n_resyncs = n_resyncs;
+        H.min_buy = R.min_buy; H.max_sell = R.max_sell; H.init_buy_range = R.init_buy; H.init_sell_range = R.init_sell;
+        for (int i = 0; i < LOBSIM_MAX_ACTION_DIM; i++) H.prev_action[i] = 0.0;
+    }
+}
+
+// engine-level entry points (unit parity of Exchange.process_order)
+__global__ __launch_bounds__(64) void lob_set_book_kernel(DevCfg C, DevPtrs P, int env, const int64_t* row, int64_t now_us) {
+    __shared__ Lds L;
+    EnvHdr& H = P.hdr[env];
+    Scal S;
+    S.slots = P.slots + (size_t)env * NSLAB * SLOTS;
+    S.status = 0; S.inv = H.inventory; S.cash = H.cash; S.n_ops = 0;
+    ladder_clear(L, S);
+    clear_step_fills(S);
+    if (row) load_snapshot_book(L, S, row, C.c.n_levels, true);
+    store_env(L, S, P, env, H);
+    if (lane() == 0) {
+        H.now_us = now_us; H.terminal_us = INT64_MAX / 4; H.episode_start_us = now_us; H.msg_cursor = 0; H.stream_id = -1;
+        H.price = 0.0; H.n_resyncs = 0; H.min_buy = (double)INFINITY; H.max_sell = 0.0;
+        H.init_buy_range = (double)INFINITY; H.init_sell_range = (double)INFINITY; H.status = S.status & ~LOBSIM_ST_EMPTY_BOOK;
+    }
+}
+
+// orders [n][6] = {type, side, price, volume (-1 none), id, is_external}; agent cancels address their target by
+// FIFO rank among the agent's orders at that price
+__global__ __launch_bounds__(64) void lob_process_orders_kernel(DevCfg C, DevPtrs P, int env, const int64_t* orders, int n, int64_t* fills_out) {
+    __shared__ Lds L;
+    EnvHdr& H = P.hdr[env];
+    const int ln = lane();
+    Scal S;
+    load_env(L, S, P, env, H);
+    clear_step_fills(S);
+    const int64_t cash0 = S.cash;
+    for (int k = 0; k < n && !S.status; k++) {
+        const int64_t* r = orders + 6 * (size_t)k;
+        int type = (int)r[0], side = (int)r[1];
+        int64_t price = r[2], vol = r[3], id = r[4];
+        bool is_ext = r[5] != 0;
+        if (vol != -1 && !(vol > 0)) { S.status |= LOBSIM_ST_ASSERT; break; }
+        if (is_ext) {
+            if (type == LOBSIM_LIMIT) submit_limit(L, S, side, price, (int32_t)vol, false, id);
+            else if (type == LOBSIM_MARKET) execute(L, S, side, false, true, 0, (int32_t)vol);
+            else remove_order(L, S, side, price, K_EXT, id, (int32_t)vol);
+        } else if (type == LOBSIM_LIMIT) submit_limit(L, S, side, price, (int32_t)vol, true, 0);
+        else if (type == LOBSIM_MARKET) execute(L, S, side, true, true, 0, (int32_t)vol);
+        else {
+            // rank -> agent index: the id-th oldest live agent order at (side, price)
+            AgentOrd o0 = L.agent[ln], o1 = L.agent[ln + 64];
+            bool m0 = o0.vol > 0 && (int)(o0.seq_side >> 31) == side && o0.price == price;
+            bool m1 = o1.vol > 0 && (int)(o1.seq_side >> 31) == side && o1.price == price;
+            uint32_t q0 = o0.seq_side & 0x7fffffffu, q1 = o1.seq_side & 0x7fffffffu;
+            uint64_t b0 = __ballot(m0), b1 = __ballot(m1);
+            int older0 = 0, older1 = 0;
+            for (int rr = 0; rr < 2; rr++) {
+                uint64_t bb = rr ? b1 : b0;
+                while (bb) {
+                    int t = ffs64(bb);
+                    bb &= bb - 1;
+                    uint32_t tq = (uint32_t)rl32((int32_t)(rr ? q1 : q0), t);
+                    if (tq < q0) older0++;
+                    if (tq < q1) older1++;
+                }
+            }
+            uint64_t h0 = __ballot(m0 && older0 == id), h1 = __ballot(m1 && older1 == id);
+            int aidx = h0 ? ffs64(h0) : (h1 ? 64 + ffs64(h1) : NA + 1000);
+            remove_order(L, S, side, price, K_AGENT, aidx, (int32_t)vol);
+        }
+        // make entries freed by this order reusable, like the reference (no step boundary at this level)
+    }
+    if (ln == 0 && fills_out) {
+        fills_out[0] = S.ag_cnt; fills_out[1] = S.ag_vol[0]; fills_out[2] = S.ag_vol[1];
+        fills_out[3] = S.ext_cnt[0]; fills_out[4] = S.ext_cnt[1]; fills_out[5] = S.ext_vol[0]; fills_out[6] = S.ext_vol[1];
+        fills_out[7] = S.cash - cash0;
+    }
+    store_env(L, S, P, env, H);
+}
+
+// (inventory, cash, price) of every env, coalesced
+__global__ void lob_gather_portfolios_kernel(DevPtrs P, int n, int64_t* inv, int64_t* cash, double* price) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (inv) inv[i] = P.hdr[i].inventory;
+    if (cash) cash[i] = P.hdr[i].cash;
+    if (price) price[i] = P.hdr[i].price;
+}
+
+__global__ void lob_init_hdr_kernel(DevPtrs P, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    EnvHdr h = EnvHdr();
+    h.status = LOBSIM_ST_NOT_RESET;
+    h.stream_id = -1;
+    h.cash = 1000;  // Portfolio(inventory=0, cash=1000), HistoricalOrderbookEnvironment.py:104
+    for (int w = 0; w < NSLAB / 64; w++) h.slab_free[w] = ~0ull;
+    for (int w = 0; w < NA / 64; w++) h.agent_free[w] = ~0ull;
+    h.min_buy = (double)INFINITY; h.init_buy_range = (double)INFINITY; h.init_sell_range = (double)INFINITY;
+    P.hdr[i] = h;
+}
+
+__global__ void lob_set_portfolio_kernel(DevPtrs P, const int32_t* ids, int n, const int64_t* inv, const int64_t* cash) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    P.hdr[ids[i]].inventory = inv[i];
+    P.hdr[ids[i]].cash = cash[i];
+}
+
+}  // namespace lobk
+
+#include "lobsim_host.inc"

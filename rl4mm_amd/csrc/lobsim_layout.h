@@ -1,0 +1,126 @@
+// lobsim_layout.h - HBM / LDS data layout of the MI355X LOB simulator (shared by kernels and host glue).
+//
+// One wavefront (64 lanes) owns one env.  Everything an env owns is private to it, so no atomics, no
+// inter-workgroup communication: the only shared data is the read-only packed message stream.
+//
+// Per env in HBM (sized for 288 GB: we spend capacity to make every access O(1) and coalesced):
+//   EnvHdr                      scalars (clock, portfolio, resync bookkeeping, fill aggregates, free masks)
+//   Ladder                      per side LV price levels, sorted best-first (SoA: price, volume, slab, head, tail, live)
+//   Slot slabs[2*LV][SLOTS]     one fixed slab per price level = that level's FIFO queue; slot index = time
+//                               priority; removed orders leave tombstones, compacted lazily when the slab fills
+//   AgentOrd agent[NA]          the agent's own live orders (the reference's "internal orderbook")
+//   feature scalars + rings     rolling windows of the observation features
+// During a launch the ladder, the agent orders and the op list live in LDS; slabs stay in HBM/L2 and are read
+// 1 KiB per wave-instruction (16 B per lane), so "find order by id", "volume ahead" and "sweep the level" are
+// one coalesced load + ballot / prefix-sum.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/lobsim.h"
+
+namespace lobk {
+
+constexpr int WAVE = 64;
+constexpr int LV = 128;          // price levels per side (2 per lane)
+constexpr int SLOTS = 128;       // order slots per price level (2 per lane)
+constexpr int NSLAB = 2 * LV;    // slabs per env
+constexpr int NA = 128;          // live agent orders per env (2 per lane)
+constexpr int QMAX = 32;         // quote levels per side (2 * QMAX <= 64 lanes)
+constexpr int OPS_MAX = 2 * QMAX + 2 * NA + 8;  // agent op list: limits + cancels (+ resync re-adds) + market order
+
+constexpr int64_t DUMMY_PRICE = 9999999999ll;
+
+enum SlotKind : int32_t { K_EXT = 0, K_AGENT = 1, K_SNAP = 2, K_DEAD = 3 };
+
+struct alignas(16) Slot {
+    int64_t id;    // K_EXT: external id; K_AGENT: index into agent[]; K_SNAP: -1
+    int32_t vol;
+    int32_t kind;  // SlotKind
+};
+static_assert(sizeof(Slot) == 16, "slot must be one dwordx4");
+
+struct alignas(16) AgentOrd {
+    int64_t price;
+    int32_t vol;        // 0 = free entry
+    uint32_t seq_side;  // seq (31 bits, submission order within the episode) | side << 31
+};
+static_assert(sizeof(AgentOrd) == 16, "");
+
+struct alignas(16) Op {  // one agent order waiting to be processed (built from the pre-step state, then replayed)
+    int64_t price;
+    int32_t vol;
+    int32_t code;  // type (bits 0-3) | side << 4 | agent index << 8
+};
+
+struct Ladder {  // HBM image of the LDS ladder
+    int64_t price[2][LV];
+    int64_t vol[2][LV];
+    uint16_t slab[2][LV];
+    uint16_t head[2][LV];
+    uint16_t tail[2][LV];
+    uint16_t live[2][LV];
+};
+
+struct alignas(16) EnvHdr {
+    int64_t now_us, terminal_us, episode_start_us;
+    int64_t inventory, cash;
+    double price;
+    double min_buy, max_sell, init_buy_range, init_sell_range;  // OrderbookSimulator.py:49-53 (ints or inf)
+    int64_t msg_cursor;  // next unreplayed message of the stream
+    int32_t stream_id;
+    int32_t status;
+    int32_t n_lv[2];
+    int32_t n_resyncs;
+    uint32_t agent_seq;
+    uint64_t slab_free[NSLAB / 64];  // bit set = slab free
+    uint64_t agent_free[NA / 64];    // bit set = agent entry free
+    // fills of the last step
+    int64_t agent_fill_count, agent_vol[2], ext_count[2], ext_vol[2];
+    int64_t cash_delta;
+    double prev_action[LOBSIM_MAX_ACTION_DIM];
+};
+
+// Feature scalars, one per (env, feature).
+struct alignas(16) FeatState {
+    double current_value;
+    int64_t first_usage_us;
+    int32_t count;   // elements in the deque
+    int32_t pos;     // ring write position
+    double p_first;  // Volatility: first price of the fill-up window; also S accumulator partner
+    double p_last;   // newest price in the deque
+    double acc;      // Volatility: running sum of squares during fill-up
+    int64_t total, diff;  // trade imbalance running sums
+};
+
+struct StreamDev {
+    const int64_t* msgs;
+    const int64_t* snaps;
+    const int32_t* sec_to_snap;  // [n_secs]: last snapshot with t <= second, -1 if none
+    const int32_t* sec_to_msg;   // [n_secs]: first message with t > second
+    int64_t n_msgs, n_snaps;
+    int64_t first_sec;
+    int32_t n_secs;
+    int32_t pad;
+};
+
+struct DevCfg {
+    lobsim_cfg c;
+    double outer_prop;          // outer_levels / n_levels
+    int32_t Q;                  // quote levels
+    int32_t obs_dim;
+    int32_t ring_off[LOBSIM_MAX_FEATURES];  // offset of feature f's ring (in 8-byte words) inside an env's ring block
+    int32_t ring_words;         // ring words per env
+};
+
+struct DevPtrs {
+    EnvHdr* hdr;
+    Ladder* ladder;
+    Slot* slots;       // [env][NSLAB][SLOTS]
+    AgentOrd* agent;   // [env][NA]
+    FeatState* feat;   // [env][LOBSIM_MAX_FEATURES]
+    int64_t* rings;    // [env][ring_words]
+    const StreamDev* streams;
+    int32_t n_streams;
+};
+
+}  // namespace lobk

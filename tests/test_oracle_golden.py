@@ -7,7 +7,7 @@ import pytest
 
 import oracle_lib as ol
 from rl4mm_amd import _capi
-from traj_util import replay_and_check
+from traj_util import replay_and_check, run_engine_case
 
 TRAJ = ["msft_fixed", "msft_teradactyl_ad", "msft_random_allfeat", "synth_default_random", "synth_teradactyl_ad_spread",
         "synth_moc_conc", "synth_moc_crash", "synth_q5_fixed"]  # fmt: skip
@@ -34,31 +34,6 @@ def test_beta_table_matches_scipy():
 def engine_case_names():
     z = np.load(ol.GOLD / "engine_cases.npz")
     return [str(n) for n in z["names"]]
-
-
-def run_engine_case(sim, z, name, L):
-    """Returns nothing; asserts book + fills after every op equal the reference's."""
-    snap = z[f"{name}/snapshot"]
-    row = ol.snapshot_row_from_levels([tuple(r) for r in snap], L) if bool(z[f"{name}/has_snapshot"]) else None
-    sim.debug_set_book(0, row, 0)
-    sim.set_portfolio(0, 0)
-    ops, dumps, doff = z[f"{name}/ops"], z[f"{name}/dumps"], z[f"{name}/dump_off"]
-    fills, foff, status = z[f"{name}/fills"], z[f"{name}/fill_off"], z[f"{name}/status"]
-    for i in range(len(status)):
-        agg = sim.debug_process_orders(0, ops[i : i + 1])
-        st = sim.env_state(0)
-        if status[i]:
-            assert st["status"] & int(status[i]), f"{name} op {i}: expected status {status[i]}, got {st['status']}"
-            return
-        assert st["status"] == 0, f"{name} op {i} {ops[i]}: status {st['status']}"
-        q = sim.queues(0)
-        assert np.array_equal(q, dumps[doff[i] : doff[i + 1]]), f"{name} op {i} {ops[i]}:\n{q}\n!=\n{dumps[doff[i]:doff[i + 1]]}"
-        f = fills[foff[i] : foff[i + 1]]
-        ag, ex = f[f[:, 0] == 0], f[f[:, 0] == 1]
-        cash = int(np.sum(np.where(ag[:, 1] == 1, ag[:, 3] * ag[:, 2], -ag[:, 3] * ag[:, 2])))
-        exp = [len(ag), ag[ag[:, 1] == 0][:, 3].sum(), ag[ag[:, 1] == 1][:, 3].sum(), (ex[:, 1] == 0).sum(), (ex[:, 1] == 1).sum(),
-               ex[ex[:, 1] == 0][:, 3].sum(), ex[ex[:, 1] == 1][:, 3].sum(), cash]  # fmt: skip
-        assert list(agg) == [int(x) for x in exp], f"{name} op {i} {ops[i]}: fills {list(agg)} != {exp}"
 
 
 @pytest.mark.parametrize("name", engine_case_names())
