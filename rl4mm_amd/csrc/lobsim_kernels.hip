@@ -182,25 +182,29 @@ DI Slot load_slot(const Slot* sl, int i, int head, int tail) {
     return dead_slot();
 }
 
-// squeeze tombstones out of a full slab (FIFO order kept)
+// squeeze tombstones out of a slab (FIFO order kept); chunk by chunk, in place: a chunk's survivors always land
+// at or below the chunk's own first slot, so nothing unread is overwritten
 DI void compact_level(Lds& L, Scal& S, int side, int idx) {
     int ln = lane();
     int slab = uni(L.slab[side][idx]), head = uni(L.head[side][idx]), tail = uni(L.tail[side][idx]);
     Slot* sl = S.slots + (size_t)slab * SLOTS;
-    Slot s0 = load_slot(sl, ln, head, tail), s1 = load_slot(sl, ln + 64, head, tail);
-    uint64_t b0 = __ballot(s0.kind != K_DEAD), b1 = __ballot(s1.kind != K_DEAD);
     uint64_t below = (1ull << ln) - 1;
-    int n0 = popc64(b0);
-    wsync();  // all loads done before any store
-    if (s0.kind != K_DEAD) sl[popc64(b0 & below)] = s0;
-    if (s1.kind != K_DEAD) sl[n0 + popc64(b1 & below)] = s1;
-    if (ln == 0) { L.head[side][idx] = 0; L.tail[side][idx] = (uint16_t)(n0 + popc64(b1)); }
+    int out = 0;
+    for (int c = head >> 6; c * 64 < tail; c++) {
+        Slot s = load_slot(sl, c * 64 + ln, head, tail);
+        uint64_t b = __ballot(s.kind != K_DEAD);
+        wsync();  // every lane's load has landed before any lane stores
+        if (s.kind != K_DEAD) sl[out + popc64(b & below)] = s;
+        out += popc64(b);
+        wsync();
+    }
+    if (ln == 0) { L.head[side][idx] = 0; L.tail[side][idx] = (uint16_t)out; }
     wsync();
 }
 
 DI void level_append(Lds& L, Scal& S, int side, int idx, int64_t id, int32_t vol, int32_t kind) {
-    int tail = uni(L.tail[side][idx]);
-    if (tail == SLOTS) {
+    int tail = uni(L.tail[side][idx]), head = uni(L.head[side][idx]), live = uni(L.live[side][idx]);
+    if (tail == SLOTS || tail - head - live >= 64) {  // full, or a whole chunk's worth of tombstones: keep scans short
         compact_level(L, S, side, idx);
         tail = uni(L.tail[side][idx]);
         if (tail == SLOTS) { S.status |= LOBSIM_ST_QUEUE_OVERFLOW; return; }
@@ -223,20 +227,16 @@ DI int alloc_agent(Scal& S) {
     return a;
 }
 
-// Take `rv` shares off slot `pos` of level idx (slots already in registers as s0/s1): the tail of
+// Take `rv` shares off slot `pos` (whose current contents are pv / pk / pid) of level idx: the tail of
 // _reduce_order_with_queue_position + _clear_empty_orders_and_prices (Exchange.py:219-247).
-DI void reduce_slot(Lds& L, Scal& S, int side, int idx, int pos, int32_t rv, Slot s0, Slot s1) {
+DI void reduce_slot(Lds& L, Scal& S, int side, int idx, int pos, int32_t rv, int32_t pv, int32_t pk, int64_t pid) {
     int ln = lane();
     int head = uni(L.head[side][idx]), tail = uni(L.tail[side][idx]), slab = uni(L.slab[side][idx]);
     Slot* sl = S.slots + (size_t)slab * SLOTS;
-    Slot mine = pos < 64 ? s0 : s1;
-    int src = pos & 63;
-    int32_t pv = rl32(mine.vol, src), pk = rl32(mine.kind, src);
-    int64_t pid = rl64(mine.id, src);
     int32_t nv = pv - rv;
     bool gone = nv == 0;
-    if (ln == src) {
-        Slot w = mine; w.vol = nv; if (gone) w.kind = K_DEAD;
+    if (ln == 0) {
+        Slot w; w.id = pid; w.vol = nv; w.kind = gone ? K_DEAD : pk;
         sl[pos] = w;
         if (pk == K_AGENT) L.agent[pid].vol = nv;
     }
@@ -245,8 +245,14 @@ DI void reduce_slot(Lds& L, Scal& S, int side, int idx, int pos, int32_t rv, Slo
     if (gone && live == 0) { wsync(); ladder_remove(L, S, side, idx); return; }
     int new_head = head;
     if (gone && pos == head) {  // next live slot after pos
-        uint64_t a0 = __ballot(s0.kind != K_DEAD && ln > pos), a1 = __ballot(s1.kind != K_DEAD && ln + 64 > pos);
-        new_head = a0 ? ffs64(a0) : (a1 ? 64 + ffs64(a1) : tail);
+        wsync();
+        new_head = tail;
+        for (int c = pos >> 6; c * 64 < tail; c++) {
+            int i = c * 64 + ln;
+            Slot s = load_slot(sl, i, head, tail);
+            uint64_t a = __ballot(s.kind != K_DEAD && i > pos);
+            if (a) { new_head = c * 64 + ffs64(a); break; }
+        }
     }
     if (ln == 0) { L.vol[side][idx] -= rv; L.live[side][idx] = (uint16_t)live; L.head[side][idx] = (uint16_t)new_head; }
     wsync();
@@ -261,19 +267,24 @@ DI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, int
     int ln = lane();
     int head = uni(L.head[side][idx]), tail = uni(L.tail[side][idx]), slab = uni(L.slab[side][idx]);
     const Slot* sl = S.slots + (size_t)slab * SLOTS;
-    Slot s0 = load_slot(sl, ln, head, tail), s1 = tail > 64 ? load_slot(sl, ln + 64, head, tail) : dead_slot();
-    uint64_t b0 = __ballot(s0.kind == kind && s0.id == id), b1 = __ballot(s1.kind == kind && s1.id == id);
-    int pos = b1 ? 64 + fls64(b1) : fls64(b0);
+    int pos = -1;
+    int32_t pv = 0, hk = K_DEAD, hv = 0;
+    for (int c = head >> 6; c * 64 < tail; c++) {  // independent 1 KiB loads: one ballot per chunk finds the order
+        Slot s = load_slot(sl, c * 64 + ln, head, tail);
+        uint64_t b = __ballot(s.kind == kind && s.id == id);
+        if (b) { int l = fls64(b); pos = c * 64 + l; pv = rl32(s.vol, l); }
+        if (c == (head >> 6)) { hk = rl32(s.kind, head & 63); hv = rl32(s.vol, head & 63); }
+    }
+    int32_t pk = kind;
+    int64_t pid = id;
     if (pos < 0) {
         // unknown id: if the head is a snapshot order (internal_id == -1) it absorbs the removal (:133-137)
-        int32_t hk = head < 64 ? rl32(s0.kind, head & 63) : rl32(s1.kind, head & 63);
         if (hk != K_SNAP) return;
         if (vol < 0) { S.status |= LOBSIM_ST_ASSERT; return; }
-        pos = head;
+        pos = head; pv = hv; pk = K_SNAP; pid = -1;
     }
-    int32_t pv = pos < 64 ? rl32(s0.vol, pos & 63) : rl32(s1.vol, pos & 63);
     int32_t rv = vol < 0 ? pv : (vol > pv ? pv : vol);  // CancellationVolumeExceededError -> whole remainder (:144-146)
-    reduce_slot(L, S, side, idx, pos, rv, s0, s1);
+    reduce_slot(L, S, side, idx, pos, rv, pv, pk, pid);
 }
 
 // execute_order (Exchange.py:85-120): the aggressor (side, limit price or market) sweeps the opposite side level by
@@ -293,10 +304,8 @@ DI int32_t execute(Lds& L, Scal& S, int side, bool is_agent, bool is_market, int
         Slot* sl = S.slots + (size_t)slab * SLOTS;
         int32_t carry = 0, exec_ext = 0, exec_agent = 0, deleted_agent_vol = 0, n_ext = 0, n_agent = 0, n_removed = 0;
         int first_survivor = tail;
-        for (int r = 0; r < 2; r++) {
-            if (r * 64 >= tail) break;
-            if (head >= 64 * (r + 1)) continue;
-            int i = ln + 64 * r;
+        for (int c = head >> 6; c * 64 < tail; c++) {
+            int i = c * 64 + ln;
             Slot s = load_slot(sl, i, head, tail);
             bool live = s.kind != K_DEAD;
             bool own = is_agent && s.kind == K_AGENT;  // the agent cannot fill its own order: it is deleted (:91-94)
@@ -313,12 +322,10 @@ DI int32_t execute(Lds& L, Scal& S, int side, bool is_agent, bool is_market, int
                 if (s.kind == K_AGENT) L.agent[s.id].vol = nv;
             }
             uint64_t gone_agent = __ballot(gone && s.kind == K_AGENT);
-            // freed agent entries (uniform bookkeeping): ids live in lanes, gather them
-            while (gone_agent) {
+            while (gone_agent) {  // freed agent entries (uniform bookkeeping): ids live in lanes, gather them
                 int b = ffs64(gone_agent);
                 gone_agent &= gone_agent - 1;
-                int64_t aid = rl64(s.id, b);
-                S.agent_pending.set((int)aid);
+                S.agent_pending.set((int)rl64(s.id, b));
             }
             bool ext_fill = reached && !own && s.kind != K_AGENT;
             bool ag_fill = reached && !own && s.kind == K_AGENT;
@@ -330,7 +337,7 @@ DI int32_t execute(Lds& L, Scal& S, int side, bool is_agent, bool is_market, int
             deleted_agent_vol += wave_sum((reached && own) ? s.vol : 0);
             carry += rl32(incl, 63);
             uint64_t surv = __ballot(live && !gone);
-            if (surv && first_survivor == tail) first_survivor = 64 * r + ffs64(surv);
+            if (surv) { first_survivor = c * 64 + ffs64(surv); break; }  // a survivor means the sweep ended in this chunk
         }
         int32_t E = exec_ext + exec_agent;
         rem -= E;

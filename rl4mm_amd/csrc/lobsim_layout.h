@@ -7,7 +7,8 @@
 //   EnvHdr                      scalars (clock, portfolio, resync bookkeeping, fill aggregates, free masks)
 //   Ladder                      per side LV price levels, sorted best-first (SoA: price, volume, slab, head, tail, live)
 //   Slot slabs[2*LV][SLOTS]     one fixed slab per price level = that level's FIFO queue; slot index = time
-//                               priority; removed orders leave tombstones, compacted lazily when the slab fills
+//                               priority; removed orders leave tombstones, squeezed out once a chunk's worth
+//                               (64) has piled up, so a scan touches ceil(live/64)+1 chunks
 //   AgentOrd agent[NA]          the agent's own live orders (the reference's "internal orderbook")
 //   feature scalars + rings     rolling windows of the observation features
 // During a launch the ladder, the agent orders and the op list live in LDS; slabs stay in HBM/L2 and are read
@@ -22,7 +23,7 @@ namespace lobk {
 
 constexpr int WAVE = 64;
 constexpr int LV = 128;          // price levels per side (2 per lane)
-constexpr int SLOTS = 128;       // order slots per price level (2 per lane)
+constexpr int SLOTS = 512;       // order slots per price level (8 chunks of one wave-load each; 8 KiB slab)
 constexpr int NSLAB = 2 * LV;    // slabs per env
 constexpr int NA = 128;          // live agent orders per env (2 per lane)
 constexpr int QMAX = 32;         // quote levels per side (2 * QMAX <= 64 lanes)
