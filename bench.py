@@ -107,7 +107,9 @@ def main():
     stream = build_stream(sim_seconds)
     cfg = _capi.make_cfg(N, 10, default_features(_capi), step_us=STEP_US, episode_us=EPISODE_US, device_id=local_rank)
     sim = _lib.new_sim(cfg)
-    sim.set_stream(torch.cuda.current_stream().cuda_stream)  # kernels run on torch's stream: events below see them
+    # kernels run on a torch-owned (non-default) stream so the torch.cuda.Event pairs below time exactly them
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+    sim.set_stream(torch.cuda.current_stream().cuda_stream)
     sim.add_stream(stream)
     sim.set_portfolio(0, 10**12)  # initial_cash 1e12 (main_helper.py:78)
     rng = np.random.Generator(np.random.PCG64(1234 + rank))

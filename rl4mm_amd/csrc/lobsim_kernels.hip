@@ -78,7 +78,15 @@ struct Scal {
 };
 
 DI int lane() { return (int)threadIdx.x; }
-DI void wsync() { __syncthreads(); }  // block == one wave: orders LDS + global accesses between lanes
+// Lanes of ONE wave exchange data through LDS and through the env's own slabs.  A wavefront's LDS instructions and
+// its vector-memory instructions each execute in program order, so a later instruction of the same wave observes an
+// earlier one's write without any s_waitcnt; what must be prevented is the COMPILER moving or caching accesses
+// across the hand-off.  A wavefront-scope fence is exactly that: no instruction emitted, no vmcnt(0) drain (a
+// __syncthreads() here cost a full global-store round trip per order: 0.94 ms -> see profiles/).
+DI void wsync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
 DI int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 DI int32_t rl32(int32_t v, int src) { return __builtin_amdgcn_readlane(v, src); }
