@@ -40,9 +40,11 @@ struct Lds {
 template <typename T>
 struct Pair {  // two wave-uniform values selected by side; kept as two registers (no dynamic register indexing)
     T a, b;
-    DI T operator[](int i) const { return i ? b : a; }
-    DI void set(int i, T v) { if (i) b = v; else a = v; }
-    DI void add(int i, T v) { if (i) b += v; else a += v; }
+    DI T operator[](int i) const { T x = a, y = b; return i ? y : x; }  // unconditional loads, select on VALUES
+    // value selects with unconditional stores: an `if (i) b = v; else a = v;` is turned into a store through a
+    // selected POINTER, which keeps the whole struct in scratch memory
+    DI void set(int i, T v) { a = i ? a : v; b = i ? v : b; }
+    DI void add(int i, T v) { a += i ? T(0) : v; b += i ? v : T(0); }
 };
 template <int N>
 struct Mask {  // N x 64-bit mask with uniform bit access through unrolled selects
@@ -53,7 +55,7 @@ struct Mask {  // N x 64-bit mask with uniform bit access through unrolled selec
     }
     DI void set(int bit) {
 #pragma unroll
-        for (int i = 0; i < N; i++) if ((bit >> 6) == i) w[i] |= 1ull << (bit & 63);
+        for (int i = 0; i < N; i++) w[i] |= (bit >> 6) == i ? 1ull << (bit & 63) : 0ull;  // unconditional: no w[bit >> 6]
     }
     DI int take_first() {  // clears and returns the lowest set bit, -1 if empty
         int r = -1;
@@ -430,12 +432,17 @@ DI double np_pairwise_sum(const double* a, int n) {  // numpy add.reduce order f
     return res;
 }
 
-DI double act_at(const double* a, int i) {  // register-array read with a runtime index, as selects
-    double r = a[0];
-#pragma unroll
-    for (int k = 1; k < LOBSIM_MAX_ACTION_DIM; k++) r = i == k ? a[k] : r;
-    return r;
-}
+struct Act5 {  // the action vector as five scalars (an array indexed at run time would live in scratch memory)
+    double v0, v1, v2, v3, v4;
+    DI double at(int i) const {
+        double a = v0, b = v1, c = v2, d = v3, e = v4;  // unconditional loads, select on values
+        double r = i == 1 ? b : a;
+        r = i == 2 ? c : r;
+        r = i == 3 ? d : r;
+        return i == 4 ? e : r;
+    }
+};
+DI double act_at(const Act5& a, int i) { return a.at(i); }
 
 DI void push_op(Lds& L, Scal& S, int type, int side, int aidx, int64_t price, int32_t vol) {
     if (lane() == 0 && S.n_ops < OPS_MAX) { Op o; o.price = price; o.vol = vol; o.code = type | (side << 4) | (aidx << 8); L.ops[S.n_ops] = o; }
@@ -444,7 +451,7 @@ DI void push_op(Lds& L, Scal& S, int type, int side, int aidx, int64_t price, in
 
 // Builds L.ops from the action and the PRE-step book; nothing is mutated (the reference computes the whole
 // order list first and only then hands it to the simulator).
-DI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const double* action) {
+DI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action) {
     const lobsim_cfg& c = C.c;
     const int Q = C.Q, ln = lane();
     const int64_t tick = c.tick_size;
@@ -948,9 +955,10 @@ __global__ __launch_bounds__(64) void lob_step_kernel(DevCfg C, DevPtrs P, StepA
     FeatState fs = FeatState();
     int64_t* ring = nullptr;
     if (ln < F) { fs = P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln]; ring = P.rings + (size_t)env * C.ring_words + C.ring_off[ln]; }
-    double act[LOBSIM_MAX_ACTION_DIM];
-#pragma unroll
-    for (int i = 0; i < LOBSIM_MAX_ACTION_DIM; i++) act[i] = i < AD ? A.actions[(size_t)env * AD + i] : 0.0;
+    const double* ap = A.actions + (size_t)env * AD;
+    Act5 act;
+    act.v0 = ap[0]; act.v1 = ap[1];
+    act.v2 = AD > 2 ? ap[2] : 0.0; act.v3 = AD > 3 ? ap[3] : 0.0; act.v4 = AD > 4 ? ap[4] : 0.0;
     int64_t now = H.now_us, cursor = H.msg_cursor;
     int stream_id = H.stream_id;
     Ranges R = {H.min_buy, H.max_sell, H.init_buy_range, H.init_sell_range};
@@ -991,7 +999,7 @@ __global__ __launch_bounds__(64) void lob_step_kernel(DevCfg C, DevPtrs P, StepA
     if (ln == 0) {
         H.now_us = now; H.msg_cursor = cursor; H.price = price; H.n_resyncs = n_resyncs;
         H.min_buy = R.min_buy; H.max_sell = R.max_sell;
-        for (int i = 0; i < LOBSIM_MAX_ACTION_DIM; i++) H.prev_action[i] = act[i];
+        H.prev_action[0] = act.v0; H.prev_action[1] = act.v1; H.prev_action[2] = act.v2; H.prev_action[3] = act.v3; H.prev_action[4] = act.v4;
     }
 }
 
