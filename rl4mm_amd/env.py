@@ -1,0 +1,499 @@
+"""Host-side mirror of the reference's Gym interface for the LOB step, backed by the HIP library.
+
+Same names, constructor arguments and return shapes as the reference so it drops into the existing RLlib loop:
+
+* ``HistoricalOrderbookEnvironment``      single env, ``reset() -> obs``, ``step(a) -> (obs, reward, done, info)``
+  (reference rl4mm/gym/HistoricalOrderbookEnvironment.py:51-178)
+* ``HistoricalOrderbookVectorEnv``        the same for N envs per launch, RLlib ``VectorEnv`` shaped
+  (``vector_reset / reset_at / vector_step``); this is what a rollout worker should hold
+* feature / reward descriptor classes     same class names and kwargs as rl4mm/features/Features.py and
+  rl4mm/rewards/RewardFunctions.py, but they only *describe* the computation: the arithmetic runs in the kernel
+* ``env_creator(env_config)``             rl4mm/gym/utils.py:42-87 with the same env_config keys
+* ``StreamCatalog``                       replaces ``HistoricalDatabase`` as the data source: packed (ticker, day)
+  streams (rl4mm_amd/stream.py)
+
+`gym` and `ray` are optional: spaces fall back to a minimal Box with the attributes RLlib and the reference's
+agents read (low, high, shape, dtype, sample, seed).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from datetime import datetime, timedelta
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import pandas as pd
+
+from . import _capi, _lib
+from .stream import PackedStream
+
+try:  # pragma: no cover - gym is not installed in the build image
+    from gym.spaces import Box  # type: ignore
+except Exception:  # noqa: BLE001
+
+    class Box:  # minimal stand-in
+        def __init__(self, low, high, shape=None, dtype=np.float32):
+            if shape is None:
+                shape = np.shape(low)
+            self.low = np.broadcast_to(np.asarray(low, dtype=dtype), shape).copy()
+            self.high = np.broadcast_to(np.asarray(high, dtype=dtype), shape).copy()
+            self.shape = tuple(shape)
+            self.dtype = np.dtype(dtype)
+            self._rng = np.random.default_rng()
+
+        def seed(self, seed=None):
+            self._rng = np.random.default_rng(seed)
+            return [seed]
+
+        def sample(self):
+            return self._rng.uniform(self.low, self.high).astype(self.dtype)
+
+        def contains(self, x):
+            return bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+
+US = timedelta(microseconds=1)
+
+
+def _us(td: timedelta) -> int:
+    return int(td / US)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# feature / reward descriptors (rl4mm/features/Features.py, rl4mm/rewards/RewardFunctions.py)
+# ---------------------------------------------------------------------------------------------------------------
+@dataclass
+class Portfolio:  # Features.py:24-27
+    inventory: int
+    cash: float
+
+
+class Feature:
+    kind = 0
+
+    def __init__(self, name, min_value, max_value, update_frequency, lookback_periods, normalisation_on=False, max_norm_len=10000):
+        assert update_frequency <= timedelta(minutes=1), "HFT update frequency must be less than 1 minute."  # Features.py:53
+        if normalisation_on:
+            raise NotImplementedError("z-score normalisation (Features.py:67-74) is not on the device path yet")
+        self.name, self.min_value, self.max_value = name, min_value, max_value
+        self.update_frequency, self.lookback_periods = update_frequency, lookback_periods
+        self.normalisation_on = normalisation_on
+
+    @property
+    def window_size(self) -> timedelta:
+        return self.lookback_periods * self.update_frequency
+
+    def desc(self) -> _capi.FeatureDesc:
+        return _capi.make_feature(self.kind, self.lookback_periods, _us(self.update_frequency), self.min_value, self.max_value)
+
+
+class Spread(Feature):  # Features.py:113
+    kind = _capi.F_SPREAD
+
+    def __init__(self, name="Spread", min_value=0, max_value=50 * 100, update_frequency=timedelta(seconds=0.1), normalisation_on=False, max_norm_len=10000):
+        super().__init__(name, min_value, max_value, update_frequency, 0, normalisation_on, max_norm_len)
+
+
+class BookImbalance(Feature):  # :132
+    kind = _capi.F_BOOK_IMBALANCE
+
+    def __init__(self, update_frequency=timedelta(seconds=0.1)):
+        super().__init__("BookImbalance", -1, 1, update_frequency, 0, False, 0)
+
+
+class PriceMove(Feature):  # :151
+    kind = _capi.F_PRICE_MOVE
+
+    def __init__(self, name="MidpriceMove", min_value=-100 * 100, max_value=100 * 100, update_frequency=timedelta(seconds=1), lookback_periods=10, normalisation_on=False, max_norm_len=100_000):
+        super().__init__(name, min_value, max_value, update_frequency, lookback_periods, normalisation_on, max_norm_len)
+
+
+class PriceRange(Feature):  # :178
+    kind = _capi.F_PRICE_RANGE
+
+    def __init__(self, name="PriceRange", min_value=0, max_value=100 * 100, update_frequency=timedelta(seconds=1), lookback_periods=10, normalisation_on=False, max_norm_len=100_000):
+        super().__init__(name, min_value, max_value, update_frequency, lookback_periods, normalisation_on, max_norm_len)
+
+
+class Volatility(Feature):  # :203
+    kind = _capi.F_VOLATILITY
+
+    def __init__(self, name="Volatility", min_value=0, max_value=1.0, update_frequency=timedelta(seconds=1), lookback_periods=10, normalisation_on=False, max_norm_len=100_000):
+        super().__init__(name, min_value, max_value, update_frequency, lookback_periods, normalisation_on, max_norm_len)
+
+
+class Price(Feature):  # :327
+    kind = _capi.F_PRICE
+
+    def __init__(self, name="Price", min_value=0, max_value=10_000 * 10_000, update_frequency=timedelta(seconds=1), normalisation_on=False, max_norm_len=100_000):
+        super().__init__(name, min_value, max_value, update_frequency, 0, normalisation_on, max_norm_len)
+
+
+class TradeDirectionImbalance(Feature):  # :351
+    kind = _capi.F_TRADE_DIRECTION_IMBALANCE
+
+    def __init__(self, name="TradeImbalance", update_frequency=timedelta(seconds=0.1), lookback_periods=600, track_internal=False, normalisation_on=False, max_norm_len=100_000):
+        if track_internal:
+            raise NotImplementedError("track_internal=True is not on the device path")
+        super().__init__(name, -1.0, 1.0, update_frequency, lookback_periods, normalisation_on, max_norm_len)
+
+
+class TradeVolumeImbalance(TradeDirectionImbalance):  # :410
+    kind = _capi.F_TRADE_VOLUME_IMBALANCE
+
+    def __init__(self, name="TradeVolumeImbalance", **kw):
+        super().__init__(name, **kw)
+
+
+class Inventory(Feature):  # :474
+    kind = _capi.F_INVENTORY
+
+    def __init__(self, name="Inventory", min_value=-1000000, max_value=1000000, update_frequency=timedelta(seconds=0.1), normalisation_on=False, max_norm_len=100_000):
+        super().__init__(name, min_value, max_value, update_frequency, 0, normalisation_on, max_norm_len)
+
+
+class EpisodeProportion(Feature):  # :493
+    kind = _capi.F_EPISODE_PROPORTION
+
+    def __init__(self, name="EpisodeProportion", update_frequency=timedelta(seconds=0.1), episode_length=timedelta(minutes=60), normalisation_on=False, max_norm_len=100_000):
+        super().__init__(name, 0.0, 1.0, update_frequency, 0, normalisation_on, max_norm_len)
+        self.episode_length = episode_length
+        self.step_size = update_frequency / episode_length  # :505
+
+    def desc(self):
+        d = super().desc()
+        d.dparam = float(self.step_size)
+        return d
+
+
+class TimeOfDay(Feature):  # :515
+    kind = _capi.F_TIME_OF_DAY
+
+    def __init__(self, name="TimeOfDay", update_frequency=timedelta(minutes=1), normalisation_on=False, max_norm_len=100_000, n_buckets=10):
+        super().__init__(name, 0, n_buckets - 1, update_frequency, 0, normalisation_on, max_norm_len)
+        self.n_buckets = n_buckets
+        self.bucket_size = (timedelta(hours=15, minutes=30) - timedelta(hours=10)) / n_buckets  # :526-528
+
+    def desc(self):
+        d = super().desc()
+        d.iparam = _us(self.bucket_size)
+        return d
+
+
+class RewardFunction:
+    def desc(self) -> Tuple[int, int, float]:
+        raise NotImplementedError
+
+
+class PnL(RewardFunction):  # RewardFunctions.py:97
+    def desc(self):
+        return (_capi.R_PNL, 0, 0.0)
+
+
+class InventoryAdjustedPnL(RewardFunction):  # :107
+    def __init__(self, inventory_aversion: float, asymmetrically_dampened: bool = False):
+        self.inventory_aversion, self.asymmetrically_dampened = inventory_aversion, asymmetrically_dampened
+
+    def desc(self):
+        return (_capi.R_INVENTORY_ADJUSTED, int(self.asymmetrically_dampened), float(self.inventory_aversion))
+
+
+def get_reward_function(reward_function: str, inventory_aversion: float = 0.1) -> RewardFunction:  # rl4mm/gym/utils.py:29-39
+    if reward_function == "AD":
+        return InventoryAdjustedPnL(inventory_aversion=inventory_aversion, asymmetrically_dampened=True)
+    if reward_function == "SD":
+        return InventoryAdjustedPnL(inventory_aversion=inventory_aversion, asymmetrically_dampened=False)
+    if reward_function == "PnL":
+        return PnL()
+    if reward_function == "RS":
+        raise NotImplementedError("RollingSharpe (RewardFunctions.py:38-94) is not on the device path yet")
+    raise NotImplementedError("You must specify one of 'AS', 'SD', 'PnL', or 'RS'")
+
+
+def get_default_features(step_size: timedelta, episode_length: timedelta, normalisation_on: bool = False) -> List[Feature]:
+    """HistoricalOrderbookEnvironment.get_default_features (HistoricalOrderbookEnvironment.py:395-440)."""
+    assert step_size <= timedelta(seconds=0.1), "Default features require a minimum step size of 0.1 seconds."
+    n = normalisation_on
+    return [
+        Spread(update_frequency=step_size, normalisation_on=n),
+        PriceMove(name="price_move_0.1_s", update_frequency=timedelta(seconds=0.1), lookback_periods=1, normalisation_on=n),
+        PriceMove(name="price_move_10_s", update_frequency=timedelta(seconds=1), lookback_periods=10, normalisation_on=n),
+        Volatility(name="volatility_1_min", update_frequency=timedelta(seconds=0.1), lookback_periods=600, normalisation_on=n),
+        Volatility(name="volatility_5_min", update_frequency=timedelta(seconds=1), lookback_periods=300, normalisation_on=n),
+        Inventory(update_frequency=step_size, normalisation_on=n),
+        EpisodeProportion(update_frequency=step_size, episode_length=episode_length, normalisation_on=n),
+        TimeOfDay(n_buckets=10, normalisation_on=n),
+        TradeDirectionImbalance(update_frequency=timedelta(seconds=0.1), lookback_periods=600, normalisation_on=n),
+        TradeVolumeImbalance(update_frequency=timedelta(seconds=0.1), lookback_periods=600, normalisation_on=n),
+    ]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# data source
+# ---------------------------------------------------------------------------------------------------------------
+class StreamCatalog:
+    """(ticker, 'YYYY-MM-DD') -> PackedStream.  Stands where ``HistoricalDatabase`` stood."""
+
+    def __init__(self):
+        self._streams: Dict[Tuple[str, str], PackedStream] = {}
+
+    def add(self, stream: PackedStream) -> "StreamCatalog":
+        self._streams[(stream.ticker, stream.trading_date)] = stream
+        return self
+
+    def get(self, ticker: str, date: str) -> PackedStream:
+        try:
+            return self._streams[(ticker, date)]
+        except KeyError:
+            raise KeyError(f"no packed stream for {ticker} on {date}; loaded: {sorted(self._streams)}") from None
+
+    def items(self):
+        return self._streams.items()
+
+    def __len__(self):
+        return len(self._streams)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# environments
+# ---------------------------------------------------------------------------------------------------------------
+class HistoricalOrderbookVectorEnv:
+    """N independent copies of the reference env stepped by one kernel launch (RLlib VectorEnv shape)."""
+
+    def __init__(
+        self,
+        num_envs: int,
+        catalog: StreamCatalog,
+        features: List[Feature] = None,
+        max_distribution_param: float = 10.0,
+        ticker: str = "MSFT",
+        step_size: timedelta = timedelta(seconds=0.1),
+        episode_length: timedelta = timedelta(minutes=30),
+        initial_portfolio: Portfolio = None,
+        min_quote_level: int = 0,
+        max_quote_level: int = 10,
+        min_date: datetime = datetime(2019, 1, 2),
+        max_date: datetime = datetime(2019, 1, 2),
+        min_start_timedelta: timedelta = timedelta(hours=10),
+        max_end_timedelta: timedelta = timedelta(hours=15, minutes=30),
+        market_order_clearing: bool = False,
+        inc_prev_action_in_obs: bool = False,
+        max_inventory: int = 100000,
+        per_step_reward_function: RewardFunction = None,
+        terminal_reward_function: RewardFunction = None,
+        info_calculator=None,
+        concentration: Optional[float] = None,
+        market_order_fraction_of_inventory: float = 0.0,
+        enter_spread: bool = False,
+        n_levels: int = 50,
+        outer_levels: int = 20,
+        device_id: int = 0,
+    ):
+        # action space, HistoricalOrderbookEnvironment.py:85-94
+        if concentration is not None:
+            assert concentration >= max_distribution_param, "Concentration is less than max_distribution_param."
+            self.action_space = Box(low=0.0, high=concentration, shape=(2,), dtype=np.float64)
+        else:
+            self.action_space = Box(low=0.0, high=max_distribution_param, shape=(4,), dtype=np.float64)
+        if market_order_clearing:
+            self.action_space = Box(low=np.append(self.action_space.low, [0.0]), high=np.append(self.action_space.high, [max_inventory]), dtype=np.float64)
+        assert episode_length % step_size == timedelta(0), "Episode length must be a multiple of step size!"  # :100
+        assert min_start_timedelta + episode_length <= max_end_timedelta, "Episode is too long"  # :372
+        if (market_order_clearing and market_order_fraction_of_inventory <= 0.0) or (not market_order_clearing and market_order_fraction_of_inventory > 0.0):
+            raise Exception("market_order_fraction_of_inventory must be positive if and only if market order clearing is on")  # :376-384
+        if info_calculator is not None:
+            raise NotImplementedError("info calculators are host-side; pass None (the reference default, main_helper.py:233)")
+        self.num_envs = num_envs
+        self.catalog = catalog
+        self.ticker, self.step_size, self.episode_length = ticker, step_size, episode_length
+        self.min_date, self.max_date = min_date, max_date
+        self.min_start_timedelta, self.max_end_timedelta = min_start_timedelta, max_end_timedelta
+        self.initial_portfolio = initial_portfolio or Portfolio(inventory=0, cash=1000)  # :104
+        self.features = features or get_default_features(step_size, episode_length)
+        self.inc_prev_action_in_obs = inc_prev_action_in_obs
+        self.per_step_reward_function = per_step_reward_function or InventoryAdjustedPnL(inventory_aversion=10 ** (-4))  # :72
+        self.terminal_reward_function = terminal_reward_function or InventoryAdjustedPnL(inventory_aversion=0.1)  # :73
+        low = np.array([np.float32(f.min_value) for f in self.features])
+        high = np.array([np.float32(f.max_value) for f in self.features])
+        if inc_prev_action_in_obs:
+            low = np.concatenate((low, np.float32(self.action_space.low)))
+            high = np.concatenate((high, np.float32(self.action_space.high)))
+        self.observation_space = Box(low=low, high=high, dtype=np.float32)  # :125-135
+        self.max_feature_window_size = max(f.window_size for f in self.features)
+        cfg = _capi.make_cfg(
+            num_envs, n_levels, [f.desc() for f in self.features], step_us=_us(step_size), episode_us=_us(episode_length),
+            warmup_us=_us(self.max_feature_window_size), outer_levels=outer_levels, min_quote_level=min_quote_level, max_quote_level=max_quote_level,
+            concentration=concentration, market_order_clearing=market_order_clearing, market_order_fraction_of_inventory=market_order_fraction_of_inventory,
+            enter_spread=enter_spread, inc_prev_action_in_obs=inc_prev_action_in_obs, per_step_reward=self.per_step_reward_function.desc(),
+            terminal_reward=self.terminal_reward_function.desc(), device_id=device_id,
+        )  # fmt: skip
+        self.sim = _lib.new_sim(cfg)  # raises if the HIP library or the GPU is missing: there is no CPU path
+        self._stream_ids: Dict[Tuple[str, str], int] = {}
+        for key, stream in catalog.items():
+            if key[0] == ticker:
+                self._stream_ids[key] = self.sim.add_stream(stream)
+        cash = self.initial_portfolio.cash
+        assert float(cash) == int(cash), "cash must be integer valued (it is kept exact as int64)"
+        self.sim.set_portfolio(int(self.initial_portfolio.inventory), int(cash))
+        self._dones = np.zeros(num_envs, dtype=bool)
+
+    # ---- start-time draw: same np.random calls, in the same order, as the reference (:196, :333-351) -------------
+    def _random_offset_timestamp(self) -> timedelta:
+        max_offset_steps = int((self.max_end_timedelta - self.episode_length - self.min_start_timedelta) / self.step_size)
+        try:
+            random_offset_steps = np.random.randint(low=0, high=max_offset_steps)
+        except ValueError:
+            random_offset_steps = 0
+        ts = self.min_start_timedelta + random_offset_steps * self.step_size
+        return ts - timedelta(microseconds=ts.microseconds)
+
+    def _get_random_trading_day(self) -> datetime:
+        trading_dates = pd.bdate_range(self.min_date, self.max_date)
+        d = pd.to_datetime(np.random.choice(trading_dates))  # get_next_trading_dt: weekdays only, NASDAQ holidays are not modelled
+        return datetime.combine(d.date(), datetime.min.time())
+
+    def _get_random_start_time(self) -> datetime:
+        return self._get_random_trading_day() + self._random_offset_timestamp()
+
+    def _draw(self, n: int):
+        sids, starts = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int64)
+        for i in range(n):
+            t = self._get_random_start_time()
+            key = (self.ticker, t.strftime("%Y-%m-%d"))
+            if key not in self._stream_ids:
+                raise KeyError(f"no packed stream loaded for {key}")
+            sids[i] = self._stream_ids[key]
+            starts[i] = _us(t - datetime.combine(t.date(), datetime.min.time()))
+        return sids, starts
+
+    # ---- VectorEnv API ------------------------------------------------------------------------------------------
+    def vector_reset(self) -> List[np.ndarray]:
+        sids, starts = self._draw(self.num_envs)
+        obs = self.sim.reset(starts, sids)
+        self._dones[:] = False
+        return list(obs)
+
+    def reset_at(self, index: Optional[int] = None) -> np.ndarray:
+        index = 0 if index is None else index
+        return self.reset_many([index])[0]
+
+    def reset_many(self, indices: Sequence[int]) -> np.ndarray:
+        ids = np.asarray(indices, dtype=np.int32)
+        sids, starts = self._draw(len(ids))
+        obs = self.sim.reset(starts, sids, ids)
+        self._dones[ids] = False
+        return obs
+
+    def vector_step(self, actions):
+        obs, reward, done = self.sim.step(np.asarray(actions, dtype=np.float64), active=(~self._dones).astype(np.uint8))
+        self._dones |= done.astype(bool)
+        return list(obs), list(reward), list(done.astype(bool)), [{} for _ in range(self.num_envs)]
+
+    def get_sub_environments(self):
+        return []
+
+    def portfolios(self):
+        """(inventory int64[N], cash int64[N], price f64[N]) straight from device state."""
+        return self.sim.portfolios()
+
+    def close(self):
+        self.sim.close()
+
+
+class HistoricalOrderbookEnvironment:
+    """Single-env facade with the reference's gym.Env surface (reset / step / seed / render / spaces)."""
+
+    metadata = {"render.modes": ["human"]}
+
+    def __init__(self, catalog: StreamCatalog = None, **kwargs):
+        if catalog is None:
+            raise ValueError("pass catalog=StreamCatalog(...): packed streams replace the reference's HistoricalDatabase")
+        kwargs.pop("simulator", None)
+        kwargs.pop("order_distributor", None)
+        kwargs.pop("preload_orders", None)
+        self._venv = HistoricalOrderbookVectorEnv(1, catalog, **kwargs)
+        self.action_space = self._venv.action_space
+        self.observation_space = self._venv.observation_space
+        self.features = self._venv.features
+        self.spec = None
+
+    def reset(self):
+        return self._venv.reset_at(0)
+
+    def step(self, action: np.ndarray):
+        obs, reward, done, info = self._venv.vector_step(np.asarray(action, dtype=np.float64)[None, :])
+        st = self._venv.sim.env_state(0) if done[0] else None
+        if st is not None and st["status"]:
+            self._raise(st["status"])
+        return obs[0], float(reward[0]), bool(done[0]), info[0]
+
+    @staticmethod
+    def _raise(status: int):  # the exceptions the reference raises on the same conditions
+        if status & _capi.ST_EMPTY_BOOK:
+            raise EmptyOrderbookError("Trying take liquidity from empty side of the book.")
+        if status & _capi.ST_ASSERT:
+            raise AssertionError("Order volume must be positive.")
+        raise RuntimeError(f"env stopped with status {status} (see include/lobsim.h: enum lobsim_status)")
+
+    def seed(self, seed=42):
+        self.np_random = np.random.RandomState(seed)
+        return [seed]
+
+    def render(self, mode="human"):
+        pass
+
+    def close(self):
+        self._venv.close()
+
+    @staticmethod
+    def get_default_features(step_size: timedelta, episode_length: timedelta, normalisation_on: bool = False):
+        return get_default_features(step_size, episode_length, normalisation_on)
+
+
+class EmptyOrderbookError(Exception):  # rl4mm/orderbook/Exchange.py:32-33
+    pass
+
+
+def env_creator(env_config: dict, catalog: StreamCatalog = None, num_envs: Optional[int] = None):
+    """rl4mm/gym/utils.py:42-87 with the same env_config keys.  ``num_envs`` (or env_config["num_envs"]) > 1 returns
+    the batched VectorEnv instead of the single-env facade."""
+    catalog = catalog if catalog is not None else env_config.get("catalog")
+    episode_length = timedelta(minutes=env_config["episode_length"])
+    step_size = timedelta(seconds=env_config["step_size"])
+    if env_config["features"] == "agent_state":
+        features = [Inventory(max_value=env_config["max_inventory"], normalisation_on=env_config["normalisation_on"])]
+    elif env_config["features"] == "full_state":
+        features = get_default_features(step_size, episode_length, env_config["normalisation_on"])
+    else:
+        raise ValueError(env_config["features"])
+    kw = dict(
+        ticker=env_config["ticker"], episode_length=episode_length, features=features, max_inventory=env_config["max_inventory"],
+        min_date=datetime.strptime(env_config["min_date"], "%Y-%m-%d"), max_date=datetime.strptime(env_config["max_date"], "%Y-%m-%d"),
+        step_size=step_size, initial_portfolio=Portfolio(inventory=env_config["initial_inventory"], cash=env_config["initial_cash"]),
+        per_step_reward_function=get_reward_function(env_config["per_step_reward_function"]),
+        terminal_reward_function=get_reward_function(env_config["terminal_reward_function"]),
+        market_order_clearing=env_config["market_order_clearing"], market_order_fraction_of_inventory=env_config["market_order_fraction_of_inventory"],
+        concentration=env_config["concentration"], min_quote_level=env_config["min_quote_level"], max_quote_level=env_config["max_quote_level"],
+        enter_spread=env_config["enter_spread"], info_calculator=env_config.get("info_calculator"), n_levels=env_config["n_levels"],
+    )  # fmt: skip
+    n = num_envs or env_config.get("num_envs", 1)
+    if n > 1:
+        return HistoricalOrderbookVectorEnv(n, catalog, **kw)
+    return HistoricalOrderbookEnvironment(catalog=catalog, **kw)
+
+
+def generate_trajectory(agent, env):
+    """rl4mm/gym/utils.py:100-117."""
+    observations, rewards, actions, infos = [], [], [], []
+    obs = env.reset()
+    observations.append(obs)
+    while True:
+        action = agent.get_action(obs)
+        obs, reward, done, info = env.step(action)
+        observations.append(obs)
+        actions.append(action)
+        rewards.append(reward)
+        infos.append(info)
+        if done:
+            break
+    return {"observations": observations, "actions": actions, "rewards": rewards, "infos": infos}

@@ -127,6 +127,8 @@ def _snapshot_rows(ts_ns: np.ndarray, freq: Optional[str]) -> np.ndarray:
         # is in it, i.e. all rows.
         return np.arange(n)
     ts = pd.DatetimeIndex(ts_ns.astype("datetime64[ns]"))
+    if freq.endswith("S") and not freq.endswith("MS"):  # pandas >= 2.2 spells the reference's "S" as "s"
+        freq = freq[:-1] + "s"
     targets = pd.date_range(ts[0].ceil(freq), ts[-1].ceil(freq), freq=freq).values.astype("datetime64[ns]")
     targets = targets.astype(np.int64)
     # last row of each distinct timestamp

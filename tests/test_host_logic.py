@@ -1,0 +1,124 @@
+"""CPU-only tests of the host side: packer vs the reference's DB ordering (golden), synthetic generator
+determinism, start-time draw, agents, env sharding + the world_size-2 gloo gather."""
+import os
+import socket
+from datetime import datetime, timedelta
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import oracle_lib as ol
+from rl4mm_amd import agents, dist as rdist
+from rl4mm_amd.stream import PackedStream, pack_lobster, unpack_meta
+from rl4mm_amd.synth import generate_lobster, synthetic_stream
+
+
+def test_packer_reproduces_db_order_quirks():
+    """Q1-Q3 on the reference's MSFT slice: floor-to-us timestamps, lexicographic row-index tie-break, hidden
+    executions dropped, executions name the aggressor."""
+    ps = ol.golden_stream("msft")
+    assert ps.n_msgs == 995 and ps.n_snaps == 1000  # 5 hidden executions dropped; one snapshot per row (freq None)
+    t = ps.msgs[:, 0]
+    assert np.all(np.diff(t) >= 0)
+    raw = np.loadtxt(ol.GOLD / "msft_message_50.csv", delimiter=",")
+    # rows 9 and 10..29 share a microsecond in the slice: DB order puts row 9 after row 29 ("10" < ... < "29" < "9")
+    vol, typ, side = unpack_meta(ps.msgs[:, 3])
+    assert set(np.unique(typ)) <= {1, 2, 3, 4}
+    ex = raw[raw[:, 1] == 4]
+    packed_ex = ps.msgs[typ == 4]
+    assert len(ex) == len(packed_ex)
+    # a LOBSTER execution of a resting SELL (-1) is a BUY aggressor (side 0)
+    for row in ex[:20]:
+        m = packed_ex[(packed_ex[:, 1] == int(row[2])) & ((packed_ex[:, 3] & ((1 << 48) - 1)) == int(row[3]))]
+        assert len(m) >= 1 and all(((mm[3] >> 52) & 1) == (0 if row[5] == -1 else 1) for mm in m)
+    # S-frequency snapshots: exactly the reference's 4 rows
+    ps_s = pack_lobster(ol.GOLD / "msft_message_50.csv", ol.GOLD / "msft_orderbook_50.csv.gz", "MSFT", "2012-06-21", 50, "S", 1000, 1000)
+    assert ps_s.n_snaps == 4 and np.array_equal(ps_s.msgs, ps.msgs)
+    assert ps_s.last_snapshot_at(36_000_000_000) == 0 and ps_s.last_snapshot_at(35_999_000_000) == -1
+
+
+def test_synthetic_generator_is_deterministic_and_matches_golden_stream():
+    a = synthetic_stream(20180221, 10, 200.0, 9.5 * 3600 + 1490, 9.5 * 3600 + 1490 + 420)
+    g = ol.golden_stream("synth_small")  # generated when the goldens were made, via CSV files the reference ingested
+    assert np.array_equal(a.msgs, g.msgs) and np.array_equal(a.snaps, g.snaps)
+    raw = generate_lobster(3, 10, 100.0, 34200, 34260)
+    assert np.all(np.diff(raw["time_ns"]) >= 0) and set(np.unique(raw["type"])) <= {1, 2, 3, 4}
+    assert np.all(raw["books"][:, 0] > raw["books"][:, 2])  # ask above bid on every row
+
+
+def test_stream_roundtrip(tmp_path):
+    g = ol.golden_stream("synth_small")
+    g.save(tmp_path / "s.npz")
+    h = PackedStream.load(tmp_path / "s.npz")
+    assert np.array_equal(g.msgs, h.msgs) and h.ticker == g.ticker and h.n_levels == 10
+    assert g.first_msg_after(int(g.msgs[10, 0])) > 10
+
+
+def test_teradactyl_matches_reference_actions():
+    """G4 pins the agent: the actions the reference's Teradactyl took on the observations it saw."""
+    for name, idx, kw in (("msft_teradactyl_ad", 0, dict(max_inventory=100, default_kappa=7.0, max_kappa=9.0)), ("synth_teradactyl_ad_spread", 3, dict(max_inventory=300))):
+        g, z = ol.load_traj(name)
+        agent = agents.Teradactyl(inventory_index=idx, **kw)
+        obs = np.concatenate([z["reset_obs"][:1], z["obs"][:-1]])
+        assert np.allclose(agent.get_action(obs), z["actions"], rtol=1e-13, atol=0)
+        assert np.allclose(agent.get_action(obs[3]), z["actions"][3], rtol=1e-13, atol=0)
+
+
+def test_start_time_draw_follows_reference_rng_calls():
+    from rl4mm_amd.env import HistoricalOrderbookVectorEnv as V
+
+    env = V.__new__(V)
+    env.min_date = env.max_date = datetime(2018, 2, 21)
+    env.min_start_timedelta, env.max_end_timedelta = timedelta(hours=10), timedelta(hours=15, minutes=30)
+    env.episode_length, env.step_size = timedelta(minutes=30), timedelta(seconds=0.1)
+    np.random.seed(7)
+    t = env._get_random_start_time()
+    np.random.seed(7)
+    np.random.choice(np.arange(1))  # trading day draw
+    steps = np.random.randint(low=0, high=int((env.max_end_timedelta - env.episode_length - env.min_start_timedelta) / env.step_size))
+    exp = timedelta(hours=10) + steps * env.step_size
+    exp -= timedelta(microseconds=exp.microseconds)
+    assert t == datetime(2018, 2, 21) + exp and t.microsecond == 0
+
+
+def test_shard_range_partitions():
+    for n, w in ((32768, 8), (4096, 1), (10, 3), (7, 8)):
+        spans = [rdist.shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def _gather_worker(rank, world, port, n_total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = rdist.shard_range(n_total, rank, world)
+    local = torch.arange(lo, hi, dtype=torch.float64) * 0.5  # stand-in for per-env episode returns
+    out = rdist.gather_episode_returns(local)
+    q.put((rank, out.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_episode_return_gather_world_size_2_gloo():
+    """The N>1 path on CPU: two processes, contiguous env shards (unequal sizes), the one collective of the design."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    n_total = 11
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        assert np.array_equal(res[r], np.arange(n_total) * 0.5)
