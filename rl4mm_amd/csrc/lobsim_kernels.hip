@@ -23,6 +23,14 @@ namespace lobk {
 
 #define DI __device__ __forceinline__
 
+// Diagnostic build only (-DLOBSIM_PROFILE, tools/phase_profile.py): s_memtime stamps between the phases of a step,
+// written to a buffer nothing else reads.  The product library is built without it and contains no stamp.
+#ifdef LOBSIM_PROFILE
+#define STAMP(k) do { __builtin_amdgcn_sched_barrier(0); prof_t[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 struct Lds {
     int64_t price[2][LV];
     int64_t vol[2][LV];
@@ -950,8 +958,13 @@ __global__ __launch_bounds__(64) void lob_step_kernel(DevCfg C, DevPtrs P, StepA
     if (A.active && !A.active[env]) return;
     EnvHdr& H = P.hdr[env];
     const int F = C.c.n_features, AD = C.c.action_dim, D = C.obs_dim;
+#ifdef LOBSIM_PROFILE
+    uint64_t prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    STAMP(0);
     Scal S;
     load_env(L, S, P, env, H);
+    STAMP(1);
     FeatState fs = FeatState();
     int64_t* ring = nullptr;
     if (ln < F) { fs = P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln]; ring = P.rings + (size_t)env * C.ring_words + C.ring_off[ln]; }
@@ -969,7 +982,15 @@ __global__ __launch_bounds__(64) void lob_step_kernel(DevCfg C, DevPtrs P, StepA
         const int64_t inv0 = S.inv, cash0 = S.cash;
         const double p0 = price;
         build_agent_ops(L, S, C, act);  // convert_action_to_orders on the pre-step state
+        STAMP(2);
+#ifdef LOBSIM_PROFILE
+        for (int k = 0; k < S.n_ops && !S.status; k++) process_op(L, S, L.ops[k]);
+        STAMP(3);
+        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, false);
+#else
         if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true);
+#endif
+        STAMP(4);
         if (!S.status) {
             StepView v = make_view(L, S, price, now);
             bool ok = true;
@@ -985,6 +1006,7 @@ __global__ __launch_bounds__(64) void lob_step_kernel(DevCfg C, DevPtrs P, StepA
         }
     }
     if (S.status) { done = 1; reward = 0.0; }
+    STAMP(5);
     // outputs
     double val = 0.0;
     if (ln < F) val = fs.current_value;
@@ -1001,6 +1023,14 @@ __global__ __launch_bounds__(64) void lob_step_kernel(DevCfg C, DevPtrs P, StepA
         H.min_buy = R.min_buy; H.max_sell = R.max_sell;
         H.prev_action[0] = act.v0; H.prev_action[1] = act.v1; H.prev_action[2] = act.v2; H.prev_action[3] = act.v3; H.prev_action[4] = act.v4;
     }
+#ifdef LOBSIM_PROFILE
+    STAMP(6);
+    if (ln == 0 && P.prof) {
+        for (int k = 0; k < 6; k++) P.prof[(size_t)env * 8 + k] += prof_t[k + 1] - prof_t[k];
+        P.prof[(size_t)env * 8 + 6] += S.n_ops;
+        P.prof[(size_t)env * 8 + 7] += 1;
+    }
+#endif
 }
 
 // env.reset(): snapshot book at (episode_start - warmup), features reset, warm-up replay without agent orders

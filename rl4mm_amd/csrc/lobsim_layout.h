@@ -122,6 +122,7 @@ struct DevPtrs {
     int64_t* rings;    // [env][ring_words]
     const StreamDev* streams;
     int32_t n_streams;
+    uint64_t* prof;    // [env][8] phase cycle sums; only a -DLOBSIM_PROFILE diagnostic build allocates and writes it
 };
 
 }  // namespace lobk
