@@ -31,18 +31,29 @@ namespace lobk {
 #define STAMP(k) do { } while (0)
 #endif
 
+struct Op8 {  // one agent order waiting to be processed (built from the pre-step state, then replayed)
+    int32_t vol;
+    int32_t code;  // type (bits 0-3) | side << 4 | from_agent << 5 | idx << 8; idx = quote level (limit) or agent index
+};
+
+// 9.4 KB per env -> 16 envs (waves) per CU: all 4096 envs of a launch are resident at once
 struct Lds {
     int64_t price[2][LV];
-    int64_t vol[2][LV];
-    uint16_t slab[2][LV];
-    uint16_t head[2][LV];
-    uint16_t tail[2][LV];
-    uint16_t live[2][LV];
+    uint64_t meta[2][LV];  // slab | head << 16 | tail << 32 | live << 48 : one ds_read_b64 per level access
+    int32_t vol[2][LV];    // total resting volume of the level
     AgentOrd agent[NA];
-    Op ops[OPS_MAX];
+    Op8 ops[OPS_MAX];
     int32_t cur[2][QMAX];
     double pdf[2][QMAX];
 };
+
+DI uint64_t mk_meta(int slab, int head, int tail, int live) {
+    return (uint64_t)(uint32_t)slab | ((uint64_t)(uint32_t)head << 16) | ((uint64_t)(uint32_t)tail << 32) | ((uint64_t)(uint32_t)live << 48);
+}
+DI int m_slab(uint64_t m) { return (int)(m & 0xffff); }
+DI int m_head(uint64_t m) { return (int)((m >> 16) & 0xffff); }
+DI int m_tail(uint64_t m) { return (int)((m >> 32) & 0xffff); }
+DI int m_live(uint64_t m) { return (int)(m >> 48); }
 
 // wave-uniform scalars of the env being advanced (kept in registers)
 template <typename T>
@@ -78,9 +89,10 @@ struct Scal {
     int32_t status;
     int32_t n_ops;
     int64_t inv, cash;
-    int64_t ag_cnt;
-    Pair<int64_t> ag_vol, ext_cnt, ext_vol;
+    int32_t ag_cnt;  // fills of the current step
+    Pair<int32_t> ag_vol, ext_cnt, ext_vol;
     uint32_t agent_seq;
+    int64_t q_buy, q_sell;  // best prices the current op list was built against (_get_best_prices)
     Mask<NSLAB / 64> slab_free;
     Mask<NA / 64> agent_free;
     Mask<NA / 64> agent_pending;  // entries freed during this step: not reused before the step ends
@@ -111,12 +123,17 @@ DI int64_t uni64(int64_t v) {
     return ((int64_t)hi << 32) | (uint32_t)lo;
 }
 
+// Inclusive prefix sum over the 64 lanes with DPP row shifts + row broadcasts (gfx9 cross-lane ALU path, a few
+// cycles per step) instead of six ds_bpermute round trips.  Lanes a shift has no source for add 0.
+template <int CTRL, int ROW_MASK>
+DI int32_t dpp_add(int32_t v) { return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false); }
 DI int32_t wave_incl_scan(int32_t v) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int32_t t = __shfl_up(v, d, 64);
-        if (lane() >= d) v += t;
-    }
+    v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);  // row_shr:8   -> inclusive scan inside each row of 16
+    v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
     return v;
 }
 DI int32_t wave_sum(int32_t v) { return rl32(wave_incl_scan(v), 63); }
@@ -149,20 +166,20 @@ DI bool ladder_insert(Lds& L, Scal& S, int side, int pos, int64_t price) {
     int n = S.n_lv[side], ln = lane();
     if (n >= LV) { S.status |= LOBSIM_ST_LEVEL_OVERFLOW; return false; }
     int slab = S.slab_free.take_first();
-    int64_t p[2], v[2]; uint16_t sl[2], hd[2], tl[2], lv[2]; bool take[2];
+    int64_t p[2]; uint64_t m[2]; int32_t v[2]; bool take[2];
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         int i = ln + 64 * r;
         take[r] = i > pos && i <= n;
-        if (take[r]) { p[r] = L.price[side][i - 1]; v[r] = L.vol[side][i - 1]; sl[r] = L.slab[side][i - 1]; hd[r] = L.head[side][i - 1]; tl[r] = L.tail[side][i - 1]; lv[r] = L.live[side][i - 1]; }
+        if (take[r]) { p[r] = L.price[side][i - 1]; m[r] = L.meta[side][i - 1]; v[r] = L.vol[side][i - 1]; }
     }
     wsync();
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         int i = ln + 64 * r;
-        if (take[r]) { L.price[side][i] = p[r]; L.vol[side][i] = v[r]; L.slab[side][i] = sl[r]; L.head[side][i] = hd[r]; L.tail[side][i] = tl[r]; L.live[side][i] = lv[r]; }
+        if (take[r]) { L.price[side][i] = p[r]; L.meta[side][i] = m[r]; L.vol[side][i] = v[r]; }
     }
-    if (ln == 0) { L.price[side][pos] = price; L.vol[side][pos] = 0; L.slab[side][pos] = (uint16_t)slab; L.head[side][pos] = 0; L.tail[side][pos] = 0; L.live[side][pos] = 0; }
+    if (ln == 0) { L.price[side][pos] = price; L.meta[side][pos] = mk_meta(slab, 0, 0, 0); L.vol[side][pos] = 0; }
     S.n_lv.set(side, n + 1);
     wsync();
     return true;
@@ -170,21 +187,19 @@ DI bool ladder_insert(Lds& L, Scal& S, int side, int pos, int64_t price) {
 
 DI void ladder_remove(Lds& L, Scal& S, int side, int pos) {
     int n = S.n_lv[side], ln = lane();
-    int slab = L.slab[side][pos];
-    slab = uni(slab);
-    S.slab_free.set(slab);
-    int64_t p[2], v[2]; uint16_t sl[2], hd[2], tl[2], lv[2]; bool take[2];
+    S.slab_free.set(m_slab((uint64_t)uni64((int64_t)L.meta[side][pos])));
+    int64_t p[2]; uint64_t m[2]; int32_t v[2]; bool take[2];
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         int i = ln + 64 * r;
         take[r] = i >= pos && i < n - 1;
-        if (take[r]) { p[r] = L.price[side][i + 1]; v[r] = L.vol[side][i + 1]; sl[r] = L.slab[side][i + 1]; hd[r] = L.head[side][i + 1]; tl[r] = L.tail[side][i + 1]; lv[r] = L.live[side][i + 1]; }
+        if (take[r]) { p[r] = L.price[side][i + 1]; m[r] = L.meta[side][i + 1]; v[r] = L.vol[side][i + 1]; }
     }
     wsync();
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         int i = ln + 64 * r;
-        if (take[r]) { L.price[side][i] = p[r]; L.vol[side][i] = v[r]; L.slab[side][i] = sl[r]; L.head[side][i] = hd[r]; L.tail[side][i] = tl[r]; L.live[side][i] = lv[r]; }
+        if (take[r]) { L.price[side][i] = p[r]; L.meta[side][i] = m[r]; L.vol[side][i] = v[r]; }
     }
     S.n_lv.set(side, n - 1);
     wsync();
@@ -201,10 +216,10 @@ DI Slot load_slot(const Slot* sl, int i, int head, int tail) {
 }
 
 // squeeze tombstones out of a slab (FIFO order kept); chunk by chunk, in place: a chunk's survivors always land
-// at or below the chunk's own first slot, so nothing unread is overwritten
-DI void compact_level(Lds& L, Scal& S, int side, int idx) {
+// at or below the chunk's own first slot, so nothing unread is overwritten.  Returns the new meta word.
+DI uint64_t compact_level(Lds& L, Scal& S, int side, int idx, uint64_t m) {
     int ln = lane();
-    int slab = uni(L.slab[side][idx]), head = uni(L.head[side][idx]), tail = uni(L.tail[side][idx]);
+    int slab = m_slab(m), head = m_head(m), tail = m_tail(m);
     Slot* sl = S.slots + (size_t)slab * SLOTS;
     uint64_t below = (1ull << ln) - 1;
     int out = 0;
@@ -216,24 +231,20 @@ DI void compact_level(Lds& L, Scal& S, int side, int idx) {
         out += popc64(b);
         wsync();
     }
-    if (ln == 0) { L.head[side][idx] = 0; L.tail[side][idx] = (uint16_t)out; }
-    wsync();
+    return mk_meta(slab, 0, out, m_live(m));
 }
 
 DI void level_append(Lds& L, Scal& S, int side, int idx, int64_t id, int32_t vol, int32_t kind) {
-    int tail = uni(L.tail[side][idx]), head = uni(L.head[side][idx]), live = uni(L.live[side][idx]);
-    if (tail == SLOTS || tail - head - live >= 64) {  // full, or a whole chunk's worth of tombstones: keep scans short
-        compact_level(L, S, side, idx);
-        tail = uni(L.tail[side][idx]);
-        if (tail == SLOTS) { S.status |= LOBSIM_ST_QUEUE_OVERFLOW; return; }
+    uint64_t m = (uint64_t)uni64((int64_t)L.meta[side][idx]);
+    if (m_tail(m) == SLOTS || m_tail(m) - m_head(m) - m_live(m) >= 64) {  // full, or a chunk's worth of tombstones
+        m = compact_level(L, S, side, idx, m);
+        if (m_tail(m) == SLOTS) { S.status |= LOBSIM_ST_QUEUE_OVERFLOW; return; }
     }
+    int tail = m_tail(m), live = m_live(m);
     if (lane() == 0) {
-        int slab = L.slab[side][idx];
         Slot s; s.id = id; s.vol = vol; s.kind = kind;
-        S.slots[(size_t)slab * SLOTS + tail] = s;
-        if (L.live[side][idx] == 0) L.head[side][idx] = (uint16_t)tail;
-        L.tail[side][idx] = (uint16_t)(tail + 1);
-        L.live[side][idx] += 1;
+        S.slots[(size_t)m_slab(m) * SLOTS + tail] = s;
+        L.meta[side][idx] = mk_meta(m_slab(m), live == 0 ? tail : m_head(m), tail + 1, live + 1);
         L.vol[side][idx] += vol;
     }
     wsync();
@@ -245,12 +256,12 @@ DI int alloc_agent(Scal& S) {
     return a;
 }
 
-// Take `rv` shares off slot `pos` (whose current contents are pv / pk / pid) of level idx: the tail of
+// Take `rv` shares off slot `pos` (whose current contents are pv / pk / pid) of level idx (meta word m): the tail of
 // _reduce_order_with_queue_position + _clear_empty_orders_and_prices (Exchange.py:219-247).
-DI void reduce_slot(Lds& L, Scal& S, int side, int idx, int pos, int32_t rv, int32_t pv, int32_t pk, int64_t pid) {
+DI void reduce_slot(Lds& L, Scal& S, int side, int idx, uint64_t m, int pos, int32_t rv, int32_t pv, int32_t pk, int64_t pid) {
     int ln = lane();
-    int head = uni(L.head[side][idx]), tail = uni(L.tail[side][idx]), slab = uni(L.slab[side][idx]);
-    Slot* sl = S.slots + (size_t)slab * SLOTS;
+    int head = m_head(m), tail = m_tail(m);
+    Slot* sl = S.slots + (size_t)m_slab(m) * SLOTS;
     int32_t nv = pv - rv;
     bool gone = nv == 0;
     if (ln == 0) {
@@ -259,7 +270,7 @@ DI void reduce_slot(Lds& L, Scal& S, int side, int idx, int pos, int32_t rv, int
         if (pk == K_AGENT) L.agent[pid].vol = nv;
     }
     if (gone && pk == K_AGENT) S.agent_pending.set((int)pid);
-    int live = uni(L.live[side][idx]) - (gone ? 1 : 0);
+    int live = m_live(m) - (gone ? 1 : 0);
     if (gone && live == 0) { wsync(); ladder_remove(L, S, side, idx); return; }
     int new_head = head;
     if (gone && pos == head) {  // next live slot after pos
@@ -272,7 +283,7 @@ DI void reduce_slot(Lds& L, Scal& S, int side, int idx, int pos, int32_t rv, int
             if (a) { new_head = c * 64 + ffs64(a); break; }
         }
     }
-    if (ln == 0) { L.vol[side][idx] -= rv; L.live[side][idx] = (uint16_t)live; L.head[side][idx] = (uint16_t)new_head; }
+    if (ln == 0) { L.meta[side][idx] = mk_meta(m_slab(m), new_head, tail, live); L.vol[side][idx] -= rv; }
     wsync();
 }
 
@@ -283,8 +294,9 @@ DI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, int
     int idx = find_level(L, S, side, price);
     if (idx < 0) return;  // warn + KeyError -> continue
     int ln = lane();
-    int head = uni(L.head[side][idx]), tail = uni(L.tail[side][idx]), slab = uni(L.slab[side][idx]);
-    const Slot* sl = S.slots + (size_t)slab * SLOTS;
+    uint64_t m = (uint64_t)uni64((int64_t)L.meta[side][idx]);
+    int head = m_head(m), tail = m_tail(m);
+    const Slot* sl = S.slots + (size_t)m_slab(m) * SLOTS;
     int pos = -1;
     int32_t pv = 0, hk = K_DEAD, hv = 0;
     for (int c = head >> 6; c * 64 < tail; c++) {  // independent 1 KiB loads: one ballot per chunk finds the order
@@ -302,7 +314,7 @@ DI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, int
         pos = head; pv = hv; pk = K_SNAP; pid = -1;
     }
     int32_t rv = vol < 0 ? pv : (vol > pv ? pv : vol);  // CancellationVolumeExceededError -> whole remainder (:144-146)
-    reduce_slot(L, S, side, idx, pos, rv, pv, pk, pid);
+    reduce_slot(L, S, side, idx, m, pos, rv, pv, pk, pid);
 }
 
 // execute_order (Exchange.py:85-120): the aggressor (side, limit price or market) sweeps the opposite side level by
@@ -318,15 +330,17 @@ DI int32_t execute(Lds& L, Scal& S, int side, bool is_agent, bool is_market, int
         }
         int64_t bp = uni64(L.price[opp][0]);
         if (!is_market && !(side == LOBSIM_BUY ? price >= bp : price <= bp)) break;
-        int head = uni(L.head[opp][0]), tail = uni(L.tail[opp][0]), slab = uni(L.slab[opp][0]);
-        Slot* sl = S.slots + (size_t)slab * SLOTS;
-        int32_t carry = 0, exec_ext = 0, exec_agent = 0, deleted_agent_vol = 0, n_ext = 0, n_agent = 0, n_removed = 0;
+        uint64_t m = (uint64_t)uni64((int64_t)L.meta[opp][0]);
+        int head = m_head(m), tail = m_tail(m);
+        Slot* sl = S.slots + (size_t)m_slab(m) * SLOTS;
+        int32_t carry = 0, exec_agent = 0, deleted_agent_vol = 0, n_ext = 0, n_agent = 0, n_removed = 0;
         int first_survivor = tail;
         for (int c = head >> 6; c * 64 < tail; c++) {
             int i = c * 64 + ln;
             Slot s = load_slot(sl, i, head, tail);
             bool live = s.kind != K_DEAD;
-            bool own = is_agent && s.kind == K_AGENT;  // the agent cannot fill its own order: it is deleted (:91-94)
+            bool is_ag = s.kind == K_AGENT;
+            bool own = is_agent && is_ag;  // the agent cannot fill its own order: it is deleted (:91-94)
             int32_t contrib = (live && !own) ? s.vol : 0;
             int32_t incl = wave_incl_scan(contrib);
             int32_t ahead = incl - contrib + carry;
@@ -337,27 +351,29 @@ DI int32_t execute(Lds& L, Scal& S, int side, bool is_agent, bool is_market, int
             if (reached) {
                 Slot w = s; w.vol = nv; if (gone) w.kind = K_DEAD;
                 sl[i] = w;
-                if (s.kind == K_AGENT) L.agent[s.id].vol = nv;
+                if (is_ag) L.agent[s.id].vol = nv;
             }
-            uint64_t gone_agent = __ballot(gone && s.kind == K_AGENT);
-            while (gone_agent) {  // freed agent entries (uniform bookkeeping): ids live in lanes, gather them
-                int b = ffs64(gone_agent);
-                gone_agent &= gone_agent - 1;
-                S.agent_pending.set((int)rl64(s.id, b));
+            uint64_t reached_agent = __ballot(reached && is_ag);
+            if (reached_agent) {  // rare: resting agent orders in the swept range
+                uint64_t gone_agent = __ballot(gone && is_ag);
+                while (gone_agent) {  // freed agent entries (uniform bookkeeping): ids live in lanes, gather them
+                    int b = ffs64(gone_agent);
+                    gone_agent &= gone_agent - 1;
+                    S.agent_pending.set((int)rl64(s.id, b));
+                }
+                n_agent += popc64(__ballot(reached && is_ag && !own));
+                exec_agent += wave_sum((reached && is_ag && !own) ? ex : 0);
+                deleted_agent_vol += wave_sum((reached && own) ? s.vol : 0);
             }
-            bool ext_fill = reached && !own && s.kind != K_AGENT;
-            bool ag_fill = reached && !own && s.kind == K_AGENT;
-            n_ext += popc64(__ballot(ext_fill));
-            n_agent += popc64(__ballot(ag_fill));
+            n_ext += popc64(__ballot(reached && !is_ag));
             n_removed += popc64(__ballot(gone));
-            exec_ext += wave_sum(ext_fill ? ex : 0);
-            exec_agent += wave_sum(ag_fill ? ex : 0);
-            deleted_agent_vol += wave_sum((reached && own) ? s.vol : 0);
             carry += rl32(incl, 63);
             uint64_t surv = __ballot(live && !gone);
             if (surv) { first_survivor = c * 64 + ffs64(surv); break; }  // a survivor means the sweep ended in this chunk
         }
-        int32_t E = exec_ext + exec_agent;
+        // fills are a FIFO prefix of the (non-own) resting volume: everything up to min(rem, volume seen)
+        int32_t E = min(rem, carry);
+        int32_t exec_ext = E - exec_agent;
         rem -= E;
         // fills: resting side = opp (Q10: external fills are counted by the resting order's direction)
         S.ext_cnt.add(opp, n_ext); S.ext_vol.add(opp, exec_ext);
@@ -371,10 +387,10 @@ DI int32_t execute(Lds& L, Scal& S, int side, bool is_agent, bool is_market, int
             if (side == LOBSIM_SELL) { S.inv -= exec_ext; S.cash += (int64_t)exec_ext * bp; }
             else { S.inv += exec_ext; S.cash -= (int64_t)exec_ext * bp; }
         }
-        int live_left = uni(L.live[opp][0]) - n_removed;
+        int live_left = m_live(m) - n_removed;
         wsync();
         if (live_left == 0) { ladder_remove(L, S, opp, 0); continue; }
-        if (ln == 0) { L.vol[opp][0] -= (int64_t)E + deleted_agent_vol; L.live[opp][0] = (uint16_t)live_left; L.head[opp][0] = (uint16_t)first_survivor; }
+        if (ln == 0) { L.meta[opp][0] = mk_meta(m_slab(m), first_survivor, tail, live_left); L.vol[opp][0] -= E + deleted_agent_vol; }
         wsync();
         if (S.status) break;
     }
@@ -419,12 +435,19 @@ DI void process_message(Lds& L, Scal& S, int type, int side, int64_t price, int6
     }
 }
 
-DI void process_op(Lds& L, Scal& S, Op op) {
-    int type = op.code & 0xf, side = (op.code >> 4) & 1, aidx = op.code >> 8;
+// one entry of the agent op list.  Prices are implied: a limit quotes level idx of the best prices the list was
+// built against; a cancellation (and a resync re-add, from_agent) takes the price of the agent entry it names.
+DI void process_op(Lds& L, Scal& S, const DevCfg& C, Op8 op) {
+    int type = op.code & 0xf, side = (op.code >> 4) & 1, from_agent = (op.code >> 5) & 1, idx = op.code >> 8;
     if (!(op.vol > 0)) { S.status |= LOBSIM_ST_ASSERT; return; }
-    if (type == LOBSIM_LIMIT) submit_limit(L, S, side, op.price, op.vol, true, 0);
-    else if (type == LOBSIM_MARKET) execute(L, S, side, true, true, 0, op.vol);
-    else remove_order(L, S, side, op.price, K_AGENT, aidx, op.vol);
+    if (type == LOBSIM_MARKET) { execute(L, S, side, true, true, 0, op.vol); return; }
+    int64_t price;
+    if (type == LOBSIM_LIMIT && !from_agent) {
+        int64_t off = (int64_t)(C.c.min_quote_level + idx) * C.c.tick_size;
+        price = side == LOBSIM_BUY ? S.q_buy - off : S.q_sell + off;
+    } else price = uni64(L.agent[idx].price);
+    if (type == LOBSIM_LIMIT) submit_limit(L, S, side, price, op.vol, true, 0);
+    else remove_order(L, S, side, price, K_AGENT, idx, op.vol);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -452,8 +475,8 @@ struct Act5 {  // the action vector as five scalars (an array indexed at run tim
 };
 DI double act_at(const Act5& a, int i) { return a.at(i); }
 
-DI void push_op(Lds& L, Scal& S, int type, int side, int aidx, int64_t price, int32_t vol) {
-    if (lane() == 0 && S.n_ops < OPS_MAX) { Op o; o.price = price; o.vol = vol; o.code = type | (side << 4) | (aidx << 8); L.ops[S.n_ops] = o; }
+DI void push_op(Lds& L, Scal& S, int type, int side, int idx, int32_t vol) {
+    if (lane() == 0 && S.n_ops < OPS_MAX) { Op8 o; o.vol = vol; o.code = type | (side << 4) | (idx << 8); L.ops[S.n_ops] = o; }
     S.n_ops++;
 }
 
@@ -493,6 +516,7 @@ DI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action) {
         best_buy = (int64_t)(floor(mid / (double)tick) * (double)tick);
         best_sell = (int64_t)(ceil(mid / (double)tick) * (double)tick);
     }
+    S.q_buy = best_buy; S.q_sell = best_sell;
     // ---- current agent volume per quoted level (_get_current_internal_order_volumes, :291-296); each agent entry
     // finds its quote level (or "wide")
     int ek[2];
@@ -503,8 +527,13 @@ DI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action) {
         if (o.vol > 0) {
             int s = o.seq_side >> 31;
             int64_t d = s == LOBSIM_BUY ? best_buy - o.price : o.price - best_sell;
-            int64_t kk = d / tick - c.min_quote_level;
-            ek[r] = (d % tick == 0 && kk >= 0 && kk < Q) ? (int)kk : -1;
+            ek[r] = -1;  // negative, not a tick multiple or beyond the quoted range: "wide"
+            if (d >= 0 && d < (int64_t)(c.min_quote_level + Q) * tick) {  // small: 32-bit divide
+                uint32_t du = (uint32_t)d, tu = (uint32_t)tick;
+                uint32_t qd = du / tu;
+                int kk = (int)qd - c.min_quote_level;
+                if (qd * tu == du && kk >= 0) ek[r] = kk;
+            }
             if (ek[r] >= 0) atomicAdd(&L.cur[s][ek[r]], o.vol);
         }
     }
@@ -518,8 +547,7 @@ DI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action) {
             m &= m - 1;
             int k = j - side * Q;
             int32_t d = rl32(diff, j);
-            int64_t price = side == LOBSIM_BUY ? best_buy - (c.min_quote_level + k) * tick : best_sell + (c.min_quote_level + k) * tick;
-            if (d > 0) { push_op(L, S, LOBSIM_LIMIT, side, 0, price, d); continue; }
+            if (d > 0) { push_op(L, S, LOBSIM_LIMIT, side, k, d); continue; }
             // cancel from the agent's NEWEST order at this price backwards (:240-249)
             int32_t need = -d;
             AgentOrd o0 = L.agent[ln], o1 = L.agent[ln + 64];
@@ -541,8 +569,8 @@ DI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action) {
             int32_t c0 = m0 && need > newer0 ? min(o0.vol, need - newer0) : 0;
             int32_t c1 = m1 && need > newer1 ? min(o1.vol, need - newer1) : 0;
             int base = S.n_ops;
-            if (c0 > 0 && base + rank0 < OPS_MAX) { Op op; op.price = price; op.vol = c0; op.code = LOBSIM_CANCELLATION | (side << 4) | (ln << 8); L.ops[base + rank0] = op; }
-            if (c1 > 0 && base + rank1 < OPS_MAX) { Op op; op.price = price; op.vol = c1; op.code = LOBSIM_CANCELLATION | (side << 4) | ((ln + 64) << 8); L.ops[base + rank1] = op; }
+            if (c0 > 0 && base + rank0 < OPS_MAX) { Op8 op; op.vol = c0; op.code = LOBSIM_CANCELLATION | (side << 4) | (ln << 8); L.ops[base + rank0] = op; }
+            if (c1 > 0 && base + rank1 < OPS_MAX) { Op8 op; op.vol = c1; op.code = LOBSIM_CANCELLATION | (side << 4) | ((ln + 64) << 8); L.ops[base + rank1] = op; }
             S.n_ops += popc64(__ballot(c0 > 0)) + popc64(__ballot(c1 > 0));
         }
         // orders resting at prices no longer quoted are cancelled in full (:250-257)
@@ -551,13 +579,13 @@ DI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action) {
             bool w = ek[r] == -1 && (int)(o.seq_side >> 31) == side;
             uint64_t bw = __ballot(w);
             int at = S.n_ops + popc64(bw & ((1ull << ln) - 1));
-            if (w && at < OPS_MAX) { Op op; op.price = o.price; op.vol = o.vol; op.code = LOBSIM_CANCELLATION | (side << 4) | ((ln + 64 * r) << 8); L.ops[at] = op; }
+            if (w && at < OPS_MAX) { Op8 op; op.vol = o.vol; op.code = LOBSIM_CANCELLATION | (side << 4) | ((ln + 64 * r) << 8); L.ops[at] = op; }
             S.n_ops += popc64(bw);
         }
     }
     if (clearing) {  // _get_inventory_clearing_market_order (:260-266)
         double v = rint((double)abs_inv * c.market_order_fraction_of_inventory);
-        push_op(L, S, LOBSIM_MARKET, S.inv < 0 ? LOBSIM_BUY : LOBSIM_SELL, 0, 0, (int32_t)v);
+        push_op(L, S, LOBSIM_MARKET, S.inv < 0 ? LOBSIM_BUY : LOBSIM_SELL, 0, (int32_t)v);
     }
     if (S.n_ops > OPS_MAX) S.status |= LOBSIM_ST_AGENT_OVERFLOW;
     wsync();
@@ -585,10 +613,10 @@ DI void set_level_to_snapshot(Lds& L, Scal& S, int side, int64_t price, int32_t 
         if (!ladder_insert(L, S, side, idx, price)) return;
     }
     if (lane() == 0) {
-        int slab = L.slab[side][idx];
+        int slab = m_slab(L.meta[side][idx]);
         Slot s; s.id = -1; s.vol = vol; s.kind = K_SNAP;
         S.slots[(size_t)slab * SLOTS] = s;
-        L.head[side][idx] = 0; L.tail[side][idx] = 1; L.live[side][idx] = 1; L.vol[side][idx] = vol;
+        L.meta[side][idx] = mk_meta(slab, 0, 1, 1); L.vol[side][idx] = vol;
     }
     wsync();
 }
@@ -651,7 +679,7 @@ DI void resync_outer_levels(Lds& L, Scal& S, const DevCfg& C, const StreamDev& s
                             hm &= ~(1ull << bl);
                             int32_t ov = rl32(o.vol, bl);
                             int aidx = bl + 64 * r;
-                            if (ln == 0 && n_readd < OPS_MAX) { Op op; op.price = price; op.vol = ov; op.code = LOBSIM_LIMIT | (side << 4); L.ops[n_readd] = op; }
+                            if (ln == 0 && n_readd < OPS_MAX) { Op8 op; op.vol = ov; op.code = LOBSIM_LIMIT | (side << 4) | (1 << 5) | (aidx << 8); L.ops[n_readd] = op; }
                             n_readd++;
                             remove_order(L, S, side, price, K_AGENT, aidx, ov);
                         }
@@ -663,7 +691,7 @@ DI void resync_outer_levels(Lds& L, Scal& S, const DevCfg& C, const StreamDev& s
     }
     if (n_readd > OPS_MAX) S.status |= LOBSIM_ST_AGENT_OVERFLOW;
     wsync();
-    for (int k = 0; k < n_readd && !S.status; k++) process_op(L, S, L.ops[k]);
+    for (int k = 0; k < n_readd && !S.status; k++) process_op(L, S, C, L.ops[k]);
     if (S.status) return;
     int64_t wb, ws;
     if (!price_range(L, S, wb, ws)) { S.status |= LOBSIM_ST_EMPTY_BOOK; return; }
@@ -698,7 +726,7 @@ DI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, i
 // microprice (models.py:80-97)
 DI bool microprice(const Lds& L, const Scal& S, double& out) {
     if (!S.n_lv[0] || !S.n_lv[1]) return false;
-    int64_t bv = uni64(L.vol[0][0]), av = uni64(L.vol[1][0]);
+    int64_t bv = uni(L.vol[0][0]), av = uni(L.vol[1][0]);
     if (bv + av == 0) return false;
     double imb = (double)(bv - av) / (double)(bv + av);
     double ask = (double)uni64(L.price[1][0]), bid = (double)uni64(L.price[0][0]);
@@ -712,6 +740,7 @@ DI bool microprice(const Lds& L, const Scal& S, double& out) {
 struct StepView {  // what Feature._update reads from State
     double price, spread;
     int64_t inventory, now_us;
+    uint32_t now_mod_min;  // (second, microsecond) part of now: now_us mod 60 s
     int64_t ext_cnt[2], ext_vol[2];
     int64_t bv, av;
     bool book_ok;
@@ -812,7 +841,7 @@ DI bool feature_reset(const lobsim_feature& d, FeatState& f, int64_t* ring, cons
 
 DI bool feature_update(const lobsim_feature& d, FeatState& f, int64_t* ring, const StepView& v) {  // update, :80-86
     if (v.now_us < f.first_usage_us) return true;
-    if ((v.now_us % 60000000ll) % d.update_us != 0) return true;  // _now_is_multiple_of_update_freq
+    if (d.update_us <= 0xffffffffll ? (v.now_mod_min % (uint32_t)d.update_us != 0) : ((int64_t)v.now_mod_min % d.update_us != 0)) return true;  // _now_is_multiple_of_update_freq
     if (!feature_raw(d, f, ring, v)) return false;
     f.current_value = clampd(f.current_value, d.min_value, d.max_value);
     return true;
@@ -839,8 +868,7 @@ DI void load_env(Lds& L, Scal& S, const DevPtrs& P, int env, const EnvHdr& H) {
 #pragma unroll
     for (int s = 0; s < 2; s++)
         for (int i = ln; i < S.n_lv[s]; i += 64) {
-            L.price[s][i] = G.price[s][i]; L.vol[s][i] = G.vol[s][i];
-            L.slab[s][i] = G.slab[s][i]; L.head[s][i] = G.head[s][i]; L.tail[s][i] = G.tail[s][i]; L.live[s][i] = G.live[s][i];
+            L.price[s][i] = G.price[s][i]; L.meta[s][i] = G.meta[s][i]; L.vol[s][i] = G.vol[s][i];
         }
     const AgentOrd* A = P.agent + (size_t)env * NA;
     L.agent[ln] = A[ln];
@@ -862,8 +890,7 @@ DI void store_env(const Lds& L, const Scal& S, const DevPtrs& P, int env, EnvHdr
 #pragma unroll
     for (int s = 0; s < 2; s++)
         for (int i = ln; i < S.n_lv[s]; i += 64) {
-            G.price[s][i] = L.price[s][i]; G.vol[s][i] = L.vol[s][i];
-            G.slab[s][i] = L.slab[s][i]; G.head[s][i] = L.head[s][i]; G.tail[s][i] = L.tail[s][i]; G.live[s][i] = L.live[s][i];
+            G.price[s][i] = L.price[s][i]; G.meta[s][i] = L.meta[s][i]; G.vol[s][i] = L.vol[s][i];
         }
     AgentOrd* A = P.agent + (size_t)env * NA;
     A[ln] = L.agent[ln];
@@ -889,10 +916,11 @@ DI void clear_step_fills(Scal& S) {
 DI StepView make_view(const Lds& L, const Scal& S, double price, int64_t now_us) {
     StepView v;
     v.price = price; v.now_us = now_us; v.inventory = S.inv;
+    v.now_mod_min = (uint32_t)(now_us % 60000000ll);
     v.spread = best_sell_d(L, S) - best_buy_d(L, S);
     v.ext_cnt[0] = S.ext_cnt[0]; v.ext_cnt[1] = S.ext_cnt[1]; v.ext_vol[0] = S.ext_vol[0]; v.ext_vol[1] = S.ext_vol[1];
     v.book_ok = S.n_lv[0] && S.n_lv[1];
-    v.bv = v.book_ok ? uni64(L.vol[0][0]) : 0; v.av = v.book_ok ? uni64(L.vol[1][0]) : 0;
+    v.bv = v.book_ok ? uni(L.vol[0][0]) : 0; v.av = v.book_ok ? uni(L.vol[1][0]) : 0;
     if (v.bv + v.av == 0) v.book_ok = false;
     return v;
 }
@@ -902,7 +930,7 @@ DI StepView make_view(const Lds& L, const Scal& S, double price, int64_t now_us)
 DI void advance_one_step(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, int stream_id, int64_t& cursor, int64_t& now_us,
                          Ranges& R, int& n_resyncs, double& price, bool with_ops) {
     if (with_ops)
-        for (int k = 0; k < S.n_ops && !S.status; k++) process_op(L, S, L.ops[k]);
+        for (int k = 0; k < S.n_ops && !S.status; k++) process_op(L, S, C, L.ops[k]);
     int64_t until = now_us + C.c.step_us;
     if (stream_id >= 0 && !S.status) replay_messages(L, S, P.streams[stream_id], cursor, until);
     now_us = until;
@@ -952,7 +980,7 @@ struct ResetArgs {
     double* obs;  // [n][obs_dim] or null
 };
 
-__global__ __launch_bounds__(64) void lob_step_kernel(DevCfg C, DevPtrs P, StepArgs A) {
+__global__ __launch_bounds__(64, 4) void lob_step_kernel(DevCfg C, DevPtrs P, StepArgs A) {
     __shared__ Lds L;
     const int env = blockIdx.x, ln = lane();
     if (A.active && !A.active[env]) return;
@@ -984,7 +1012,7 @@ __global__ __launch_bounds__(64) void lob_step_kernel(DevCfg C, DevPtrs P, StepA
         build_agent_ops(L, S, C, act);  // convert_action_to_orders on the pre-step state
         STAMP(2);
 #ifdef LOBSIM_PROFILE
-        for (int k = 0; k < S.n_ops && !S.status; k++) process_op(L, S, L.ops[k]);
+        for (int k = 0; k < S.n_ops && !S.status; k++) process_op(L, S, C, L.ops[k]);
         STAMP(3);
         if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, false);
 #else
@@ -1035,7 +1063,7 @@ __global__ __launch_bounds__(64) void lob_step_kernel(DevCfg C, DevPtrs P, StepA
 
 // env.reset(): snapshot book at (episode_start - warmup), features reset, warm-up replay without agent orders
 // (HistoricalOrderbookEnvironment.py:147-161)
-__global__ __launch_bounds__(64) void lob_reset_kernel(DevCfg C, DevPtrs P, ResetArgs A) {
+__global__ __launch_bounds__(64, 4) void lob_reset_kernel(DevCfg C, DevPtrs P, ResetArgs A) {
     __shared__ Lds L;
     const int k = blockIdx.x, ln = lane();
     const int env = A.env_ids[k];

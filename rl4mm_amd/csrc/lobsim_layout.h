@@ -5,7 +5,7 @@
 //
 // Per env in HBM (sized for 288 GB: we spend capacity to make every access O(1) and coalesced):
 //   EnvHdr                      scalars (clock, portfolio, resync bookkeeping, fill aggregates, free masks)
-//   Ladder                      per side LV price levels, sorted best-first (SoA: price, volume, slab, head, tail, live)
+//   Ladder                      per side LV price levels, sorted best-first (SoA: price, packed slab/head/tail/live, volume)
 //   Slot slabs[2*LV][SLOTS]     one fixed slab per price level = that level's FIFO queue; slot index = time
 //                               priority; removed orders leave tombstones, squeezed out once a chunk's worth
 //                               (64) has piled up, so a scan touches ceil(live/64)+1 chunks
@@ -27,7 +27,7 @@ constexpr int SLOTS = 512;       // order slots per price level (8 chunks of one
 constexpr int NSLAB = 2 * LV;    // slabs per env
 constexpr int NA = 128;          // live agent orders per env (2 per lane)
 constexpr int QMAX = 32;         // quote levels per side (2 * QMAX <= 64 lanes)
-constexpr int OPS_MAX = 2 * QMAX + 2 * NA + 8;  // agent op list: limits + cancels (+ resync re-adds) + market order
+constexpr int OPS_MAX = 2 * QMAX + NA + 8;  // agent op list: limits + cancels + market order (resync re-adds reuse it)
 
 constexpr int64_t DUMMY_PRICE = 9999999999ll;
 
@@ -47,19 +47,10 @@ struct alignas(16) AgentOrd {
 };
 static_assert(sizeof(AgentOrd) == 16, "");
 
-struct alignas(16) Op {  // one agent order waiting to be processed (built from the pre-step state, then replayed)
-    int64_t price;
-    int32_t vol;
-    int32_t code;  // type (bits 0-3) | side << 4 | agent index << 8
-};
-
 struct Ladder {  // HBM image of the LDS ladder
     int64_t price[2][LV];
-    int64_t vol[2][LV];
-    uint16_t slab[2][LV];
-    uint16_t head[2][LV];
-    uint16_t tail[2][LV];
-    uint16_t live[2][LV];
+    uint64_t meta[2][LV];  // slab | head << 16 | tail << 32 | live << 48
+    int32_t vol[2][LV];    // total resting volume of the level
 };
 
 struct alignas(16) EnvHdr {
