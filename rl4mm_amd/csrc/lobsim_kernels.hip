@@ -397,60 +397,58 @@ DI int32_t execute(Lds& L, Scal& S, int side, bool is_agent, bool is_market, int
     return rem;
 }
 
-// book[direction][price] = deque([LimitOrder(internal_id=-1)]) (Exchange.py:172-178, OrderbookSimulator.py:130)
-DI void set_level_to_snapshot(Lds& L, Scal& S, int side, int64_t price, int32_t vol) {
+// submit_order (Exchange.py:71-83): cross -> execute, remainder rests at the back of its level's queue
+DI void submit_limit(Lds& L, Scal& S, int side, int64_t price, int32_t vol, bool is_agent, int64_t ext_id) {
+    const int opp = side ^ 1;
+    bool cross = false;
+    if (S.n_lv[opp] > 0) { int64_t bp = uni64(L.price[opp][0]); cross = side == LOBSIM_BUY ? price >= bp : price <= bp; }
+    if (cross) {
+        vol = execute(L, S, side, is_agent, false, price, vol);
+        if (S.status || vol <= 0) return;
+    }
     int idx = find_level(L, S, side, price);
     if (idx < 0) {
         idx = insert_pos(L, S, side, price);
         if (!ladder_insert(L, S, side, idx, price)) return;
     }
-    if (lane() == 0) {
-        int slab = m_slab(L.meta[side][idx]);
-        Slot s; s.id = -1; s.vol = vol; s.kind = K_SNAP;
-        S.slots[(size_t)slab * SLOTS] = s;
-        L.meta[side][idx] = mk_meta(slab, 0, 1, 1); L.vol[side][idx] = vol;
+    int64_t id = ext_id;
+    if (is_agent) {
+        int a = alloc_agent(S);
+        if (a < 0) return;
+        if (lane() == 0) { AgentOrd o; o.price = price; o.vol = vol; o.seq_side = (S.agent_seq & 0x7fffffffu) | ((uint32_t)side << 31); L.agent[a] = o; }
+        S.agent_seq++;
+        id = a;
     }
-    wsync();
+    level_append(L, S, side, idx, id, vol, is_agent ? K_AGENT : K_EXT);
 }
 
-constexpr int OP_SETLEVEL = 8;  // resync op: replace a price level by one snapshot order (not a LOBSTER type)
-
-// Exchange.process_order (Exchange.py:58-69) with submit_order (:71-83) folded in.  This is the ONLY call site of
-// execute / remove_order / the resting path in a kernel: agent ops, historical messages and resync ops all funnel
-// through it, so each primitive exists once and the step kernel stays inside the instruction cache.
-// (kind, id) = (K_EXT, external id) for messages, (K_AGENT, agent index) for the agent's own orders.
-DI void process_order(Lds& L, Scal& S, int type, int side, int64_t price, int32_t vol, int32_t kind, int64_t id) {
-    const bool is_agent = kind == K_AGENT;
-    if (type == LOBSIM_LIMIT || type == LOBSIM_MARKET) {
-        const bool is_market = type == LOBSIM_MARKET;
-        const int opp = side ^ 1;
-        bool cross = is_market;
-        if (!cross && S.n_lv[opp] > 0) { int64_t bp = uni64(L.price[opp][0]); cross = side == LOBSIM_BUY ? price >= bp : price <= bp; }
-        if (cross) {
-            vol = execute(L, S, side, is_agent, is_market, price, vol);
-            if (is_market || S.status || vol <= 0) return;
-        }
-        // rest at the back of the level's queue
-        int idx = find_level(L, S, side, price);
-        if (idx < 0) {
-            idx = insert_pos(L, S, side, price);
-            if (!ladder_insert(L, S, side, idx, price)) return;
-        }
-        if (is_agent) {
-            int a = alloc_agent(S);
-            if (a < 0) return;
-            if (lane() == 0) { AgentOrd o; o.price = price; o.vol = vol; o.seq_side = (S.agent_seq & 0x7fffffffu) | ((uint32_t)side << 31); L.agent[a] = o; }
-            S.agent_seq++;
-            id = a;
-        }
-        level_append(L, S, side, idx, id, vol, kind);
-    } else if (type == LOBSIM_CANCELLATION || type == LOBSIM_DELETION) {
-        remove_order(L, S, side, price, kind, id, vol);
-    } else if (type == OP_SETLEVEL) {
-        set_level_to_snapshot(L, S, side, price, vol);
-    } else {
-        S.status |= LOBSIM_ST_BAD_MESSAGE;  // cross_trade / trading_halt (HistoricalOrderGenerator.py:54-56)
+// process_order (Exchange.py:58-69) for one historical message
+DI void process_message(Lds& L, Scal& S, int type, int side, int64_t price, int64_t vol64, int64_t ext_id) {
+    if (!(vol64 > 0)) { S.status |= LOBSIM_ST_ASSERT; return; }  // assert order.volume > 0
+    int32_t vol = vol64 > 0x7fffffffll ? 0x7fffffff : (int32_t)vol64;
+    switch (type) {
+    case LOBSIM_LIMIT: submit_limit(L, S, side, price, vol, false, ext_id); break;
+    case LOBSIM_MARKET: execute(L, S, side, false, true, 0, vol); break;
+    case LOBSIM_CANCELLATION:
+    case LOBSIM_DELETION: remove_order(L, S, side, price, K_EXT, ext_id, vol); break;
+    default: S.status |= LOBSIM_ST_BAD_MESSAGE; break;  // cross_trade / trading_halt (HistoricalOrderGenerator.py:54-56)
     }
+}
+
+// one entry of the agent op list.  Prices are implied: a limit quotes level idx of the best prices the list was
+// built against; a cancellation (and a resync re-add, from_agent) takes the price of the agent entry it names.
+DI void process_op(Lds& L, Scal& S, const DevCfg& C, Op8 op) {
+    op.code = uni(op.code); op.vol = uni(op.vol);  // same value in every lane: keep the dispatch on the scalar unit
+    int type = op.code & 0xf, side = (op.code >> 4) & 1, from_agent = (op.code >> 5) & 1, idx = op.code >> 8;
+    if (!(op.vol > 0)) { S.status |= LOBSIM_ST_ASSERT; return; }
+    if (type == LOBSIM_MARKET) { execute(L, S, side, true, true, 0, op.vol); return; }
+    int64_t price;
+    if (type == LOBSIM_LIMIT && !from_agent) {
+        int64_t off = (int64_t)(C.c.min_quote_level + idx) * C.c.tick_size;
+        price = side == LOBSIM_BUY ? S.q_buy - off : S.q_sell + off;
+    } else price = uni64(L.agent[idx].price);
+    if (type == LOBSIM_LIMIT) submit_limit(L, S, side, price, op.vol, true, 0);
+    else remove_order(L, S, side, price, K_AGENT, idx, op.vol);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -608,6 +606,22 @@ DI void ladder_clear(Lds& L, Scal& S) {
     wsync();
 }
 
+// book[direction][price] = deque([LimitOrder(internal_id=-1)]) (Exchange.py:172-178, OrderbookSimulator.py:130)
+DI void set_level_to_snapshot(Lds& L, Scal& S, int side, int64_t price, int32_t vol) {
+    int idx = find_level(L, S, side, price);
+    if (idx < 0) {
+        idx = insert_pos(L, S, side, price);
+        if (!ladder_insert(L, S, side, idx, price)) return;
+    }
+    if (lane() == 0) {
+        int slab = m_slab(L.meta[side][idx]);
+        Slot s; s.id = -1; s.vol = vol; s.kind = K_SNAP;
+        S.slots[(size_t)slab * SLOTS] = s;
+        L.meta[side][idx] = mk_meta(slab, 0, 1, 1); L.vol[side][idx] = vol;
+    }
+    wsync();
+}
+
 // orderbook_price_range (Exchange.py:158-169): lowest buy price > 0 and highest sell price < 9999999999
 DI bool price_range(const Lds& L, const Scal& S, int64_t& worst_buy, int64_t& worst_sell) {
     int ln = lane();
@@ -628,58 +642,89 @@ struct alignas(16) I64x2 { int64_t x, y; };
 
 struct Ranges { double min_buy, max_sell, init_buy, init_sell; };
 
-// update_outer_levels (OrderbookSimulator.py:105-135) as an op list: for every snapshot level outside
-// [min_buy, max_sell] (buy levels first, snapshot order) the cancellations of the agent's orders resting there (in
-// submission order), then SETLEVEL; after all levels the same agent orders again as limits (they rejoin at the back).
-// Returns the number of ops written to L.ops.
-DI int build_resync_ops(Lds& L, Scal& S, const DevCfg& C, const int64_t* row, const Ranges& R) {
+// update_outer_levels (OrderbookSimulator.py:105-135)
+DI void resync_outer_levels(Lds& L, Scal& S, const DevCfg& C, const StreamDev& st, int64_t now_us, Ranges& R) {
     const int Lv = C.c.n_levels, ln = lane();
-    int n = 0;
-    for (int side = 0; side < 2; side++) {
-        for (int base = 0; base < Lv; base += 64) {
-            int l = base + ln;
-            int64_t p = 0;
-            bool pass = false;
-            if (l < Lv) {
-                p = side == LOBSIM_BUY ? row[4 * l + 2] : row[4 * l];
-                pass = side == LOBSIM_BUY ? (double)p < R.min_buy : (double)p > R.max_sell;  // _initial_prices_filter_function
-            }
-            uint64_t pm = __ballot(pass);
-            while (pm) {
-                int j = ffs64(pm);
-                pm &= pm - 1;
-                int64_t price = rl64(p, j);
-                for (int r = 0; r < 2; r++) {  // agent orders at this price, oldest first
-                    AgentOrd o = L.agent[ln + 64 * r];
-                    bool hit = o.vol > 0 && (int)(o.seq_side >> 31) == side && o.price == price;
-                    uint64_t hm = __ballot(hit);
-                    uint32_t myq = o.seq_side & 0x7fffffffu;
-                    int older = 0;
-                    for (uint64_t t = hm; t; t &= t - 1) older += (uint32_t)rl32((int32_t)myq, ffs64(t)) < myq ? 1 : 0;
-                    if (hit && n + older < OPS_MAX) { Op8 op; op.vol = o.vol; op.code = LOBSIM_CANCELLATION | (side << 4) | ((ln + 64 * r) << 8); L.ops[n + older] = op; }
-                    n += popc64(hm);
+    int64_t sec = now_us / 1000000 - st.first_sec;
+    // (a load through a pointer that was itself loaded from memory is a flat-address-space load, which the compiler
+    // must treat as lane-varying: readfirstlane keeps what follows scalar)
+    int32_t si = sec < 0 ? -1 : (sec >= st.n_secs ? (int32_t)st.n_snaps - 1 : uni(st.sec_to_snap[sec]));
+    int n_readd = 0;  // re-add list lives in L.ops[0..): limit ops to be replayed after all levels were replaced
+    if (si >= 0) {
+        const int64_t* row = st.snaps + (int64_t)si * (2 + 4 * Lv) + 2;
+        for (int side = 0; side < 2 && !S.status; side++) {
+            for (int base = 0; base < Lv && !S.status; base += 64) {
+                int l = base + ln;
+                int64_t p = 0; int64_t v = 0; bool pass = false;
+                if (l < Lv) {
+                    p = side == LOBSIM_BUY ? row[4 * l + 2] : row[4 * l];
+                    v = side == LOBSIM_BUY ? row[4 * l + 3] : row[4 * l + 1];
+                    pass = side == LOBSIM_BUY ? (double)p < R.min_buy : (double)p > R.max_sell;  // _initial_prices_filter_function
                 }
-                if (ln == 0 && n < OPS_MAX) { Op8 op; op.vol = 0; op.code = OP_SETLEVEL | (side << 4) | ((base + j) << 8); L.ops[n] = op; }
-                n++;
+                uint64_t pm = __ballot(pass);
+                while (pm && !S.status) {
+                    int j = ffs64(pm);
+                    pm &= pm - 1;
+                    int64_t price = rl64(p, j);
+                    int32_t vol = (int32_t)rl64(v, j);
+                    // agent orders at this level: cancel them now, re-submit them at the back afterwards (:114-129)
+                    for (int r = 0; r < 2 && !S.status; r++) {
+                        AgentOrd o = L.agent[ln + 64 * r];
+                        bool hit = o.vol > 0 && (int)(o.seq_side >> 31) == side && o.price == price;
+                        uint64_t hm = __ballot(hit);
+                        // process in submission order
+                        while (hm && !S.status) {
+                            uint32_t myq = hit ? (o.seq_side & 0x7fffffffu) : 0xffffffffu;
+                            // lane holding the smallest seq among remaining hits
+                            uint32_t best = 0xffffffffu; int bl = -1;
+                            uint64_t t = hm;
+                            while (t) { int b = ffs64(t); t &= t - 1; uint32_t q = (uint32_t)rl32((int32_t)myq, b); if (q < best) { best = q; bl = b; } }
+                            hm &= ~(1ull << bl);
+                            int32_t ov = rl32(o.vol, bl);
+                            int aidx = bl + 64 * r;
+                            if (ln == 0 && n_readd < OPS_MAX) { Op8 op; op.vol = ov; op.code = LOBSIM_LIMIT | (side << 4) | (1 << 5) | (aidx << 8); L.ops[n_readd] = op; }
+                            n_readd++;
+                            remove_order(L, S, side, price, K_AGENT, aidx, ov);
+                        }
+                    }
+                    if (!S.status) set_level_to_snapshot(L, S, side, price, vol);
+                }
             }
         }
     }
+    if (n_readd > OPS_MAX) S.status |= LOBSIM_ST_AGENT_OVERFLOW;
     wsync();
-    const int n1 = n < OPS_MAX ? n : OPS_MAX;
-    for (int base = 0; base < n1; base += 64) {  // re-adds: one per cancellation, same order
-        int i = base + ln;
-        Op8 op = i < n1 ? L.ops[i] : Op8{0, 0};
-        bool c = i < n1 && (op.code & 0xf) == LOBSIM_CANCELLATION;
-        uint64_t cm = __ballot(c);
-        int at = n + popc64(cm & ((1ull << ln) - 1));
-        if (c && at < OPS_MAX) { Op8 r = op; r.code = LOBSIM_LIMIT | (op.code & 0x10) | (1 << 5) | (op.code & ~0xff); L.ops[at] = r; }
-        n += popc64(cm);
-    }
-    wsync();
-    return n;
+    for (int k = 0; k < n_readd && !S.status; k++) process_op(L, S, C, L.ops[k]);
+    if (S.status) return;
+    int64_t wb, ws;
+    if (!price_range(L, S, wb, ws)) { S.status |= LOBSIM_ST_EMPTY_BOOK; return; }
+    if ((double)wb < R.min_buy) R.min_buy = (double)wb;
+    if ((double)ws > R.max_sell) R.max_sell = (double)ws;
 }
 
-enum StepPhase { PH_OPS = 0, PH_MSG_LOAD = 1, PH_MSG = 2, PH_RESYNC = 3 };
+// the window (now, until] of historical messages, in stream order (OrderbookSimulator.py:70-85)
+DI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, int64_t until_us) {
+    int ln = lane();
+    while (!S.status) {
+        int64_t i = cursor + ln;
+        int64_t t = 0, eid = 0, price = 0, meta = 0;
+        bool in = false;
+        if (i < st.n_msgs) {
+            const I64x2* m = reinterpret_cast<const I64x2*>(st.msgs + i * LOBSIM_MSG_WORDS);
+            I64x2 a = m[0], b = m[1];  // 2 x dwordx4, 32 contiguous bytes per lane
+            t = a.x; eid = a.y; price = b.x; meta = b.y;
+            in = t <= until_us;
+        }
+        uint64_t bm = __ballot(in);
+        int cnt = popc64(bm);  // the stream is time-sorted: the in-window lanes are a prefix
+        for (int j = 0; j < cnt && !S.status; j++) {
+            int64_t mm = rl64(meta, j);
+            process_message(L, S, (int)((mm >> LOBSIM_TYPE_SHIFT) & 0xf), (int)((mm >> LOBSIM_SIDE_SHIFT) & 1), rl64(price, j), mm & LOBSIM_VOL_MASK, rl64(eid, j));
+        }
+        cursor += cnt;
+        if (cnt < 64) break;
+    }
+}
 
 // microprice (models.py:80-97)
 DI bool microprice(const Lds& L, const Scal& S, double& out) {
@@ -883,102 +928,21 @@ DI StepView make_view(const Lds& L, const Scal& S, double price, int64_t now_us)
     return v;
 }
 
-// OrderbookSimulator.forward_step (:70-88) + update_internal_state (HistoricalOrderbookEnvironment.py:199-204) as ONE
-// fetch -> dispatch loop: the agent op list, then the (now, until] window of the stream 64 messages per coalesced load,
-// then the clock and - on whole seconds near the edge of the initial price range - the resync op list.
+// OrderbookSimulator.forward_step (:70-88) + update_internal_state (HistoricalOrderbookEnvironment.py:199-204):
+// agent ops first, then the message window, clock, resync check, new price.
 DI void advance_one_step(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, int stream_id, int64_t& cursor, int64_t& now_us,
-                         Ranges& R, int& n_resyncs, double& price, bool with_ops
-#ifdef LOBSIM_PROFILE
-                         , uint64_t* prof_t
-#endif
-) {
-    const int ln = lane();
-    const int64_t until = now_us + C.c.step_us;
-    const bool has_stream = stream_id >= 0;
-    const StreamDev* st = P.streams + (has_stream ? stream_id : 0);
-    int phase = with_ops ? PH_OPS : PH_MSG_LOAD;
-    int k = 0, n_list = with_ops ? S.n_ops : 0, cnt = 0, j = 0;
-    int64_t m_eid = 0, m_price = 0, m_meta = 0;  // one message per lane
-    const int64_t* snap_row = nullptr;
-    bool resynced = false;
-    while (!S.status) {
-        int type, side, kind;
-        int64_t o_price = 0, id = 0;
-        int32_t vol;
-        if (phase == PH_OPS || phase == PH_RESYNC) {
-            if (k >= n_list) {
-                if (phase == PH_RESYNC) break;
-                STAMP(3);
-                phase = PH_MSG_LOAD;
-                continue;
-            }
-            Op8 op = L.ops[k++];
-            type = op.code & 0xf; side = (op.code >> 4) & 1; kind = K_AGENT;
-            const int from_agent = (op.code >> 5) & 1, idx = op.code >> 8;
-            vol = op.vol; id = idx;
-            if (type == OP_SETLEVEL) {
-                o_price = uni64(side == LOBSIM_BUY ? snap_row[4 * idx + 2] : snap_row[4 * idx]);
-                vol = (int32_t)uni64(side == LOBSIM_BUY ? snap_row[4 * idx + 3] : snap_row[4 * idx + 1]);
-            } else {
-                if (!(vol > 0)) { S.status |= LOBSIM_ST_ASSERT; break; }  // assert order.volume > 0 (Exchange.py:59-60)
-                if (type == LOBSIM_LIMIT && !from_agent) {  // quote level idx of the prices the list was built against
-                    int64_t off = (int64_t)(C.c.min_quote_level + idx) * C.c.tick_size;
-                    o_price = side == LOBSIM_BUY ? S.q_buy - off : S.q_sell + off;
-                } else if (type != LOBSIM_MARKET) o_price = uni64(L.agent[idx].price);
-            }
-        } else if (phase == PH_MSG_LOAD) {
-            cnt = 0; j = 0;
-            if (has_stream) {
-                int64_t i = cursor + ln;
-                bool in = false;
-                if (i < st->n_msgs) {
-                    const I64x2* mp = reinterpret_cast<const I64x2*>(st->msgs + i * LOBSIM_MSG_WORDS);
-                    I64x2 a = mp[0], b = mp[1];  // 2 x dwordx4, 32 contiguous bytes per lane
-                    m_eid = a.y; m_price = b.x; m_meta = b.y;
-                    in = a.x <= until;
-                }
-                cnt = popc64(__ballot(in));  // the stream is time-sorted: the in-window lanes are a prefix
-            }
-            phase = PH_MSG;
-            continue;
-        } else {  // PH_MSG
-            if (j >= cnt) {
-                cursor += cnt;
-                if (cnt == 64) { phase = PH_MSG_LOAD; continue; }
-                // window done: clock, then the resync check (OrderbookSimulator.py:85-87)
-                if (!has_stream || until % 1000000 != 0) break;
-                bool near = best_buy_d(L, S) < R.min_buy + C.outer_prop * R.init_buy || best_sell_d(L, S) > R.max_sell - C.outer_prop * R.init_sell;
-                if (!near) break;
-                n_resyncs++;
-                resynced = true;
-                int64_t sec = until / 1000000 - st->first_sec;
-                int32_t si = sec < 0 ? -1 : (sec >= st->n_secs ? (int32_t)st->n_snaps - 1 : st->sec_to_snap[sec]);
-                if (si < 0) break;  // no snapshot yet: nothing to add
-                snap_row = st->snaps + (int64_t)si * (2 + 4 * C.c.n_levels) + 2;
-                n_list = build_resync_ops(L, S, C, snap_row, R);
-                if (n_list > OPS_MAX) { S.status |= LOBSIM_ST_AGENT_OVERFLOW; break; }
-                k = 0;
-                phase = PH_RESYNC;
-                continue;
-            }
-            int64_t mm = rl64(m_meta, j);
-            type = (int)((mm >> LOBSIM_TYPE_SHIFT) & 0xf); side = (int)((mm >> LOBSIM_SIDE_SHIFT) & 1); kind = K_EXT;
-            int64_t v64 = mm & LOBSIM_VOL_MASK;
-            if (!(v64 > 0)) { S.status |= LOBSIM_ST_ASSERT; break; }
-            vol = v64 > 0x7fffffffll ? 0x7fffffff : (int32_t)v64;
-            o_price = rl64(m_price, j); id = rl64(m_eid, j);
-            j++;
-        }
-        process_order(L, S, type, side, o_price, vol, kind, id);
-    }
+                         Ranges& R, int& n_resyncs, double& price, bool with_ops) {
+    if (with_ops)
+        for (int k = 0; k < S.n_ops && !S.status; k++) process_op(L, S, C, L.ops[k]);
+    int64_t until = now_us + C.c.step_us;
+    if (stream_id >= 0 && !S.status) replay_messages(L, S, P.streams[stream_id], cursor, until);
     now_us = until;
     if (S.status) return;
-    if (resynced) {  // OrderbookSimulator.py:134-135
-        int64_t wb, ws;
-        if (!price_range(L, S, wb, ws)) { S.status |= LOBSIM_ST_EMPTY_BOOK; return; }
-        if ((double)wb < R.min_buy) R.min_buy = (double)wb;
-        if ((double)ws > R.max_sell) R.max_sell = (double)ws;
+    if (stream_id >= 0 && now_us % 1000000 == 0) {
+        bool near = best_buy_d(L, S) < R.min_buy + C.outer_prop * R.init_buy || best_sell_d(L, S) > R.max_sell - C.outer_prop * R.init_sell;
+        if (near) { n_resyncs++; resync_outer_levels(L, S, C, P.streams[stream_id], now_us, R); }
     }
+    if (S.status) return;
     if (!microprice(L, S, price)) S.status |= LOBSIM_ST_EMPTY_BOOK;
 }
 
@@ -1052,12 +1016,14 @@ __global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg 
         build_agent_ops(L, S, C, act);  // convert_action_to_orders on the pre-step state
         STAMP(2);
 #ifdef LOBSIM_PROFILE
-        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true, prof_t);
+        for (int k = 0; k < S.n_ops && !S.status; k++) process_op(L, S, C, L.ops[k]);
+        STAMP(3);
+        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, false);
 #else
         if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true);
 #endif
         STAMP(4);
-        if (ln < F) fs = P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln];  // loaded late: not live across the order loop
+        if (ln < F) fs = P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln];  // loaded late: not live across the order loops
         if (!S.status) {
             StepView v = make_view(L, S, price, now);
             bool ok = true;
@@ -1102,7 +1068,7 @@ __global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg 
 
 // env.reset(): snapshot book at (episode_start - warmup), features reset, warm-up replay without agent orders
 // (HistoricalOrderbookEnvironment.py:147-161)
-__global__ __launch_bounds__(64, 3) void lob_reset_kernel(DevCfg C, DevPtrs P, ResetArgs A) {
+__global__ __launch_bounds__(64, 4) void lob_reset_kernel(DevCfg C, DevPtrs P, ResetArgs A) {
     __shared__ Lds L;
     const int k = blockIdx.x, ln = lane();
     const int env = A.env_ids[k];
@@ -1149,12 +1115,7 @@ __global__ __launch_bounds__(64, 3) void lob_reset_kernel(DevCfg C, DevPtrs P, R
     const int64_t n_warm = C.c.warmup_us / C.c.step_us;
     for (int64_t s = 0; s < n_warm && !S.status; s++) {
         clear_step_fills(S);
-#ifdef LOBSIM_PROFILE
-        uint64_t prof_t[8];
-        advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, false, prof_t);
-#else
         advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, false);
-#endif
         if (S.status) break;
         StepView v = make_view(L, S, price, now);
         bool ok = true;
@@ -1206,34 +1167,34 @@ __global__ __launch_bounds__(64) void lob_process_orders_kernel(DevCfg C, DevPtr
         int64_t price = r[2], vol = r[3], id = r[4];
         bool is_ext = r[5] != 0;
         if (vol != -1 && !(vol > 0)) { S.status |= LOBSIM_ST_ASSERT; break; }
-        int32_t kind = K_EXT;
-        int64_t oid = id;
-        if (!is_ext) {
-            kind = K_AGENT;
-            oid = 0;
-            if (type == LOBSIM_CANCELLATION || type == LOBSIM_DELETION) {
-                // rank -> agent index: the id-th oldest live agent order at (side, price)
-                AgentOrd o0 = L.agent[ln], o1 = L.agent[ln + 64];
-                bool m0 = o0.vol > 0 && (int)(o0.seq_side >> 31) == side && o0.price == price;
-                bool m1 = o1.vol > 0 && (int)(o1.seq_side >> 31) == side && o1.price == price;
-                uint32_t q0 = o0.seq_side & 0x7fffffffu, q1 = o1.seq_side & 0x7fffffffu;
-                uint64_t b0 = __ballot(m0), b1 = __ballot(m1);
-                int older0 = 0, older1 = 0;
-                for (int rr = 0; rr < 2; rr++) {
-                    uint64_t bb = rr ? b1 : b0;
-                    while (bb) {
-                        int t = ffs64(bb);
-                        bb &= bb - 1;
-                        uint32_t tq = (uint32_t)rl32((int32_t)(rr ? q1 : q0), t);
-                        if (tq < q0) older0++;
-                        if (tq < q1) older1++;
-                    }
+        if (is_ext) {
+            if (type == LOBSIM_LIMIT) submit_limit(L, S, side, price, (int32_t)vol, false, id);
+            else if (type == LOBSIM_MARKET) execute(L, S, side, false, true, 0, (int32_t)vol);
+            else remove_order(L, S, side, price, K_EXT, id, (int32_t)vol);
+        } else if (type == LOBSIM_LIMIT) submit_limit(L, S, side, price, (int32_t)vol, true, 0);
+        else if (type == LOBSIM_MARKET) execute(L, S, side, true, true, 0, (int32_t)vol);
+        else {
+            // rank -> agent index: the id-th oldest live agent order at (side, price)
+            AgentOrd o0 = L.agent[ln], o1 = L.agent[ln + 64];
+            bool m0 = o0.vol > 0 && (int)(o0.seq_side >> 31) == side && o0.price == price;
+            bool m1 = o1.vol > 0 && (int)(o1.seq_side >> 31) == side && o1.price == price;
+            uint32_t q0 = o0.seq_side & 0x7fffffffu, q1 = o1.seq_side & 0x7fffffffu;
+            uint64_t b0 = __ballot(m0), b1 = __ballot(m1);
+            int older0 = 0, older1 = 0;
+            for (int rr = 0; rr < 2; rr++) {
+                uint64_t bb = rr ? b1 : b0;
+                while (bb) {
+                    int t = ffs64(bb);
+                    bb &= bb - 1;
+                    uint32_t tq = (uint32_t)rl32((int32_t)(rr ? q1 : q0), t);
+                    if (tq < q0) older0++;
+                    if (tq < q1) older1++;
                 }
-                uint64_t h0 = __ballot(m0 && older0 == id), h1 = __ballot(m1 && older1 == id);
-                oid = h0 ? ffs64(h0) : (h1 ? 64 + ffs64(h1) : NA + 1000);
             }
+            uint64_t h0 = __ballot(m0 && older0 == id), h1 = __ballot(m1 && older1 == id);
+            int aidx = h0 ? ffs64(h0) : (h1 ? 64 + ffs64(h1) : NA + 1000);
+            remove_order(L, S, side, price, K_AGENT, aidx, (int32_t)vol);
         }
-        process_order(L, S, type, side, price, (int32_t)vol, kind, oid);
         // make entries freed by this order reusable, like the reference (no step boundary at this level)
     }
     if (ln == 0 && fills_out) {

@@ -14,12 +14,12 @@ stream = bench.build_stream(60)
 starts = (36_000 + np.random.default_rng(1).integers(0, 60, size=N)) * 1_000_000
 acts = torch.from_numpy(np.random.default_rng(2).uniform(0, 10, size=(K + 20, N, 4))).to(dev)
 res = {}
-variants = [a.split(":", 1) for a in sys.argv[1:]] or [["default", ""]]
+variants = [(a.split(":") + ["", ""])[:3] for a in sys.argv[1:]] or [["default", "", ""]]  # name:flags:source
 sims = {}
-for name, flags in variants:
+for name, flags, src in variants:
     so = ROOT / "gpurun_out" / f"liblobsim_{name}.so"
     so.parent.mkdir(exist_ok=True)
-    subprocess.check_call(["hipcc", *_lib.HIPCC_FLAGS, *flags.split(), "-o", str(so), str(_lib.SOURCES[0])])
+    subprocess.check_call(["hipcc", *_lib.HIPCC_FLAGS, *flags.split(), "-o", str(so), str(ROOT / src) if src else str(_lib.SOURCES[0])])
     cfg = _capi.make_cfg(N, 10, bench.default_features(_capi), step_us=100_000, episode_us=1_800_000_000)
     sim = _capi.Sim(_capi.Binding(so), cfg)
     sim.add_stream(stream); sim.set_portfolio(0, 10**12)
