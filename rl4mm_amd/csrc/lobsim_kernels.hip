@@ -45,6 +45,8 @@ struct Lds {
     Op8 ops[OPS_MAX];
     int32_t cur[2][QMAX];
     double pdf[2][QMAX];
+    uint16_t apos[NA];             // slot index of each live agent order inside its level's slab
+    unsigned long long freed[NA / 64];  // agent entries freed by the lane-parallel cancel pass (OR-ed by lanes)
 };
 
 DI uint64_t mk_meta(int slab, int head, int tail, int live) {
@@ -227,7 +229,11 @@ DI uint64_t compact_level(Lds& L, Scal& S, int side, int idx, uint64_t m) {
         Slot s = load_slot(sl, c * 64 + ln, head, tail);
         uint64_t b = __ballot(s.kind != K_DEAD);
         wsync();  // every lane's load has landed before any lane stores
-        if (s.kind != K_DEAD) sl[out + popc64(b & below)] = s;
+        if (s.kind != K_DEAD) {
+            int np = out + popc64(b & below);
+            sl[np] = s;
+            if (s.kind == K_AGENT) L.apos[s.id] = (uint16_t)np;
+        }
         out += popc64(b);
         wsync();
     }
@@ -244,6 +250,7 @@ DI void level_append(Lds& L, Scal& S, int side, int idx, int64_t id, int32_t vol
     if (lane() == 0) {
         Slot s; s.id = id; s.vol = vol; s.kind = kind;
         S.slots[(size_t)m_slab(m) * SLOTS + tail] = s;
+        if (kind == K_AGENT) L.apos[id] = (uint16_t)tail;
         L.meta[side][idx] = mk_meta(m_slab(m), live == 0 ? tail : m_head(m), tail + 1, live + 1);
         L.vol[side][idx] += vol;
     }
@@ -297,13 +304,16 @@ DI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, int
     uint64_t m = (uint64_t)uni64((int64_t)L.meta[side][idx]);
     int head = m_head(m), tail = m_tail(m);
     const Slot* sl = S.slots + (size_t)m_slab(m) * SLOTS;
-    int pos = -1;
+    int pos = -1, first_live = -1;
     int32_t pv = 0, hk = K_DEAD, hv = 0;
     for (int c = head >> 6; c * 64 < tail; c++) {  // independent 1 KiB loads: one ballot per chunk finds the order
         Slot s = load_slot(sl, c * 64 + ln, head, tail);
         uint64_t b = __ballot(s.kind == kind && s.id == id);
         if (b) { int l = fls64(b); pos = c * 64 + l; pv = rl32(s.vol, l); }
-        if (c == (head >> 6)) { hk = rl32(s.kind, head & 63); hv = rl32(s.vol, head & 63); }
+        if (first_live < 0) {  // the queue's head = first slot that is not a tombstone (heads are advanced lazily)
+            uint64_t lv = __ballot(s.kind != K_DEAD);
+            if (lv) { int l = ffs64(lv); first_live = c * 64 + l; hk = rl32(s.kind, l); hv = rl32(s.vol, l); }
+        }
     }
     int32_t pk = kind;
     int64_t pid = id;
@@ -311,7 +321,7 @@ DI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, int
         // unknown id: if the head is a snapshot order (internal_id == -1) it absorbs the removal (:133-137)
         if (hk != K_SNAP) return;
         if (vol < 0) { S.status |= LOBSIM_ST_ASSERT; return; }
-        pos = head; pv = hv; pk = K_SNAP; pid = -1;
+        pos = first_live; pv = hv; pk = K_SNAP; pid = -1;
     }
     int32_t rv = vol < 0 ? pv : (vol > pv ? pv : vol);  // CancellationVolumeExceededError -> whole remainder (:144-146)
     reduce_slot(L, S, side, idx, m, pos, rv, pv, pk, pid);
@@ -592,6 +602,107 @@ DI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action) {
     wsync();
 }
 
+// per-lane binary search of a price in the sorted ladder of one side; -1 if there is no such level
+DI int lane_find_level(const Lds& L, int side, int n, int64_t price) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        int64_t p = L.price[side][mid];
+        bool better = side == LOBSIM_BUY ? p > price : p < price;
+        if (better) lo = mid + 1; else hi = mid;
+    }
+    return (lo < n && L.price[side][lo] == price) ? lo : -1;
+}
+
+// The agent's op list, one op per lane.  Agent limits and cancellations at distinct (side, price) commute as long as
+// nothing can cross (all buy quotes <= q_buy < q_sell <= all sell quotes, no market order), so instead of replaying
+// the list one op at a time every lane applies its own op: the level is found with a per-lane binary search of the
+// LDS ladder, a new order is appended at its level's tail, a cancellation goes straight to the slot recorded in apos
+// (no queue scan), and level totals shared by several cancellations are updated with LDS atomics.  Anything unusual
+// (level missing, slab full or due for compaction, stale position) is left to the sequential path: the returned
+// mask has one bit per op still to be replayed in list order.  Requires S.n_ops <= 64.
+DI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
+    const int ln = lane(), n = S.n_ops;
+    const uint64_t below = (1ull << ln) - 1;
+    const bool have = ln < n;
+    Op8 op; op.vol = 0; op.code = 0;
+    if (have) op = L.ops[ln];
+    const int type = op.code & 0xf, side = (op.code >> 4) & 1, idx = op.code >> 8;
+    const bool is_limit = have && type == LOBSIM_LIMIT && op.vol > 0, is_cancel = have && type == LOBSIM_CANCELLATION && op.vol > 0;
+    int64_t price = 0;
+    if (is_limit) {
+        int64_t off = (int64_t)(C.c.min_quote_level + idx) * C.c.tick_size;
+        price = side == LOBSIM_BUY ? S.q_buy - off : S.q_sell + off;
+    }
+    if (is_cancel) price = L.agent[idx].price;
+    const int nlv = side ? S.n_lv.b : S.n_lv.a;
+    const int li = (is_limit || is_cancel) ? lane_find_level(L, side, nlv, price) : -1;
+    const uint64_t m = li >= 0 ? L.meta[side][li] : 0;
+    Slot* sl = S.slots + (size_t)m_slab(m) * SLOTS;
+    // ---- new orders: append at the tail of an existing level that has room
+    bool lim_ok = is_limit && li >= 0 && m_tail(m) < SLOTS && m_tail(m) - m_head(m) - m_live(m) < 64;
+    uint64_t lim_mask = __ballot(lim_ok);
+    int R = popc64(lim_mask);
+    if (R > popc64(S.agent_free.w[0]) + popc64(S.agent_free.w[1])) { lim_ok = false; lim_mask = 0; R = 0; }  // sequential path reports the overflow
+    if (lim_ok) {
+        int r = popc64(lim_mask & below);  // my rank among the appenders -> the r-th free agent entry
+        uint64_t w0 = S.agent_free.w[0], w1 = S.agent_free.w[1];
+        int c0 = popc64(w0), aidx;
+        if (r < c0) { for (int t = 0; t < r; t++) w0 &= w0 - 1; aidx = ffs64(w0); }
+        else { r -= c0; for (int t = 0; t < r; t++) w1 &= w1 - 1; aidx = 64 + ffs64(w1); }
+        const int tail = m_tail(m), live = m_live(m);
+        Slot w; w.id = aidx; w.vol = op.vol; w.kind = K_AGENT;
+        sl[tail] = w;
+        L.meta[side][li] = mk_meta(m_slab(m), live == 0 ? tail : m_head(m), tail + 1, live + 1);
+        L.vol[side][li] += op.vol;
+        AgentOrd o; o.price = price; o.vol = op.vol;
+        o.seq_side = ((S.agent_seq + (uint32_t)popc64(lim_mask & below)) & 0x7fffffffu) | ((uint32_t)side << 31);
+        L.agent[aidx] = o;
+        L.apos[aidx] = (uint16_t)tail;
+    }
+    for (int t = 0; t < R; t++) {  // the R lowest free entries are now taken
+        if (S.agent_free.w[0]) S.agent_free.w[0] &= S.agent_free.w[0] - 1; else S.agent_free.w[1] &= S.agent_free.w[1] - 1;
+    }
+    S.agent_seq += (uint32_t)R;
+    // ---- cancellations: straight to the recorded slot
+    bool can_ok = is_cancel && li >= 0;
+    const int pos = can_ok ? L.apos[idx] : 0;
+    can_ok = can_ok && pos >= m_head(m) && pos < m_tail(m);
+    Slot cs = dead_slot();
+    if (can_ok) cs = sl[pos];
+    can_ok = can_ok && cs.kind == K_AGENT && cs.id == idx;
+    bool gone = false;
+    if (can_ok) {
+        const int32_t cv = op.vol > cs.vol ? cs.vol : op.vol, nv = cs.vol - cv;
+        gone = nv == 0;
+        Slot w = cs; w.vol = nv; if (gone) w.kind = K_DEAD;
+        sl[pos] = w;
+        L.agent[idx].vol = nv;
+        atomicAdd(&L.vol[side][li], -cv);
+        if (gone) {
+            atomicAdd(reinterpret_cast<unsigned long long*>(&L.meta[side][li]), (unsigned long long)(-(1ll << 48)));  // live -= 1
+            atomicOr(&L.freed[idx >> 6], 1ull << (idx & 63));
+        }
+    }
+    wsync();
+    S.agent_pending.w[0] |= (uint64_t)uni64((int64_t)L.freed[0]);
+    S.agent_pending.w[1] |= (uint64_t)uni64((int64_t)L.freed[1]);
+    wsync();
+    if (ln == 0) { L.freed[0] = 0; L.freed[1] = 0; }
+    // levels emptied by the cancellations leave the ladder (rare; sequential, looked up again by price)
+    bool emptied = can_ok && gone && m_live(L.meta[side][li]) == 0;
+    uint64_t em = __ballot(emptied);
+    while (em) {
+        int j = ffs64(em);
+        em &= em - 1;
+        int sd = rl32(side, j);
+        int ix = find_level(L, S, sd, rl64(price, j));
+        if (ix >= 0 && m_live((uint64_t)uni64((int64_t)L.meta[sd][ix])) == 0) ladder_remove(L, S, sd, ix);
+    }
+    wsync();
+    return __ballot(have && !(lim_ok || can_ok));
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // simulator: snapshot -> book, outer-level resync, message replay
 // ---------------------------------------------------------------------------------------------------------------
@@ -602,6 +713,9 @@ DI void ladder_clear(Lds& L, Scal& S) {
     S.agent_pending.fill(0);
     L.agent[lane()].vol = 0;
     L.agent[lane() + 64].vol = 0;
+    L.apos[lane()] = 0;
+    L.apos[lane() + 64] = 0;
+    if (lane() < NA / 64) L.freed[lane()] = 0;
     S.agent_seq = 0;
     wsync();
 }
@@ -876,6 +990,10 @@ DI void load_env(Lds& L, Scal& S, const DevPtrs& P, int env, const EnvHdr& H) {
     const AgentOrd* A = P.agent + (size_t)env * NA;
     L.agent[ln] = A[ln];
     L.agent[ln + 64] = A[ln + 64];
+    const uint16_t* AP = P.apos + (size_t)env * NA;
+    L.apos[ln] = AP[ln];
+    L.apos[ln + 64] = AP[ln + 64];
+    if (ln < NA / 64) L.freed[ln] = 0;
     S.status = H.status; S.inv = H.inventory; S.cash = H.cash; S.agent_seq = H.agent_seq; S.n_ops = 0;
 #pragma unroll
     for (int w = 0; w < NSLAB / 64; w++) S.slab_free.w[w] = H.slab_free[w];
@@ -898,6 +1016,9 @@ DI void store_env(const Lds& L, const Scal& S, const DevPtrs& P, int env, EnvHdr
     AgentOrd* A = P.agent + (size_t)env * NA;
     A[ln] = L.agent[ln];
     A[ln + 64] = L.agent[ln + 64];
+    uint16_t* AP = P.apos + (size_t)env * NA;
+    AP[ln] = L.apos[ln];
+    AP[ln + 64] = L.apos[ln + 64];
     if (ln == 0) {
         H.n_lv[0] = S.n_lv[0]; H.n_lv[1] = S.n_lv[1];
         H.status = S.status; H.inventory = S.inv; H.cash = S.cash; H.agent_seq = S.agent_seq;
@@ -932,8 +1053,17 @@ DI StepView make_view(const Lds& L, const Scal& S, double price, int64_t now_us)
 // agent ops first, then the message window, clock, resync check, new price.
 DI void advance_one_step(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, int stream_id, int64_t& cursor, int64_t& now_us,
                          Ranges& R, int& n_resyncs, double& price, bool with_ops) {
-    if (with_ops)
-        for (int k = 0; k < S.n_ops && !S.status; k++) process_op(L, S, C, L.ops[k]);
+    if (with_ops) {
+        uint64_t todo = S.n_ops >= 64 ? ~0ull : (1ull << S.n_ops) - 1;
+        bool has_market = false;
+        if (S.n_ops > 0) has_market = (uni(L.ops[S.n_ops - 1].code) & 0xf) == LOBSIM_MARKET;  // the clearing order is last
+        if (S.n_ops <= 64 && !has_market && S.q_buy < S.q_sell) todo = apply_agent_ops_parallel(L, S, C);
+        if (S.n_ops <= 64) {
+            while (todo && !S.status) { int k = ffs64(todo); todo &= todo - 1; process_op(L, S, C, L.ops[k]); }
+        } else {
+            for (int k = 0; k < S.n_ops && !S.status; k++) process_op(L, S, C, L.ops[k]);
+        }
+    }
     int64_t until = now_us + C.c.step_us;
     if (stream_id >= 0 && !S.status) replay_messages(L, S, P.streams[stream_id], cursor, until);
     now_us = until;

@@ -109,6 +109,7 @@ struct DevPtrs {
     Ladder* ladder;
     Slot* slots;       // [env][NSLAB][SLOTS]
     AgentOrd* agent;   // [env][NA]
+    uint16_t* apos;    // [env][NA] slot index of each live agent order inside its level's slab
     FeatState* feat;   // [env][LOBSIM_MAX_FEATURES]
     int64_t* rings;    // [env][ring_words]
     const StreamDev* streams;
