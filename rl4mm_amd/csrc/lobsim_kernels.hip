@@ -1049,21 +1049,24 @@ DI StepView make_view(const Lds& L, const Scal& S, double price, int64_t now_us)
     return v;
 }
 
+// the agent's orders of this step, before any historical message (OrderbookSimulator.py:76-81)
+DI void run_agent_ops(Lds& L, Scal& S, const DevCfg& C) {
+    uint64_t todo = S.n_ops >= 64 ? ~0ull : (1ull << S.n_ops) - 1;
+    bool has_market = false;
+    if (S.n_ops > 0) has_market = (uni(L.ops[S.n_ops - 1].code) & 0xf) == LOBSIM_MARKET;  // the clearing order is last
+    if (S.n_ops <= 64 && !has_market && S.q_buy < S.q_sell) todo = apply_agent_ops_parallel(L, S, C);
+    if (S.n_ops <= 64) {
+        while (todo && !S.status) { int k = ffs64(todo); todo &= todo - 1; process_op(L, S, C, L.ops[k]); }
+    } else {
+        for (int k = 0; k < S.n_ops && !S.status; k++) process_op(L, S, C, L.ops[k]);
+    }
+}
+
 // OrderbookSimulator.forward_step (:70-88) + update_internal_state (HistoricalOrderbookEnvironment.py:199-204):
 // agent ops first, then the message window, clock, resync check, new price.
 DI void advance_one_step(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, int stream_id, int64_t& cursor, int64_t& now_us,
                          Ranges& R, int& n_resyncs, double& price, bool with_ops) {
-    if (with_ops) {
-        uint64_t todo = S.n_ops >= 64 ? ~0ull : (1ull << S.n_ops) - 1;
-        bool has_market = false;
-        if (S.n_ops > 0) has_market = (uni(L.ops[S.n_ops - 1].code) & 0xf) == LOBSIM_MARKET;  // the clearing order is last
-        if (S.n_ops <= 64 && !has_market && S.q_buy < S.q_sell) todo = apply_agent_ops_parallel(L, S, C);
-        if (S.n_ops <= 64) {
-            while (todo && !S.status) { int k = ffs64(todo); todo &= todo - 1; process_op(L, S, C, L.ops[k]); }
-        } else {
-            for (int k = 0; k < S.n_ops && !S.status; k++) process_op(L, S, C, L.ops[k]);
-        }
-    }
+    if (with_ops) run_agent_ops(L, S, C);
     int64_t until = now_us + C.c.step_us;
     if (stream_id >= 0 && !S.status) replay_messages(L, S, P.streams[stream_id], cursor, until);
     now_us = until;
@@ -1146,7 +1149,7 @@ __global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg 
         build_agent_ops(L, S, C, act);  // convert_action_to_orders on the pre-step state
         STAMP(2);
 #ifdef LOBSIM_PROFILE
-        for (int k = 0; k < S.n_ops && !S.status; k++) process_op(L, S, C, L.ops[k]);
+        if (!S.status) run_agent_ops(L, S, C);
         STAMP(3);
         if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, false);
 #else

@@ -274,3 +274,45 @@ def test_vector_env_runs_and_resets():
                 obs[i] = o
     assert n_done == 64  # every env finished its 50-step episode exactly once
     v.close()
+
+
+def test_full_length_episode_against_oracle():
+    """A whole reference-default episode (30 min = 18000 steps after the 5 min warm-up, default full_state features,
+    random Beta-policy actions): no env may hit a capacity flag, every env must report done exactly at the last step,
+    and a sample of envs must agree with the oracle on inventory / cash (bit-exact) and observations at checkpoints."""
+    import bench
+
+    n, n_check = 512, 6
+    stream = synthetic_stream(31, 10, 200.0, 9.5 * 3600 + 1200, 9.5 * 3600 + 1200 + 2460)  # 09:50:00 .. 10:31:00
+    feats = bench.default_features(_capi)
+    cfg = _capi.make_cfg(n, 10, feats, step_us=100_000, episode_us=1_800_000_000)
+    gpu = _lib.new_sim(cfg)
+    cpu = ol.oracle_sim(_capi.make_cfg(n_check, 10, feats, step_us=100_000, episode_us=1_800_000_000))
+    rng = np.random.Generator(np.random.PCG64(3))
+    starts = (36_000 + rng.integers(0, 50, size=n)) * 1_000_000
+    for sim, st in ((gpu, starts), (cpu, starts[:n_check])):
+        sim.add_stream(stream)
+        sim.set_portfolio(0, 10**12)
+        sim.reset(st, 0)
+    steps = 18000
+    for t in range(steps):
+        act = rng.uniform(0, 10, size=(n, 4))
+        og, rg, dg = gpu.step(act)
+        oc, rc, dc = cpu.step(act[:n_check])
+        assert dg.sum() == (n if t == steps - 1 else 0), f"step {t}: {dg.sum()} envs done"
+        if t % 1500 == 0 or t == steps - 1:
+            ig, cg, pg = gpu.portfolios()
+            ic, cc, pc = cpu.portfolios()
+            assert np.array_equal(ig[:n_check], ic) and np.array_equal(cg[:n_check], cc), f"step {t}"
+            assert np.array_equal(pg[:n_check], pc) and np.allclose(og[:n_check], oc, rtol=RTOL, atol=ATOL), f"step {t}"
+            assert np.array_equal(dg[:n_check], dc)
+    worst = {"levels": 0, "agent": 0}
+    for e in range(0, n, 16):
+        st = gpu.env_state(e)
+        assert st["status"] == 0, (e, st["status"])
+        worst["levels"] = max(worst["levels"], st["n_buy_levels"], st["n_sell_levels"])
+        worst["agent"] = max(worst["agent"], st["n_agent_orders"])
+    assert worst["levels"] < 128 and worst["agent"] < 128
+    for e in range(n_check):
+        assert np.array_equal(gpu.queues(e), cpu.queues(e)), f"env {e}: book contents differ after a full episode"
+    gpu.close()
