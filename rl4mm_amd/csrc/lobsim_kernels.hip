@@ -1370,3 +1370,15 @@ __global__ void lob_set_portfolio_kernel(DevPtrs P, const int32_t* ids, int n, c
 }  // namespace lobk
 
 #include "lobsim_host.inc"
+
+#ifdef LOBSIM_ISA_PROBE
+// compile-only probes: static instruction count of one call of each engine primitive (tools: hipcc -S -DLOBSIM_ISA_PROBE)
+namespace lobk {
+#define PROBE_PROLOGUE __shared__ Lds L; EnvHdr& H = P.hdr[blockIdx.x]; Scal S; load_env(L, S, P, blockIdx.x, H);
+__global__ __launch_bounds__(64, 4) void probe_base(DevCfg C, DevPtrs P, int side, int64_t price, int vol, int64_t id) { PROBE_PROLOGUE; store_env(L, S, P, blockIdx.x, H); }
+__global__ __launch_bounds__(64, 4) void probe_limit(DevCfg C, DevPtrs P, int side, int64_t price, int vol, int64_t id) { PROBE_PROLOGUE; submit_limit(L, S, side, price, vol, false, id); store_env(L, S, P, blockIdx.x, H); }
+__global__ __launch_bounds__(64, 4) void probe_remove(DevCfg C, DevPtrs P, int side, int64_t price, int vol, int64_t id) { PROBE_PROLOGUE; remove_order(L, S, side, price, K_EXT, id, vol); store_env(L, S, P, blockIdx.x, H); }
+__global__ __launch_bounds__(64, 4) void probe_market(DevCfg C, DevPtrs P, int side, int64_t price, int vol, int64_t id) { PROBE_PROLOGUE; execute(L, S, side, false, true, 0, vol); store_env(L, S, P, blockIdx.x, H); }
+__global__ __launch_bounds__(64, 4) void probe_find(DevCfg C, DevPtrs P, int side, int64_t price, int vol, int64_t id) { PROBE_PROLOGUE; S.status = find_level(L, S, side, price); store_env(L, S, P, blockIdx.x, H); }
+}
+#endif
