@@ -29,12 +29,9 @@ obs = torch.zeros((N, sim.obs_dim), dtype=torch.float64, device=dev)
 reward = torch.zeros(N, dtype=torch.float64, device=dev); done = torch.zeros(N, dtype=torch.uint8, device=dev)
 out = np.zeros((N, 8), dtype=np.uint64)
 b.lib.lobsim_prof_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-b.lib.lobsim_prof_msg.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-msg = np.zeros(16, dtype=np.uint64)
-b.lib.lobsim_prof_msg(sim.h, msg.ctypes.data, 1)
+
 for t in range(10): sim.step_device(acts[t].data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr())
 b.lib.lobsim_prof_read(sim.h, out.ctypes.data, 1)
-b.lib.lobsim_prof_msg(sim.h, msg.ctypes.data, 1)
 for t in range(10, K): sim.step_device(acts[t].data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr())
 b.lib.lobsim_prof_read(sim.h, out.ctypes.data, 0)
 steps = out[:, 7].astype(float)
@@ -46,7 +43,3 @@ for k, n in enumerate(names):
     c = out[:, k].astype(float) / steps
     print(f"  {n:26s} {c.mean():9.0f} cycles  {100*c.mean()/tot.mean():5.1f} %")
 
-b.lib.lobsim_prof_msg(sim.h, msg.ctypes.data, 0)
-# note: the per-type sums are updated by lane 0 of every wave without atomics: racy, read them as estimates
-for ty, name in ((1, "limit"), (2, "cancel"), (3, "delete"), (4, "market")):
-    if msg[2 * ty + 1]: print(f"  msg {name:7s} ~{msg[2*ty] / msg[2*ty+1]:8.0f} cycles each, share of messages {msg[2*ty+1] / msg[3::2].sum() if False else msg[2*ty+1] / sum(msg[2*k+1] for k in range(8)):.2f}")
