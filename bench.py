@@ -95,7 +95,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if "RANK" in os.environ and "MASTER_ADDR" in os.environ:  # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
