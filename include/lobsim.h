@@ -179,9 +179,10 @@ int lobsim_reset(lobsim_t* h, const int32_t* env_ids, int32_t n, const int32_t* 
 int lobsim_step(lobsim_t* h, const double* actions, const uint8_t* active, double* obs, double* reward, uint8_t* done);
 
 /* Same with DEVICE pointers, asynchronous on the handle's stream (no host sync).  obs_f32 (device, may be NULL)
- * additionally receives the observation as float32, the dtype of observation_space (:131-135). */
+ * additionally receives the observation as float32, the dtype of observation_space (:131-135); d_return_acc (device,
+ * may be NULL) accumulates reward per env (episode returns for the rollout's gather) in the kernel epilogue. */
 int lobsim_step_device(lobsim_t* h, const double* d_actions, const uint8_t* d_active, double* d_obs, float* d_obs_f32,
-                       double* d_reward, uint8_t* d_done);
+                       double* d_reward, uint8_t* d_done, double* d_return_acc);
 int lobsim_sync(lobsim_t* h);
 
 int lobsim_obs_dim(const lobsim_t* h);

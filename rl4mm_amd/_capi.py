@@ -121,7 +121,7 @@ PROTOTYPES = {
     "set_portfolio": (C.c_int, [C.c_void_p, _P32, C.c_int32, _P64, _P64]),
     "reset": (C.c_int, [C.c_void_p, _P32, C.c_int32, _P32, _P64, _PD]),
     "step": (C.c_int, [C.c_void_p, _PD, _PU8, _PD, _PD, _PU8]),
-    "step_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "step_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sync": (C.c_int, [C.c_void_p]),
     "obs_dim": (C.c_int, [C.c_void_p]),
     "get_env_state": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(EnvState)]),
@@ -274,8 +274,8 @@ class Sim:
         self._check(self.b.fn["step"](self.h, _ptr(actions, _PD), _ptr(act, _PU8), _ptr(obs, _PD), _ptr(reward, _PD), _ptr(done, _PU8)), "step")
         return obs, reward, done
 
-    def step_device(self, d_actions: int, d_active: int, d_obs: int, d_obs_f32: int, d_reward: int, d_done: int):
-        self._check(self.b.fn["step_device"](self.h, d_actions, d_active, d_obs, d_obs_f32, d_reward, d_done), "step_device")
+    def step_device(self, d_actions: int, d_active: int, d_obs: int, d_obs_f32: int, d_reward: int, d_done: int, d_return_acc: int = 0):
+        self._check(self.b.fn["step_device"](self.h, d_actions, d_active, d_obs, d_obs_f32, d_reward, d_done, d_return_acc), "step_device")
 
     def sync(self):
         self._check(self.b.fn["sync"](self.h), "sync")

@@ -1107,6 +1107,7 @@ struct StepArgs {
     float* obs_f32;         // or null
     double* reward;
     uint8_t* done;
+    double* return_acc;     // or null: per-env sum of rewards (episode return), accumulated here
 };
 
 struct ResetArgs {
@@ -1181,7 +1182,7 @@ __global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg 
         if (A.obs) A.obs[(size_t)env * D + ln] = val;
         if (A.obs_f32) A.obs_f32[(size_t)env * D + ln] = (float)val;
     }
-    if (ln == 0) { A.reward[env] = reward; A.done[env] = (uint8_t)done; }
+    if (ln == 0) { A.reward[env] = reward; A.done[env] = (uint8_t)done; if (A.return_acc) A.return_acc[env] += reward; }
     if (ln < F) P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln] = fs;
     store_env(L, S, P, env, H);
     if (ln == 0) {

@@ -31,10 +31,10 @@ t = 0
 for rep in range(3):  # interleaved A/B in one process
     for name, sim in sims.items():
         tt = 20 * rep  # every variant steps the same actions from its own (identical) state
-        for i in range(5): sim.step_device(acts[(tt + i) % K].data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr())
+        for i in range(5): sim.step_device(acts[(tt + i) % K].data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr(), 0)
         sim.sync(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(60): sim.step_device(acts[(tt + 5 + i) % K].data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr())
+        for i in range(60): sim.step_device(acts[(tt + 5 + i) % K].data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr(), 0)
         sim.sync()
         res[name]["runs"].append(1e6 * (time.perf_counter() - t0) / 60)
 for name, r in res.items():

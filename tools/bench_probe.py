@@ -29,7 +29,7 @@ for K in (1, 10, 100, 300):
     sync()
     t0 = time.perf_counter()
     for _ in range(K):
-        sim.step_device(acts[t].data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr()); t += 1
+        sim.step_device(acts[t].data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr(), 0); t += 1
     t1 = time.perf_counter()
     s = sync()
     t2 = time.perf_counter()
@@ -42,7 +42,7 @@ for variant in ("events", "add", "both"):
     t0 = time.perf_counter()
     for i in range(K):
         if variant in ("events", "both"): ev[i][0].record()
-        sim.step_device(acts[t % 600].data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr()); t += 1
+        sim.step_device(acts[t % 600].data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr(), 0); t += 1
         if variant in ("events", "both"): ev[i][1].record()
         if variant in ("add", "both"): returns += reward
     t1 = time.perf_counter(); s = sync(); t2 = time.perf_counter()

@@ -30,9 +30,9 @@ reward = torch.zeros(N, dtype=torch.float64, device=dev); done = torch.zeros(N, 
 out = np.zeros((N, 8), dtype=np.uint64)
 b.lib.lobsim_prof_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 
-for t in range(10): sim.step_device(acts[t].data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr())
+for t in range(10): sim.step_device(acts[t].data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr(), 0)
 b.lib.lobsim_prof_read(sim.h, out.ctypes.data, 1)
-for t in range(10, K): sim.step_device(acts[t].data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr())
+for t in range(10, K): sim.step_device(acts[t].data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr(), 0)
 b.lib.lobsim_prof_read(sim.h, out.ctypes.data, 0)
 steps = out[:, 7].astype(float)
 names = ["load_env", "build_ops", "process_ops", "messages+resync+price", "features+reward", "outputs+store_env"]
