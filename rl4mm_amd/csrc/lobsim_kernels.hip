@@ -550,50 +550,62 @@ DI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action) {
     }
     wsync();
     int32_t diff = quoting ? desired - L.cur[my_side][my_k] : 0;
-    uint64_t todo = __ballot(diff != 0);
-    for (int side = 0; side < 2; side++) {
-        uint64_t m = todo & (((1ull << Q) - 1) << (side * Q));
-        while (m) {
-            int j = ffs64(m);
-            m &= m - 1;
-            int k = j - side * Q;
-            int32_t d = rl32(diff, j);
-            if (d > 0) { push_op(L, S, LOBSIM_LIMIT, side, k, d); continue; }
-            // cancel from the agent's NEWEST order at this price backwards (:240-249)
-            int32_t need = -d;
-            AgentOrd o0 = L.agent[ln], o1 = L.agent[ln + 64];
-            bool m0 = ek[0] == k && (int)(o0.seq_side >> 31) == side, m1 = ek[1] == k && (int)(o1.seq_side >> 31) == side;
-            uint64_t b0 = __ballot(m0), b1 = __ballot(m1);
-            uint32_t q0 = o0.seq_side & 0x7fffffffu, q1 = o1.seq_side & 0x7fffffffu;
-            int32_t newer0 = 0, newer1 = 0, rank0 = 0, rank1 = 0;  // volume / count of matching orders newer than mine
-            for (int r = 0; r < 2; r++) {
-                uint64_t bb = r ? b1 : b0;
-                while (bb) {
-                    int t = ffs64(bb);
-                    bb &= bb - 1;
-                    uint32_t tq = (uint32_t)rl32((int32_t)(r ? q1 : q0), t);
-                    int32_t tv = rl32(r ? o1.vol : o0.vol, t);
-                    if (m0 && tq > q0) { newer0 += tv; rank0++; }
-                    if (m1 && tq > q1) { newer1 += tv; rank1++; }
-                }
+    wsync();
+    if (quoting) L.cur[my_side][my_k] = diff;  // publish: agent entries read their level's diff
+    wsync();
+    // ---- _volume_diff_to_orders (:227-258), all levels at once.  Every agent entry works out its own cancellation:
+    // a level with diff < 0 is cancelled from its NEWEST order backwards (:240-249), an order at a price no longer
+    // quoted is cancelled in full (:250-257).  Within one side the order of ops at different prices is unobservable
+    // (no crossing is possible among them); buy ops stay before sell ops and the clearing order stays last.
+    AgentOrd ao[2] = {L.agent[ln], L.agent[ln + 64]};
+    int32_t need[2], newer[2] = {0, 0}, code[2];
+    bool cand[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int sd = (int)(ao[r].seq_side >> 31);
+        need[r] = ek[r] >= 0 ? -L.cur[sd][ek[r]] : 0;
+        cand[r] = ek[r] >= 0 && need[r] > 0;
+        code[r] = cand[r] ? (sd << 8) | ek[r] : -1 - r;  // (side, level) key; distinct dummies when not a candidate
+    }
+    {
+        const uint32_t q0 = ao[0].seq_side & 0x7fffffffu, q1 = ao[1].seq_side & 0x7fffffffu;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {  // broadcast every candidate once: volume of same-level orders newer than mine
+            uint64_t bb = __ballot(cand[r]);
+            while (bb) {
+                const int t = ffs64(bb);
+                bb &= bb - 1;
+                const int tc = rl32(code[r], t);
+                const uint32_t tq = (uint32_t)rl32((int32_t)(r ? q1 : q0), t);
+                const int32_t tv = rl32(ao[r].vol, t);
+                newer[0] += (tc == code[0] && tq > q0) ? tv : 0;
+                newer[1] += (tc == code[1] && tq > q1) ? tv : 0;
             }
-            int32_t c0 = m0 && need > newer0 ? min(o0.vol, need - newer0) : 0;
-            int32_t c1 = m1 && need > newer1 ? min(o1.vol, need - newer1) : 0;
-            int base = S.n_ops;
-            if (c0 > 0 && base + rank0 < OPS_MAX) { Op8 op; op.vol = c0; op.code = LOBSIM_CANCELLATION | (side << 4) | (ln << 8); L.ops[base + rank0] = op; }
-            if (c1 > 0 && base + rank1 < OPS_MAX) { Op8 op; op.vol = c1; op.code = LOBSIM_CANCELLATION | (side << 4) | ((ln + 64) << 8); L.ops[base + rank1] = op; }
-            S.n_ops += popc64(__ballot(c0 > 0)) + popc64(__ballot(c1 > 0));
-        }
-        // orders resting at prices no longer quoted are cancelled in full (:250-257)
-        for (int r = 0; r < 2; r++) {
-            AgentOrd o = L.agent[ln + 64 * r];
-            bool w = ek[r] == -1 && (int)(o.seq_side >> 31) == side;
-            uint64_t bw = __ballot(w);
-            int at = S.n_ops + popc64(bw & ((1ull << ln) - 1));
-            if (w && at < OPS_MAX) { Op8 op; op.vol = o.vol; op.code = LOBSIM_CANCELLATION | (side << 4) | ((ln + 64 * r) << 8); L.ops[at] = op; }
-            S.n_ops += popc64(bw);
         }
     }
+    int32_t cvol[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        cvol[r] = 0;
+        if (cand[r] && need[r] > newer[r]) cvol[r] = min(ao[r].vol, need[r] - newer[r]);
+        if (ek[r] == -1) cvol[r] = ao[r].vol;  // wide
+    }
+    const uint64_t below = (1ull << ln) - 1;
+    int base = 0;
+    for (int side = 0; side < 2; side++) {
+        const bool lim = quoting && my_side == side && diff > 0;
+        const uint64_t lm = __ballot(lim);
+        if (lim) { const int at = base + popc64(lm & below); if (at < OPS_MAX) { Op8 op; op.vol = diff; op.code = LOBSIM_LIMIT | (side << 4) | (my_k << 8); L.ops[at] = op; } }
+        base += popc64(lm);
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const bool cn = cvol[r] > 0 && (int)(ao[r].seq_side >> 31) == side;
+            const uint64_t cm = __ballot(cn);
+            if (cn) { const int at = base + popc64(cm & below); if (at < OPS_MAX) { Op8 op; op.vol = cvol[r]; op.code = LOBSIM_CANCELLATION | (side << 4) | ((ln + 64 * r) << 8); L.ops[at] = op; } }
+            base += popc64(cm);
+        }
+    }
+    S.n_ops = base;
     if (clearing) {  // _get_inventory_clearing_market_order (:260-266)
         double v = rint((double)abs_inv * c.market_order_fraction_of_inventory);
         push_op(L, S, LOBSIM_MARKET, S.inv < 0 ? LOBSIM_BUY : LOBSIM_SELL, 0, (int32_t)v);
