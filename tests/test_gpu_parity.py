@@ -316,3 +316,42 @@ def test_full_length_episode_against_oracle():
     for e in range(n_check):
         assert np.array_equal(gpu.queues(e), cpu.queues(e)), f"env {e}: book contents differ after a full episode"
     gpu.close()
+
+
+def test_mixed_streams_50_levels_100ms_snapshots_against_oracle():
+    """Towards BASELINE config 5: 50-level books (the synthetic book is shallower, so snapshot rows carry LOBSTER's
+    +-9999999999 dummy levels), two tickers with different message rates in one batch, 100 ms snapshot frequency."""
+    n, steps = 128, 120
+    streams = [
+        synthetic_stream(5, 50, 300.0, 9.5 * 3600 + 1500, 9.5 * 3600 + 1500 + 120, ticker="AAA", book_snapshot_freq="100ms"),
+        synthetic_stream(6, 50, 60.0, 9.5 * 3600 + 1500, 9.5 * 3600 + 1500 + 120, mid_price=1_550_000, ticker="BBB", book_snapshot_freq="100ms"),
+    ]
+    assert (streams[0].snaps[:, 2:] == 9999999999).any(), "expected dummy levels in the 50-level snapshot rows"
+    cfg = _capi.make_cfg(n, 50, _short_features(), step_us=100_000, episode_us=8_000_000, outer_levels=20)
+    gpu, cpu = _lib.new_sim(cfg), ol.oracle_sim(cfg)
+    rng = np.random.Generator(np.random.PCG64(77))
+    sids = rng.integers(0, 2, size=n).astype(np.int32)
+    starts = (35_715 + rng.integers(0, 60, size=n)) * 1_000_000
+    for sim in (gpu, cpu):
+        for s in streams:
+            sim.add_stream(s)
+        sim.set_portfolio(5, 10**9)
+    og, oc = gpu.reset(starts, sids), cpu.reset(starts, sids)
+    assert np.allclose(og, oc, rtol=RTOL, atol=ATOL)
+    for t in range(steps):
+        act = rng.uniform(0, 10, size=(n, 4))
+        og, rg, dg = gpu.step(act)
+        oc, rc, dc = cpu.step(act)
+        ig, cg, pg = gpu.portfolios()
+        ic, cc, pc = cpu.portfolios()
+        assert np.array_equal(ig, ic) and np.array_equal(cg, cc) and np.array_equal(dg, dc), f"step {t}"
+        assert np.array_equal(pg, pc) and np.allclose(og, oc, rtol=RTOL, atol=ATOL) and np.allclose(rg, rc, rtol=0, atol=ATOL), f"step {t}"
+        if dg.any():
+            ids = np.nonzero(dg)[0].astype(np.int32)
+            starts[ids] += 9_000_000
+            assert np.allclose(gpu.reset(starts[ids], sids[ids], ids), cpu.reset(starts[ids], sids[ids], ids), rtol=RTOL, atol=ATOL)
+    for e in (0, 1, 63, 127):
+        assert np.array_equal(gpu.queues(e), cpu.queues(e)), e
+        sg, sc = gpu.env_state(e), cpu.env_state(e)
+        assert sg["n_resyncs"] == sc["n_resyncs"] and sg["status"] == sc["status"] == 0
+    gpu.close()
