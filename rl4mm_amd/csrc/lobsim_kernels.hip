@@ -279,17 +279,9 @@ DI void reduce_slot(Lds& L, Scal& S, int side, int idx, uint64_t m, int pos, int
     if (gone && pk == K_AGENT) S.agent_pending.set((int)pid);
     int live = m_live(m) - (gone ? 1 : 0);
     if (gone && live == 0) { wsync(); ladder_remove(L, S, side, idx); return; }
-    int new_head = head;
-    if (gone && pos == head) {  // next live slot after pos
-        wsync();
-        new_head = tail;
-        for (int c = pos >> 6; c * 64 < tail; c++) {
-            int i = c * 64 + ln;
-            Slot s = load_slot(sl, i, head, tail);
-            uint64_t a = __ballot(s.kind != K_DEAD && i > pos);
-            if (a) { new_head = c * 64 + ffs64(a); break; }
-        }
-    }
+    // heads are advanced lazily: `head` is only a lower bound of the first live slot (every reader skips
+    // tombstones), so removing the head order costs no dependent re-scan of the slab
+    const int new_head = (gone && pos == head) ? head + 1 : head;
     if (ln == 0) { L.meta[side][idx] = mk_meta(m_slab(m), new_head, tail, live); L.vol[side][idx] -= rv; }
     wsync();
 }
@@ -304,21 +296,25 @@ DI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, int
     uint64_t m = (uint64_t)uni64((int64_t)L.meta[side][idx]);
     int head = m_head(m), tail = m_tail(m);
     const Slot* sl = S.slots + (size_t)m_slab(m) * SLOTS;
-    int pos = -1, first_live = -1;
-    int32_t pv = 0, hk = K_DEAD, hv = 0;
+    int pos = -1;
+    int32_t pv = 0;
     for (int c = head >> 6; c * 64 < tail; c++) {  // independent 1 KiB loads: one ballot per chunk finds the order
         Slot s = load_slot(sl, c * 64 + ln, head, tail);
         uint64_t b = __ballot(s.kind == kind && s.id == id);
         if (b) { int l = fls64(b); pos = c * 64 + l; pv = rl32(s.vol, l); }
-        if (first_live < 0) {  // the queue's head = first slot that is not a tombstone (heads are advanced lazily)
-            uint64_t lv = __ballot(s.kind != K_DEAD);
-            if (lv) { int l = ffs64(lv); first_live = c * 64 + l; hk = rl32(s.kind, l); hv = rl32(s.vol, l); }
-        }
     }
     int32_t pk = kind;
     int64_t pid = id;
     if (pos < 0) {
-        // unknown id: if the head is a snapshot order (internal_id == -1) it absorbs the removal (:133-137)
+        // unknown id: if the head - the first slot that is not a tombstone - is a snapshot order (internal_id == -1)
+        // it absorbs the removal (:133-137).  Rare path: look the head up with a second pass.
+        int first_live = -1;
+        int32_t hk = K_DEAD, hv = 0;
+        for (int c = head >> 6; c * 64 < tail && first_live < 0; c++) {
+            Slot s = load_slot(sl, c * 64 + ln, head, tail);
+            uint64_t lv = __ballot(s.kind != K_DEAD);
+            if (lv) { int l = ffs64(lv); first_live = c * 64 + l; hk = rl32(s.kind, l); hv = rl32(s.vol, l); }
+        }
         if (hk != K_SNAP) return;
         if (vol < 0) { S.status |= LOBSIM_ST_ASSERT; return; }
         pos = first_live; pv = hv; pk = K_SNAP; pid = -1;
