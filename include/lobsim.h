@@ -76,7 +76,8 @@ enum lobsim_feature_kind { /* rl4mm/features/Features.py */
     LOBSIM_F_TRADE_VOLUME_IMBALANCE = 8,    /* :410 */
     LOBSIM_F_BOOK_IMBALANCE = 9,            /* :132 */
     LOBSIM_F_PRICE_RANGE = 10,              /* :178 */
-    LOBSIM_F_PRICE = 11                     /* :327 */
+    LOBSIM_F_PRICE = 11,                    /* :327 */
+    LOBSIM_F_AMIHUD_LAMBDA = 12             /* :245; lookback = (lookback_periods + 1) * slowing_factor, iparam = slowing_factor */
 };
 
 typedef struct lobsim_feature {
@@ -85,7 +86,7 @@ typedef struct lobsim_feature {
     int64_t update_us; /* update_frequency in microseconds */
     double min_value, max_value;
     double dparam;  /* EpisodeProportion: update_frequency / episode_length (Features.py:505) */
-    int64_t iparam; /* TimeOfDay: bucket size in us (Features.py:528); n_buckets - 1 is max_value */
+    int64_t iparam; /* TimeOfDay: bucket size in us (Features.py:528); AmihudLambda: slowing_factor */
 } lobsim_feature;
 
 enum lobsim_reward_kind { LOBSIM_R_PNL = 1 /* RewardFunctions.py:97 */, LOBSIM_R_INVENTORY_ADJUSTED = 2 /* :107 */ };

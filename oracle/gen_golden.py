@@ -41,7 +41,7 @@ from rl4mm.agents.baseline_agents import FixedActionAgent, Teradactyl  # noqa: E
 from rl4mm.database.HistoricalDatabase import HistoricalDatabase  # noqa: E402
 from rl4mm.database.populate_database import populate_database  # noqa: E402
 from rl4mm.features.Features import (  # noqa: E402
-    BookImbalance, EpisodeProportion, Inventory, Portfolio, Price, PriceMove, PriceRange, Spread, TimeOfDay,
+    AmihudLambda, BookImbalance, EpisodeProportion, Inventory, Portfolio, Price, PriceMove, PriceRange, Spread, TimeOfDay,
     TradeDirectionImbalance, TradeVolumeImbalance, Volatility,
 )
 from rl4mm.gym.HistoricalOrderbookEnvironment import HistoricalOrderbookEnvironment  # noqa: E402
@@ -282,7 +282,7 @@ def make_db(data_dir, ticker, date, n_levels, freq, max_rows=99999999999, batch_
 
 FEATURE_KINDS = {
     "Spread": 1, "PriceMove": 2, "Volatility": 3, "Inventory": 4, "EpisodeProportion": 5, "TimeOfDay": 6,
-    "TradeDirectionImbalance": 7, "TradeVolumeImbalance": 8, "BookImbalance": 9, "PriceRange": 10, "Price": 11,
+    "TradeDirectionImbalance": 7, "TradeVolumeImbalance": 8, "BookImbalance": 9, "PriceRange": 10, "Price": 11, "AmihudLambda": 12,
 }  # fmt: skip
 
 
@@ -295,6 +295,8 @@ def feature_desc(f):
         d["dparam"] = float(f.step_size)
     if isinstance(f, TimeOfDay):
         d["iparam"] = int(f.bucket_size / timedelta(microseconds=1))
+    if isinstance(f, AmihudLambda):
+        d["iparam"] = int(f.slowing_factor)
     return d
 
 
@@ -521,6 +523,9 @@ def main():
         # market_order_fraction 0.5 rounds a 1-share inventory to a 0-volume market order: the reference asserts
         run_trajectory("synth_moc_crash", db_s, "SYN", sdate, 10, short(), random_agent(9, high=40.0), 1, [35960], 20.0, step_reward="SD", terminal_reward="PnL",
                        moc=True, mofi=0.5, concentration=12.0, initial=(0, 10**12), stream_file="synth_small")  # fmt: skip
+        amihud = lambda: [Spread(), Inventory(), AmihudLambda(), AmihudLambda(name="al2", update_frequency=timedelta(seconds=0.2), lookback_periods=4, slowing_factor=5),  # noqa: E731
+                          TradeVolumeImbalance(update_frequency=timedelta(seconds=0.1), lookback_periods=30)]
+        run_trajectory("synth_amihud", db_s, "SYN", sdate, 10, amihud(), random_agent(21), 1, [35950], 25.0, step_reward="PnL", terminal_reward="SD", stream_file="synth_small")
         run_trajectory("synth_q5_fixed", db_s, "SYN", sdate, 10, short(), fixed_agent([2, 5, 5, 2]), 1, [36010], 20.0, minq=2, maxq=7, stream_file="synth_small")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

@@ -97,6 +97,12 @@ typedef struct {
     int64_t *buys, *sells; /* trade imbalance deques */
     int n_trades;
     int64_t total, diff;
+    /* AmihudLambda (Features.py:245-324) */
+    int64_t* dvols; /* dollar_volumes deque */
+    int n_dvols;
+    double partial_price_sum;
+    int64_t partial_dollar_volume;
+    int steps_until_update;
 } Feature;
 
 typedef struct {
@@ -580,8 +586,9 @@ static void feature_alloc(Feature* f) {
     f->prices = (double*)calloc((size_t)lb + 2, sizeof(double));
     f->buys = (int64_t*)calloc((size_t)lb + 1, 8);
     f->sells = (int64_t*)calloc((size_t)lb + 1, 8);
+    f->dvols = (int64_t*)calloc((size_t)lb + 1, 8);
 }
-static void feature_free(Feature* f) { free(f->prices); free(f->buys); free(f->sells); }
+static void feature_free(Feature* f) { free(f->prices); free(f->buys); free(f->sells); free(f->dvols); }
 
 static void trades_append(Feature* f, int64_t b, int64_t s) { /* deque(maxlen=lookback).append */
     int lb = f->d.lookback;
@@ -674,6 +681,50 @@ static int feature_raw_update(const oracle_t* h, Env* e, Feature* f) {
         f->current_value = f->total != 0 ? (double)f->diff / (double)f->total : 0.5;
         return 1;
     }
+    case LOBSIM_F_AMIHUD_LAMBDA: { /* :285-324 */
+        int slowing = (int)f->d.iparam, tlb = f->d.lookback / slowing - 1; /* true_lookback_periods */
+        if (f->steps_until_update > 0) {
+            f->steps_until_update -= 1;
+            f->partial_price_sum += e->price;
+            for (int i = 0; i < e->fex.n; i++) f->partial_dollar_volume += e->fex.f[i].vol;
+            return 1;
+        }
+        f->steps_until_update = slowing - 1;
+        if (f->n_prices < tlb) { /* _update_prices_and_dollar_volumes; value 0 */
+            f->prices[f->n_prices++] = f->partial_price_sum / slowing;
+            if (f->n_dvols == tlb) { memmove(f->dvols, f->dvols + 1, 8 * (size_t)(tlb - 1)); f->n_dvols--; }
+            f->dvols[f->n_dvols++] = f->partial_dollar_volume;
+            f->current_value = 0.0;
+        } else if (f->n_prices == tlb) {
+            f->prices[f->n_prices++] = f->partial_price_sum / slowing;
+            if (f->n_dvols == tlb) { memmove(f->dvols, f->dvols + 1, 8 * (size_t)(tlb - 1)); f->n_dvols--; }
+            f->dvols[f->n_dvols++] = f->partial_dollar_volume;
+            double p0 = f->prices[0], sum = 0.0; /* python sum() of a float array starting from int 0 */
+            for (int i = 0; i < tlb; i++) {
+                double r = (f->prices[i + 1] - f->prices[i]) / p0;
+                if (f->dvols[i] > 0) sum = sum + fabs(r) / (double)f->dvols[i];
+            }
+            f->current_value = sum / tlb;
+        } else {
+            double oldest = f->prices[0];
+            memmove(f->prices, f->prices + 1, sizeof(double) * (size_t)tlb);
+            double old_ret = (f->prices[0] - oldest) / oldest;
+            int64_t old_dv = f->dvols[0];
+            memmove(f->dvols, f->dvols + 1, 8 * (size_t)(tlb - 1));
+            f->n_dvols--;
+            double new_price = f->partial_price_sum / slowing;
+            double new_ret = (new_price - f->prices[tlb - 1]) / f->prices[tlb - 1];
+            int64_t new_dv = f->partial_dollar_volume;
+            f->prices[tlb] = new_price;
+            f->dvols[f->n_dvols++] = new_dv;
+            double new_ratio = new_dv > 0 ? fabs(new_ret) / (double)new_dv : 0.0;
+            double old_ratio = old_dv > 0 ? fabs(old_ret) / (double)old_dv : 0.0;
+            double sr = f->current_value * tlb + new_ratio - old_ratio;
+            f->current_value = sr / tlb;
+        }
+        f->partial_price_sum = 0; f->partial_dollar_volume = 0; /* _reset_partial_values */
+        return 1;
+    }
     case LOBSIM_F_INVENTORY: /* :489-490 */
         f->current_value = (double)e->inventory;
         return 1;
@@ -693,6 +744,8 @@ static int feature_raw_update(const oracle_t* h, Env* e, Feature* f) {
 
 static void feature_reset(const oracle_t* h, Env* e, Feature* f, int64_t first_usage_us) { /* reset/_reset, :92-96 */
     f->n_prices = 0; f->n_trades = 0; f->total = 0; f->diff = 0;
+    f->n_dvols = 0; f->partial_price_sum = 0; f->partial_dollar_volume = 0;
+    f->steps_until_update = f->d.kind == LOBSIM_F_AMIHUD_LAMBDA ? (int)f->d.iparam - 1 : 0; /* :278-283 */
     f->first_usage_us = first_usage_us;
     if (!feature_raw_update(h, e, f)) e->status |= LOBSIM_ST_EMPTY_BOOK;
     if (f->d.kind == LOBSIM_F_EPISODE_PROPORTION) f->current_value = 0.0; /* :508-509 */

@@ -20,7 +20,7 @@ ST_EMPTY_BOOK, ST_BAD_MESSAGE, ST_LEVEL_OVERFLOW, ST_QUEUE_OVERFLOW = 1, 2, 4, 8
 ST_AGENT_OVERFLOW, ST_STREAM_END, ST_ASSERT, ST_NOT_RESET = 16, 32, 64, 128
 
 F_SPREAD, F_PRICE_MOVE, F_VOLATILITY, F_INVENTORY, F_EPISODE_PROPORTION, F_TIME_OF_DAY = 1, 2, 3, 4, 5, 6
-F_TRADE_DIRECTION_IMBALANCE, F_TRADE_VOLUME_IMBALANCE, F_BOOK_IMBALANCE, F_PRICE_RANGE, F_PRICE = 7, 8, 9, 10, 11
+F_TRADE_DIRECTION_IMBALANCE, F_TRADE_VOLUME_IMBALANCE, F_BOOK_IMBALANCE, F_PRICE_RANGE, F_PRICE, F_AMIHUD_LAMBDA = 7, 8, 9, 10, 11, 12
 R_PNL, R_INVENTORY_ADJUSTED = 1, 2
 
 

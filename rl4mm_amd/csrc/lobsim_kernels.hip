@@ -933,6 +933,49 @@ DI bool feature_raw(const lobsim_feature& d, FeatState& f, int64_t* ring, const 
         }
         return true;
     }
+    case LOBSIM_F_AMIHUD_LAMBDA: {  // Features.py:285-324.  ring: prices [0, tlb+1), dollar volumes [tlb+1, 2*tlb+1)
+        const int slowing = (int)d.iparam, tlb = lb / slowing - 1, cap = tlb + 1;
+        int64_t* dv = ring + cap;
+        // f.diff = steps_until_update, f.acc = partial_price_sum, f.total = partial_dollar_volume, f.count = periods so far
+        if (f.diff > 0) {
+            f.diff -= 1;
+            f.acc += v.price;
+            f.total += v.ext_vol[0] + v.ext_vol[1];
+            return true;
+        }
+        f.diff = slowing - 1;
+        const double new_price = f.acc / slowing;
+        const int64_t new_dv = f.total;
+        const int n = f.count;  // appends so far; the deques hold min(n, cap) prices and min(n, tlb) volumes
+        if (n < tlb) {
+            pr[n] = new_price; dv[n % tlb] = new_dv;
+            f.current_value = 0.0;
+        } else if (n == tlb) {
+            pr[n] = new_price; dv[n % tlb] = new_dv;  // the volume deque (maxlen tlb) just dropped its oldest entry
+            const double p0 = pr[0];
+            double sum = 0.0;
+            for (int i = 0; i < tlb; i++) {
+                const double r = (pr[i + 1] - pr[i]) / p0;
+                const int64_t dvi = dv[(i + 1) % tlb];
+                if (dvi > 0) sum = sum + fabs(r) / (double)dvi;
+            }
+            f.current_value = sum / tlb;
+        } else {
+            const int po = n % cap;  // oldest price (the slot the new one overwrites)
+            const double oldest = pr[po], next_oldest = pr[(po + 1) % cap], newest = pr[(po + cap - 1) % cap];
+            const double old_ret = (next_oldest - oldest) / oldest;
+            const int64_t old_dv = dv[n % tlb];
+            const double new_ret = (new_price - newest) / newest;
+            pr[po] = new_price; dv[n % tlb] = new_dv;
+            const double new_ratio = new_dv > 0 ? fabs(new_ret) / (double)new_dv : 0.0;
+            const double old_ratio = old_dv > 0 ? fabs(old_ret) / (double)old_dv : 0.0;
+            const double sr = f.current_value * tlb + new_ratio - old_ratio;
+            f.current_value = sr / tlb;
+        }
+        f.count = n + 1;
+        f.acc = 0.0; f.total = 0;  // _reset_partial_values
+        return true;
+    }
     case LOBSIM_F_TRADE_DIRECTION_IMBALANCE:
     case LOBSIM_F_TRADE_VOLUME_IMBALANCE: {  // Features.py:376-403 / 435-462 as running sums over a ring
         bool dirn = d.kind == LOBSIM_F_TRADE_DIRECTION_IMBALANCE;
@@ -959,6 +1002,7 @@ DI bool feature_raw(const lobsim_feature& d, FeatState& f, int64_t* ring, const 
 DI bool feature_reset(const lobsim_feature& d, FeatState& f, int64_t* ring, const StepView& v, int64_t first_usage) {  // _reset, :92-96
     f.count = 0; f.pos = 0; f.total = 0; f.diff = 0; f.acc = 0.0; f.p_first = 0.0; f.p_last = 0.0;
     f.first_usage_us = first_usage;
+    if (d.kind == LOBSIM_F_AMIHUD_LAMBDA) f.diff = d.iparam - 1;  // steps_until_update (Features.py:278-283)
     bool ok = feature_raw(d, f, ring, v);
     if (d.kind == LOBSIM_F_EPISODE_PROPORTION) f.current_value = 0.0;
     return ok;

@@ -129,6 +129,19 @@ class Price(Feature):  # :327
         super().__init__(name, min_value, max_value, update_frequency, 0, normalisation_on, max_norm_len)
 
 
+class AmihudLambda(Feature):  # :245
+    kind = _capi.F_AMIHUD_LAMBDA
+
+    def __init__(self, name="AmihudLambda", min_value=0, max_value=1.0, update_frequency=timedelta(seconds=0.1), lookback_periods=10, slowing_factor=10, normalisation_on=False, max_norm_len=100_000):
+        super().__init__(name, min_value, max_value, update_frequency, (lookback_periods + 1) * slowing_factor, normalisation_on, max_norm_len)
+        self.true_lookback_periods, self.slowing_factor = lookback_periods, slowing_factor
+
+    def desc(self):
+        d = super().desc()
+        d.iparam = int(self.slowing_factor)
+        return d
+
+
 class TradeDirectionImbalance(Feature):  # :351
     kind = _capi.F_TRADE_DIRECTION_IMBALANCE
 

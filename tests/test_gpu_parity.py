@@ -16,7 +16,7 @@ from traj_util import replay_and_check, run_engine_case
 pytestmark = pytest.mark.gpu
 
 RTOL, ATOL = 1e-12, 1e-9
-TRAJ = ["msft_fixed", "msft_teradactyl_ad", "msft_random_allfeat", "synth_default_random", "synth_teradactyl_ad_spread",
+TRAJ = ["msft_fixed", "msft_teradactyl_ad", "msft_random_allfeat", "synth_default_random", "synth_teradactyl_ad_spread", "synth_amihud",
         "synth_moc_conc", "synth_moc_crash", "synth_q5_fixed"]  # fmt: skip
 
 
