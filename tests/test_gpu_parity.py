@@ -355,3 +355,49 @@ def test_mixed_streams_50_levels_100ms_snapshots_against_oracle():
         sg, sc = gpu.env_state(e), cpu.env_state(e)
         assert sg["n_resyncs"] == sc["n_resyncs"] and sg["status"] == sc["status"] == 0
     gpu.close()
+
+
+def test_argument_validation_and_status_flags():
+    """Error behaviour at the boundary: bad arguments are refused with an error string; stepping an env that was never
+    reset reports done with the NOT_RESET bit; a queue that outgrows its slab flags QUEUE_OVERFLOW instead of
+    corrupting the book (the reference has no such limit: the flag is how the difference shows)."""
+    cfg = _small_cfg(2, 8)
+    sim = _lib.new_sim(cfg)
+    with pytest.raises(_capi.LobsimError):
+        sim.reset(np.array([36_000_000_500, 36_000_000_000]), 0)  # not on the second / unknown stream
+    sim.add_stream(ol.golden_stream("synth_small").__class__("SYN", "2018-02-21", 8, np.zeros((0, 4), np.int64), np.zeros((0, 34), np.int64)))
+    with pytest.raises(_capi.LobsimError):
+        sim.reset(np.array([36_000_000_500, 36_000_000_000]), 0)  # "Episodes must be started on the second"
+    with pytest.raises(_capi.LobsimError):
+        sim.reset(np.array([36_000_000_000, 36_000_000_000]), 0, env_ids=np.array([0, 0], dtype=np.int32))  # repeated env id
+    obs, rew, done = sim.step(np.ones((2, 4)))
+    assert done.all() and sim.env_state(0)["status"] & _capi.ST_NOT_RESET
+    # empty stream: reset finds no snapshot -> STREAM_END, done
+    sim.reset(np.array([36_000_000_000, 36_000_000_000]), 0)
+    assert sim.env_state(0)["status"] & _capi.ST_STREAM_END
+    # more live orders at one price than a slab holds
+    sim.debug_set_book(0, None, 0)
+    orders = np.array([[1, 0, 300000, 1, 10_000 + i, 1] for i in range(600)], dtype=np.int64)
+    sim.debug_process_orders(0, orders)
+    assert sim.env_state(0)["status"] & _capi.ST_QUEUE_OVERFLOW
+    # more price levels on a side than the ladder holds
+    sim.debug_set_book(1, None, 0)
+    orders = np.array([[1, 0, 300000 - 100 * i, 1, 20_000 + i, 1] for i in range(140)], dtype=np.int64)
+    sim.debug_process_orders(1, orders)
+    assert sim.env_state(1)["status"] & _capi.ST_LEVEL_OVERFLOW
+    # tombstones are squeezed out: 5000 submit/delete pairs at one price never overflow
+    sim.debug_set_book(0, None, 0)
+    keep = np.array([[1, 0, 300000, 7, 1, 1]], dtype=np.int64)
+    sim.debug_process_orders(0, keep)
+    for base in range(0, 5000, 500):
+        pairs = []
+        for i in range(base, base + 500):
+            pairs += [[1, 0, 300000, 3, 100 + i, 1], [3, 0, 300000, 3, 100 + i, 1]]
+        sim.debug_process_orders(0, np.array(pairs, dtype=np.int64))
+    st = sim.env_state(0)
+    assert st["status"] == 0
+    q = sim.queues(0)
+    assert q.shape[0] == 1 and q[0].tolist() == [0, 300000, 0, 1, 7]
+    with pytest.raises(_capi.LobsimError):
+        _lib.new_sim(_capi.make_cfg(4, 10, [_capi.make_feature(_capi.F_INVENTORY)], max_quote_level=40))  # > 32 quote levels
+    sim.close()
