@@ -155,6 +155,17 @@ def main():
     kernel_ms_sampled = float(np.mean([a.elapsed_time(b) for a, b in ev.values()]))  # event pair around single launches
     kernel_ms = ev_all[0].elapsed_time(ev_all[1]) / K  # average launch duration over the timed region (back-to-back launches)
 
+    # extra (not `value`): the same K steps as ONE launch with the pre-drawn actions (lobsim_rollout_device) - the
+    # mode the reference's rule-based baseline sweeps can use; no per-step launch tail, state stays on chip
+    roll_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    steps_taken = torch.zeros(N, dtype=torch.int32, device=dev)
+    roll_ev[0].record()
+    sim.rollout_device(_capi.POLICY_GIVEN, [], K, acts[W:].data_ptr(), 0, obs.data_ptr(), obs32.data_ptr(), reward.data_ptr(), done.data_ptr(), 0, steps_taken.data_ptr())
+    roll_ev[1].record()
+    torch.cuda.synchronize()
+    rollout_ms = roll_ev[0].elapsed_time(roll_ev[1])
+    rollout_steps = int(steps_taken.sum().item())
+
     # the only collective: gather per-env episode returns (RCCL over xGMI; 32 KiB per GPU)
     if dist:
         el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -192,6 +203,10 @@ def main():
                 "traffic": None, "kernel": "lob_step_kernel", "kernel_ms": kernel_ms, "kernel_ms_sampled_pairs": kernel_ms_sampled, "algorithmic_bytes_per_env_step": round(b_step, 1),
             },
         }  # fmt: skip
+        out["open_loop_rollout"] = {
+            "value": rollout_steps / (rollout_ms * 1e-3), "unit": "env-steps/s (rank 0)", "steps_per_launch": K, "launch_ms": rollout_ms,
+            "note": "lob_rollout_kernel: K steps per env in one launch with pre-drawn actions; reported beside, never as, `value`",
+        }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(_capi, stream, 256, 1000)
         print(json.dumps(out))

@@ -186,6 +186,22 @@ int lobsim_step_device(lobsim_t* h, const double* d_actions, const uint8_t* d_ac
                        double* d_reward, uint8_t* d_done, double* d_return_acc);
 int lobsim_sync(lobsim_t* h);
 
+/* Open-loop / rule-based rollouts: up to T consecutive env.step()s per env in ONE launch, the action of every step
+ * produced on the device (the reference's rule-based baselines, rl4mm/agents/baseline_agents.py, and its
+ * generate_trajectory loop, rl4mm/gym/utils.py:100-117).  An env stops early when it reports done.
+ *   policy LOBSIM_POLICY_GIVEN      d_actions [T][n_envs][action_dim] f64 (e.g. pre-drawn RandomAgent actions)
+ *   policy LOBSIM_POLICY_FIXED      FixedActionAgent: params[0 .. action_dim) is the action
+ *   policy LOBSIM_POLICY_TERADACTYL Teradactyl.get_action (baseline_agents.py:58-87) on the observation entry
+ *                                   params = {max_inventory, default_kappa, default_omega, max_kappa, exponent,
+ *                                             inventory_index, market_clearing (0/1), denom (max_inventory or 100)}
+ * Outputs (device pointers, any of d_obs / d_obs_f32 / d_return_acc / d_steps_taken may be NULL): observation, reward
+ * and done flag of the LAST step each env took, the sum of its rewards added to d_return_acc, the number of steps it
+ * took.  Asynchronous on the handle's stream. */
+enum lobsim_policy { LOBSIM_POLICY_GIVEN = 0, LOBSIM_POLICY_FIXED = 1, LOBSIM_POLICY_TERADACTYL = 2 };
+int lobsim_rollout_device(lobsim_t* h, int32_t policy, const double* params8, int32_t T, const double* d_actions,
+                          const uint8_t* d_active, double* d_obs, float* d_obs_f32, double* d_reward, uint8_t* d_done,
+                          double* d_return_acc, int32_t* d_steps_taken);
+
 int lobsim_obs_dim(const lobsim_t* h);
 
 /* --- inspection (parity tests, info dicts) ---------------------------------------------------------------- */

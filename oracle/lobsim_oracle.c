@@ -1040,6 +1040,57 @@ int oracle_step(oracle_t* h, const double* actions, const uint8_t* active, doubl
     return LOBSIM_OK;
 }
 
+/* Teradactyl.get_action (rl4mm/agents/baseline_agents.py:58-87) */
+static void teradactyl_action(const double* p, double inventory, double* a) {
+    const double max_inv = p[0], def_kappa = p[1], w = p[2], max_kappa = p[3], e = p[4], denom = p[7], eps = 0.00001;
+    double x = inventory / denom;
+    double u = x < 1 - eps ? x : 1 - eps;
+    u = u > -1 + eps ? u : -1 + eps;
+    double omega_bid, omega_ask;
+    if (inventory >= 0) {
+        omega_bid = w * (1 + (1 / w - 1) * pow(u, e));
+        omega_ask = w * (1 - pow(u, e));
+    } else {
+        omega_bid = w * (1 - pow(fabs(u), e));
+        omega_ask = w * (1 + (1 / w - 1) * pow(fabs(u), e));
+    }
+    double kappa = (max_kappa - def_kappa) * pow(fabs(inventory / max_inv), e) + def_kappa;
+    a[0] = omega_bid * (kappa - 2) + 1; a[1] = (1 - omega_bid) * (kappa - 2) + 1;
+    a[2] = omega_ask * (kappa - 2) + 1; a[3] = (1 - omega_ask) * (kappa - 2) + 1;
+    a[4] = p[6] != 0.0 ? max_inv * 2 : 0.0;
+}
+
+/* generate_trajectory (rl4mm/gym/utils.py:100-117) with the action of every step produced here: host mirror of
+ * lobsim_rollout_device.  actions_out (may be NULL) [T][n_envs][A] receives the actions taken. */
+int oracle_rollout(oracle_t* h, int32_t policy, const double* params8, int32_t T, const double* actions, const uint8_t* active,
+                   double* obs, double* reward, uint8_t* done, double* return_acc, int32_t* steps_taken, double* actions_out) {
+    int D = oracle_obs_dim(h), A = h->cfg.action_dim, N = h->cfg.n_envs;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int i = 0; i < N; i++) {
+        if (active && !active[i]) continue;
+        Env* e = &h->env[i];
+        double ob[LOBSIM_MAX_FEATURES + LOBSIM_MAX_ACTION_DIM], r = 0.0, ret = 0.0;
+        uint8_t d = e->status ? 1 : 0;
+        int steps = 0;
+        for (int t = 0; t < T && !d; t++) {
+            double a[LOBSIM_MAX_ACTION_DIM] = {0, 0, 0, 0, 0};
+            if (policy == LOBSIM_POLICY_GIVEN) for (int k = 0; k < A; k++) a[k] = actions[((size_t)t * N + i) * A + k];
+            else if (policy == LOBSIM_POLICY_FIXED) for (int k = 0; k < A; k++) a[k] = params8[k];
+            else teradactyl_action(params8, e->feat[(int)params8[5]].current_value, a);
+            if (actions_out) for (int k = 0; k < A; k++) actions_out[((size_t)t * N + i) * A + k] = a[k];
+            env_step(h, e, a, ob, &r, &d);
+            ret += r;
+            steps++;
+        }
+        write_obs(h, e, ob, 1);
+        if (obs) memcpy(obs + (size_t)i * D, ob, sizeof(double) * (size_t)D);
+        reward[i] = r; done[i] = d;
+        if (return_acc) return_acc[i] += ret;
+        if (steps_taken) steps_taken[i] = steps;
+    }
+    return LOBSIM_OK;
+}
+
 int oracle_get_env_state(oracle_t* h, int32_t env, lobsim_env_state* out) {
     if (env < 0 || env >= h->cfg.n_envs) return LOBSIM_ERR_ARG;
     Env* e = &h->env[env];

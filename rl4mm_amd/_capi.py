@@ -22,6 +22,7 @@ ST_AGENT_OVERFLOW, ST_STREAM_END, ST_ASSERT, ST_NOT_RESET = 16, 32, 64, 128
 F_SPREAD, F_PRICE_MOVE, F_VOLATILITY, F_INVENTORY, F_EPISODE_PROPORTION, F_TIME_OF_DAY = 1, 2, 3, 4, 5, 6
 F_TRADE_DIRECTION_IMBALANCE, F_TRADE_VOLUME_IMBALANCE, F_BOOK_IMBALANCE, F_PRICE_RANGE, F_PRICE, F_AMIHUD_LAMBDA = 7, 8, 9, 10, 11, 12
 R_PNL, R_INVENTORY_ADJUSTED = 1, 2
+POLICY_GIVEN, POLICY_FIXED, POLICY_TERADACTYL = 0, 1, 2
 
 
 class FeatureDesc(C.Structure):
@@ -123,6 +124,7 @@ PROTOTYPES = {
     "step": (C.c_int, [C.c_void_p, _PD, _PU8, _PD, _PD, _PU8]),
     "step_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sync": (C.c_int, [C.c_void_p]),
+    "rollout_device": (C.c_int, [C.c_void_p, C.c_int32, _PD, C.c_int32] + [C.c_void_p] * 8),
     "obs_dim": (C.c_int, [C.c_void_p]),
     "get_env_state": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(EnvState)]),
     "get_portfolios": (C.c_int, [C.c_void_p, _P64, _P64, _PD]),
@@ -132,7 +134,7 @@ PROTOTYPES = {
     "debug_process_orders": (C.c_int, [C.c_void_p, C.c_int32, _P64, C.c_int32, _P64]),
 }
 # the oracle has no device entry points
-ORACLE_SKIP = {"set_stream", "step_device", "sync"}
+ORACLE_SKIP = {"set_stream", "step_device", "sync", "rollout_device"}
 
 
 def _ptr(a: Optional[np.ndarray], typ):
@@ -276,6 +278,12 @@ class Sim:
 
     def step_device(self, d_actions: int, d_active: int, d_obs: int, d_obs_f32: int, d_reward: int, d_done: int, d_return_acc: int = 0):
         self._check(self.b.fn["step_device"](self.h, d_actions, d_active, d_obs, d_obs_f32, d_reward, d_done, d_return_acc), "step_device")
+
+    def rollout_device(self, policy: int, params, T: int, d_actions: int, d_active: int, d_obs: int, d_obs_f32: int, d_reward: int, d_done: int,
+                       d_return_acc: int = 0, d_steps_taken: int = 0):
+        p8 = np.zeros(8, dtype=np.float64)
+        p8[: len(params)] = params
+        self._check(self.b.fn["rollout_device"](self.h, policy, _ptr(p8, _PD), T, d_actions, d_active, d_obs, d_obs_f32, d_reward, d_done, d_return_acc, d_steps_taken), "rollout_device")
 
     def sync(self):
         self._check(self.b.fn["sync"](self.h), "sync")

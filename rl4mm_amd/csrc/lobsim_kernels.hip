@@ -1252,6 +1252,118 @@ __global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg 
 #endif
 }
 
+struct RolloutArgs {
+    int32_t policy, T;
+    const double* actions;  // LOBSIM_POLICY_GIVEN: [T][n_envs][A]
+    double params[8];
+    const uint8_t* active;
+    double* obs;
+    float* obs_f32;
+    double* reward;
+    uint8_t* done;
+    double* return_acc;
+    int32_t* steps_taken;
+};
+
+// Teradactyl.get_action (rl4mm/agents/baseline_agents.py:58-87), same f64 operation order
+DI Act5 teradactyl_action(const double* p, double inventory) {
+    const double max_inv = p[0], def_kappa = p[1], w = p[2], max_kappa = p[3], e = p[4], denom = p[7], eps = 0.00001;
+    double x = inventory / denom;
+    double u = x < 1 - eps ? x : 1 - eps;  // clamp_to_unit: max(min(x, 1 - eps), -1 + eps)
+    u = u > -1 + eps ? u : -1 + eps;
+    double omega_bid, omega_ask;
+    if (inventory >= 0) {
+        omega_bid = w * (1 + (1 / w - 1) * pow(u, e));
+        omega_ask = w * (1 - pow(u, e));
+    } else {
+        omega_bid = w * (1 - pow(fabs(u), e));
+        omega_ask = w * (1 + (1 / w - 1) * pow(fabs(u), e));
+    }
+    const double kappa = (max_kappa - def_kappa) * pow(fabs(inventory / max_inv), e) + def_kappa;
+    Act5 a;
+    a.v0 = omega_bid * (kappa - 2) + 1;
+    a.v1 = (1 - omega_bid) * (kappa - 2) + 1;
+    a.v2 = omega_ask * (kappa - 2) + 1;
+    a.v3 = (1 - omega_ask) * (kappa - 2) + 1;
+    a.v4 = p[6] != 0.0 ? max_inv * 2 : 0.0;
+    return a;
+}
+
+// generate_trajectory (rl4mm/gym/utils.py:100-117) for open-loop / rule-based agents: up to T env.step()s per env in
+// one launch.  Every wave runs its env's steps back to back, so a launch no longer lasts as long as the busiest env of
+// EACH step, and the ladder / agent orders / feature scalars stay in LDS / registers between steps.
+__global__ __launch_bounds__(64, 3) void lob_rollout_kernel(DevCfg C, DevPtrs P, RolloutArgs A) {
+    __shared__ Lds L;
+    const int env = blockIdx.x, ln = lane();
+    if (A.active && !A.active[env]) return;
+    EnvHdr& H = P.hdr[env];
+    const int F = C.c.n_features, AD = C.c.action_dim, D = C.obs_dim, N = gridDim.x;
+    Scal S;
+    load_env(L, S, P, env, H);
+    FeatState fs = FeatState();
+    int64_t* ring = nullptr;
+    if (ln < F) { fs = P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln]; ring = P.rings + (size_t)env * C.ring_words + C.ring_off[ln]; }
+    int64_t now = H.now_us, cursor = H.msg_cursor;
+    const int stream_id = H.stream_id;
+    Ranges R = {H.min_buy, H.max_sell, H.init_buy_range, H.init_sell_range};
+    int n_resyncs = H.n_resyncs;
+    double price = H.price, reward = 0.0, ret = 0.0;
+    int done = S.status ? 1 : 0, steps = 0;
+    Act5 act;
+    act.v0 = H.prev_action[0]; act.v1 = H.prev_action[1]; act.v2 = H.prev_action[2]; act.v3 = H.prev_action[3]; act.v4 = H.prev_action[4];
+    for (int t = 0; t < A.T && !done; t++) {
+        if (A.policy == LOBSIM_POLICY_GIVEN) {
+            const double* ap = A.actions + ((size_t)t * N + env) * AD;
+            act.v0 = ap[0]; act.v1 = ap[1];
+            act.v2 = AD > 2 ? ap[2] : 0.0; act.v3 = AD > 3 ? ap[3] : 0.0; act.v4 = AD > 4 ? ap[4] : 0.0;
+        } else if (A.policy == LOBSIM_POLICY_FIXED) {
+            act.v0 = A.params[0]; act.v1 = A.params[1]; act.v2 = A.params[2]; act.v3 = A.params[3]; act.v4 = A.params[4];
+        } else {
+            act = teradactyl_action(A.params, rld(fs.current_value, (int)A.params[5]));  // obs[inventory_index]
+        }
+        clear_step_fills(S);
+        const int64_t inv0 = S.inv, cash0 = S.cash;
+        const double p0 = price;
+        reward = 0.0;
+        build_agent_ops(L, S, C, act);
+        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true);
+        if (!S.status) {
+            StepView v = make_view(L, S, price, now);
+            bool ok = true;
+            if (ln < F) ok = feature_update(C.c.features[ln], fs, ring, v);
+            if (__ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
+        }
+        if (!S.status) {
+            reward = reward_of(C.c.per_step_reward, inv0, cash0, p0, S.inv, S.cash, price);
+            if (2 * (H.terminal_us - now) < C.c.step_us) {
+                reward = reward_of(C.c.terminal_reward, inv0, cash0, p0, S.inv, S.cash, price);
+                done = 1;
+            }
+        } else { done = 1; reward = 0.0; }
+        ret += reward;
+        steps++;
+    }
+    double val = 0.0;
+    if (ln < F) val = fs.current_value;
+    else if (ln < D) val = act_at(act, ln - F);
+    if (ln < D) {
+        if (A.obs) A.obs[(size_t)env * D + ln] = val;
+        if (A.obs_f32) A.obs_f32[(size_t)env * D + ln] = (float)val;
+    }
+    if (ln == 0) {
+        A.reward[env] = reward; A.done[env] = (uint8_t)done;
+        if (A.return_acc) A.return_acc[env] += ret;
+        if (A.steps_taken) A.steps_taken[env] = steps;
+    }
+    if (ln < F) P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln] = fs;
+    store_env(L, S, P, env, H);
+    if (ln == 0) {
+        H.now_us = now; H.msg_cursor = cursor; H.price = price; H.n_resyncs = n_resyncs;
+        H.min_buy = R.min_buy; H.max_sell = R.max_sell;
+        H.prev_action[0] = act.v0; H.prev_action[1] = act.v1; H.prev_action[2] = act.v2; H.prev_action[3] = act.v3; H.prev_action[4] = act.v4;
+    }
+}
+
 // env.reset(): snapshot book at (episode_start - warmup), features reset, warm-up replay without agent orders
 // (HistoricalOrderbookEnvironment.py:147-161)
 __global__ __launch_bounds__(64, 4) void lob_reset_kernel(DevCfg C, DevPtrs P, ResetArgs A) {

@@ -34,6 +34,9 @@ def oracle_binding() -> _capi.Binding:
         b.lib.oracle_debug_forward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64]
         b.lib.oracle_debug_reset_episode.restype = C.c_int
         b.lib.oracle_debug_reset_episode.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64]
+        PI32, PU8 = C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+        b.lib.oracle_rollout.restype = C.c_int
+        b.lib.oracle_rollout.argtypes = [C.c_void_p, C.c_int32, PD, C.c_int32, PD, PU8, PD, PD, PU8, PD, PI32, PD]
         _binding = b
     return _binding
 
@@ -101,3 +104,25 @@ def snapshot_row_from_levels(levels, n_levels: int) -> np.ndarray:
             row[4 * ns], row[4 * ns + 1] = price, vol
             ns += 1
     return row
+
+
+def oracle_rollout(sim, policy, params, T, actions=None):
+    """Host mirror of Sim.rollout_device: -> dict(obs, reward, done, ret, steps, actions)."""
+    n, A, D = sim.n_envs, sim.action_dim, sim.obs_dim
+    p8 = np.zeros(8, dtype=np.float64)
+    p8[: len(params)] = params
+    obs = np.zeros((n, D)); reward = np.zeros(n); done = np.zeros(n, dtype=np.uint8); ret = np.zeros(n)
+    steps = np.zeros(n, dtype=np.int32); acts_out = np.zeros((max(T, 1), n, A))
+    PD, PU8, PI32 = C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
+    a = None if actions is None else np.ascontiguousarray(actions, dtype=np.float64)
+    rc = sim.b.lib.oracle_rollout(sim.h, policy, p8.ctypes.data_as(PD), T, None if a is None else a.ctypes.data_as(PD), None,
+                                  obs.ctypes.data_as(PD), reward.ctypes.data_as(PD), done.ctypes.data_as(PU8), ret.ctypes.data_as(PD),
+                                  steps.ctypes.data_as(PI32), acts_out.ctypes.data_as(PD))
+    assert rc == 0
+    return dict(obs=obs, reward=reward, done=done, ret=ret, steps=steps, actions=acts_out[:T])
+
+
+TERADACTYL_GOLDEN = {  # the agents oracle/gen_golden.py drove the reference with (policy parameters of lobsim_rollout_device)
+    "msft_teradactyl_ad": [100, 7.0, 0.5, 9.0, 1.0, 0, 0, 100],
+    "synth_teradactyl_ad_spread": [300, 10.0, 0.5, 10.0, 1.0, 3, 0, 300],
+}

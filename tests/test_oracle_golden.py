@@ -116,3 +116,22 @@ def test_known_answers_from_reference_tests():
     assert len(orders) == 20 and np.all(orders[:, 3] == 10) and np.all(orders[:, 0] == 1)
     orders = ol.oracle_peek_orders(sim, [1, 2, 1, 2])
     assert list(orders[:, 3]) == [19, 17, 15, 13, 11, 9, 7, 5, 3, 1] * 2
+
+
+@pytest.mark.parametrize("name", list(ol.TERADACTYL_GOLDEN))
+def test_rollout_with_on_device_teradactyl_reproduces_reference(name):
+    """G4: a whole episode in one oracle_rollout call, the Teradactyl policy evaluated inside: the actions it takes,
+    the return and the final portfolio must be the reference's (generate_trajectory with the reference's agent)."""
+    g, z = ol.load_traj(name)
+    sim = ol.oracle_sim(ol.cfg_from_golden(g))
+    sid = sim.add_stream(ol.golden_stream(g["stream_file"]))
+    sim.set_portfolio(g["initial_inventory"], g["initial_cash"])
+    sim.reset(g["starts_us"][0], sid)
+    n = len(z["reward"])
+    out = ol.oracle_rollout(sim, _capi.POLICY_TERADACTYL, ol.TERADACTYL_GOLDEN[name], n + 5)
+    assert out["steps"][0] == n and out["done"][0] == 1
+    assert np.array_equal(out["actions"][:n, 0, :], z["actions"])
+    assert out["ret"][0] == np.add.accumulate(z["reward"])[-1] or abs(out["ret"][0] - z["reward"].sum()) < 1e-6
+    assert np.array_equal(out["obs"][0], z["obs"][-1]) and out["reward"][0] == z["reward"][-1]
+    st = sim.env_state(0)
+    assert st["inventory"] == z["inventory"][-1] and st["cash"] == z["cash"][-1]
