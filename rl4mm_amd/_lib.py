@@ -28,16 +28,33 @@ def _stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
-    """hipcc --offload-arch=gfx950 -> liblobsim.so (in-tree, so it travels with the repo snapshot)."""
+    """hipcc --offload-arch=gfx950 -> liblobsim.so (in-tree, so it travels with the repo snapshot).  Safe when several
+    ranks import at once: the build is serialised by a file lock and the library is replaced atomically."""
     if not force and not _stale():
         return LIB_PATH
+    import fcntl
+    import tempfile
+
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("liblobsim.so is missing or stale and hipcc was not found: cannot build the HIP library")
-    cmd = [hipcc, *HIPCC_FLAGS, "-o", str(LIB_PATH), str(SOURCES[0])]
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    subprocess.check_call(cmd, cwd=str(CSRC))
+    with open(CSRC / ".build.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or _stale():  # another process may have built it while we waited
+                fd, tmp = tempfile.mkstemp(suffix=".so", dir=str(CSRC))
+                os.close(fd)
+                cmd = [hipcc, *HIPCC_FLAGS, "-o", tmp, str(SOURCES[0])]
+                if verbose:
+                    cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+                try:
+                    subprocess.check_call(cmd, cwd=str(CSRC))
+                    os.replace(tmp, LIB_PATH)
+                finally:
+                    if os.path.exists(tmp):
+                        os.unlink(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
