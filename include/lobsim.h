@@ -208,6 +208,9 @@ int lobsim_obs_dim(const lobsim_t* h);
 int lobsim_get_env_state(lobsim_t* h, int32_t env, lobsim_env_state* out);
 /* Device-side bulk read of (inventory, cash, price) for all envs into host arrays (any may be NULL). */
 int lobsim_get_portfolios(lobsim_t* h, int64_t* inventory, int64_t* cash, double* price);
+/* Best prices of the central book of every env (Orderbook.best_buy_price / best_sell_price, models.py:71-77): 0 when the
+ * buy side is empty, INT64_MAX when the sell side is empty.  market spread = best_sell - best_buy (info calculators). */
+int lobsim_get_best_prices(lobsim_t* h, int64_t* best_buy, int64_t* best_sell);
 /* Central book, best level first: prices/volumes/order counts of up to max_levels levels of one side. */
 int lobsim_get_book(lobsim_t* h, int32_t env, int32_t side, int64_t* prices, int64_t* volumes, int32_t* n_orders,
                     int32_t max_levels, int32_t* n_levels_out);

@@ -46,6 +46,7 @@ from rl4mm.features.Features import (  # noqa: E402
 )
 from rl4mm.gym.HistoricalOrderbookEnvironment import HistoricalOrderbookEnvironment  # noqa: E402
 from rl4mm.gym.action_interpretation.OrderDistributors import BetaOrderDistributor  # noqa: E402
+from rl4mm.gym.order_tracking.InfoCalculators import SimpleInfoCalculator  # noqa: E402
 from rl4mm.gym.utils import get_reward_function  # noqa: E402
 from rl4mm.orderbook.Exchange import Exchange  # noqa: E402
 from rl4mm.orderbook.models import Cancellation, Deletion, LimitOrder, MarketOrder  # noqa: E402
@@ -302,7 +303,7 @@ def feature_desc(f):
 
 def run_trajectory(name, db, ticker, date, n_levels, features, agent_fn, n_episodes, starts, episode_s, step_s=0.1,
                    step_reward="PnL", terminal_reward="PnL", enter_spread=False, inc_prev=False, moc=False, mofi=0.0,
-                   concentration=None, minq=0, maxq=10, initial=(0, 1000), outer_levels=20, top_k=12, stream_file=None):  # fmt: skip
+                   concentration=None, minq=0, maxq=10, initial=(0, 1000), outer_levels=20, top_k=12, stream_file=None, info=False):  # fmt: skip
     step = timedelta(seconds=step_s)
     episode = timedelta(seconds=episode_s)
     warm = max(f.window_size for f in features)
@@ -315,6 +316,7 @@ def run_trajectory(name, db, ticker, date, n_levels, features, agent_fn, n_episo
         min_date=date, max_date=date, simulator=sim, market_order_clearing=moc, inc_prev_action_in_obs=inc_prev,
         per_step_reward_function=get_reward_function(step_reward), terminal_reward_function=get_reward_function(terminal_reward),
         concentration=concentration, market_order_fraction_of_inventory=mofi, enter_spread=enter_spread, n_levels=n_levels,
+        info_calculator=SimpleInfoCalculator(market_order_fraction_of_inventory=mofi, enter_spread=enter_spread, concentration=concentration) if info else None,
     )  # fmt: skip
     captured = {}
     orig_convert = env.convert_action_to_orders
@@ -350,12 +352,16 @@ def run_trajectory(name, db, ticker, date, n_levels, features, agent_fn, n_episo
         while True:
             action = np.asarray(agent(obs), dtype=np.float64)
             try:
-                obs, reward, done, info = env.step(action)
+                obs, reward, done, info_ = env.step(action)
             except (AssertionError, Exception) as exc:  # the reference crashes here; pin where and why
                 rec["crash"] = (len(rec["reward"]), type(exc).__name__)
                 rec["crash_action"] = action
                 break
             rec["actions"].append(action)
+            if info:
+                rec.setdefault("info", []).append([float(np.asarray(x).reshape(-1)[0]) for x in (
+                    info_["asset_price"], info_["inventory"], info_["cash"], info_["aum"], info_["market_spread"], info_["agent_spread"], info_["midprice_offset"],
+                    info_["weighted_midprice_offset"], info_["market_order_count"], info_["market_order_total_volume"])])
             rec["obs"].append(np.asarray(obs, dtype=np.float64))
             rec["reward"].append(float(reward))
             rec["done"].append(bool(done))
@@ -395,7 +401,7 @@ def run_trajectory(name, db, ticker, date, n_levels, features, agent_fn, n_episo
         orders=np.array(rec["orders"], dtype=np.int64).reshape(-1, 4), order_off=np.array(rec["order_off"]),
         reset_obs=np.array(rec["reset_obs"]), queues=np.concatenate(rec["queues"]), queue_off=np.array(rec["queue_off"]),
         crash_step=np.array(rec["crash"][0] if "crash" in rec else -1), crash_type=np.array(rec["crash"][1] if "crash" in rec else ""),
-        crash_action=np.array(rec.get("crash_action", np.zeros(A))),
+        crash_action=np.array(rec.get("crash_action", np.zeros(A))), info=np.array(rec.get("info", np.zeros((0, 10)))),
     )  # fmt: skip
     np.savez_compressed(GOLD / f"traj_{name}.npz", **out)
     print(f"traj_{name}: {len(rec['reward'])} steps, final inv {rec['inventory'][-1]} cash {rec['cash'][-1]}, "
@@ -526,6 +532,9 @@ def main():
         amihud = lambda: [Spread(), Inventory(), AmihudLambda(), AmihudLambda(name="al2", update_frequency=timedelta(seconds=0.2), lookback_periods=4, slowing_factor=5),  # noqa: E731
                           TradeVolumeImbalance(update_frequency=timedelta(seconds=0.1), lookback_periods=30)]
         run_trajectory("synth_amihud", db_s, "SYN", sdate, 10, amihud(), random_agent(21), 1, [35950], 25.0, step_reward="PnL", terminal_reward="SD", stream_file="synth_small")
+        run_trajectory("synth_info_moc", db_s, "SYN", sdate, 10, short(), random_agent(9, high=40.0), 1, [35965], 15.0, step_reward="PnL", terminal_reward="PnL",
+                       moc=True, mofi=1.0, concentration=12.0, initial=(0, 10**12), stream_file="synth_small", info=True)  # fmt: skip
+        run_trajectory("synth_info_spread", db_s, "SYN", sdate, 10, short(), random_agent(10), 1, [35930], 12.0, enter_spread=True, stream_file="synth_small", info=True)
         run_trajectory("synth_q5_fixed", db_s, "SYN", sdate, 10, short(), fixed_agent([2, 5, 5, 2]), 1, [36010], 20.0, minq=2, maxq=7, stream_file="synth_small")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

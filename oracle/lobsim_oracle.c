@@ -1126,6 +1126,15 @@ int oracle_get_portfolios(oracle_t* h, int64_t* inventory, int64_t* cash, double
     return LOBSIM_OK;
 }
 
+int oracle_get_best_prices(oracle_t* h, int64_t* best_buy, int64_t* best_sell) {
+    for (int i = 0; i < h->cfg.n_envs; i++) {
+        double bb = book_best_buy(&h->env[i].ex.central), bs = book_best_sell(&h->env[i].ex.central);
+        best_buy[i] = (int64_t)bb;
+        best_sell[i] = bs < INFINITY ? (int64_t)bs : INT64_MAX;
+    }
+    return LOBSIM_OK;
+}
+
 int oracle_get_book(oracle_t* h, int32_t env, int32_t side, int64_t* prices, int64_t* volumes, int32_t* n_orders, int32_t max_levels, int32_t* n_out) {
     if (env < 0 || env >= h->cfg.n_envs || side < 0 || side > 1) return LOBSIM_ERR_ARG;
     Side* s = &h->env[env].ex.central.s[side];

@@ -128,6 +128,7 @@ PROTOTYPES = {
     "obs_dim": (C.c_int, [C.c_void_p]),
     "get_env_state": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(EnvState)]),
     "get_portfolios": (C.c_int, [C.c_void_p, _P64, _P64, _PD]),
+    "get_best_prices": (C.c_int, [C.c_void_p, _P64, _P64]),
     "get_book": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _P64, _P64, _P32, C.c_int32, _P32]),
     "get_level_orders": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(OrderView), C.c_int32, _P32]),
     "debug_set_book": (C.c_int, [C.c_void_p, C.c_int32, _P64, C.c_int64]),
@@ -303,6 +304,12 @@ class Sim:
         price = np.zeros(self.n_envs, dtype=np.float64)
         self._check(self.b.fn["get_portfolios"](self.h, _ptr(inv, _P64), _ptr(cash, _P64), _ptr(price, _PD)), "get_portfolios")
         return inv, cash, price
+
+    def best_prices(self):
+        bb = np.zeros(self.n_envs, dtype=np.int64)
+        bs = np.zeros(self.n_envs, dtype=np.int64)
+        self._check(self.b.fn["get_best_prices"](self.h, _ptr(bb, _P64), _ptr(bs, _P64)), "get_best_prices")
+        return bb, bs
 
     def book(self, env: int, side: int, max_levels: int = 256):
         prices = np.zeros(max_levels, dtype=np.int64)

@@ -1512,6 +1512,13 @@ __global__ void lob_gather_portfolios_kernel(DevPtrs P, int n, int64_t* inv, int
     if (price) price[i] = P.hdr[i].price;
 }
 
+__global__ void lob_gather_best_prices_kernel(DevPtrs P, int n, int64_t* best_buy, int64_t* best_sell) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    best_buy[i] = P.hdr[i].n_lv[0] > 0 ? P.ladder[i].price[0][0] : 0;
+    best_sell[i] = P.hdr[i].n_lv[1] > 0 ? P.ladder[i].price[1][0] : INT64_MAX;
+}
+
 __global__ void lob_init_hdr_kernel(DevPtrs P, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

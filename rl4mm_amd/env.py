@@ -241,6 +241,92 @@ def get_default_features(step_size: timedelta, episode_length: timedelta, normal
     ]
 
 
+def beta_volumes(actions: np.ndarray, quote_levels: int = 10, concentration: Optional[float] = None, active_volume: int = 100):
+    """BetaOrderDistributor.convert_action (rl4mm/gym/action_interpretation/OrderDistributors.py:23-56) for a batch of
+    actions [N, A] -> (buy [N, Q], sell [N, Q]) integer volumes; same closed form as the kernel (x^(a-1) (1-x)^(b-1),
+    the 1/B(a,b) of the pdf cancels in the normalisation), checked against the scipy table in tests/golden."""
+    a = np.asarray(actions, dtype=np.float64) + 0.000001
+    if concentration is not None:
+        ab, bb, as_, bs = a[:, 0], concentration - a[:, 0] + 0.000001, a[:, 1], concentration - a[:, 1] + 0.000001
+    else:
+        ab, bb, as_, bs = a[:, 0], a[:, 1], a[:, 2], a[:, 3]
+    x = 1 / quote_levels * np.array([i + 0.5 for i in range(quote_levels)])
+    out = []
+    for al, be in ((ab, bb), (as_, bs)):
+        pdf = np.power(x[None, :], al[:, None] - 1.0) * np.power(1.0 - x[None, :], be[:, None] - 1.0)
+        pdf = pdf / np.array([row.sum() for row in pdf])[:, None]  # per-row np.sum = the reference's summation order
+        out.append(np.round(pdf * active_volume).astype(np.int64))
+    return out[0], out[1]
+
+
+class SimpleInfoCalculator:
+    """rl4mm/gym/order_tracking/InfoCalculators.py:17-89, batched: the `info` dict of every env from bulk device reads
+    (price, inventory, cash, best prices) and the actions.  Host side by design: it is evaluation tooling, not the
+    rollout hot path (the reference default is info_calculator=None)."""
+
+    def __init__(self, market_order_fraction_of_inventory: float = 0.0, enter_spread: bool = False, order_distributor=None, concentration: float = None,
+                 quote_levels: int = 10, active_volume: int = 100):
+        self.market_order_fraction_of_inventory = market_order_fraction_of_inventory
+        self.enter_spread, self.concentration = enter_spread, concentration
+        self.quote_levels, self.active_volume = quote_levels, active_volume  # BetaOrderDistributor defaults (:29)
+        self.market_order_count = None
+        self.market_order_total_volume = None
+
+    def calculate_arrays(self, sim, actions: np.ndarray) -> Dict[str, np.ndarray]:
+        actions = np.asarray(actions, dtype=np.float64)
+        n = actions.shape[0]
+        if self.market_order_count is None:
+            self.market_order_count = np.zeros(n, dtype=np.int64)
+            self.market_order_total_volume = np.zeros(n, dtype=np.float64)
+        inv, cash, price = sim.portfolios()
+        bb, bs = sim.best_prices()
+        spread = (bs - bb).astype(np.int64)
+        buy, sell = beta_volumes(actions, self.quote_levels, self.concentration, self.active_volume)
+        levels = np.arange(self.quote_levels)
+        best_buy, best_sell = np.sign(buy).argmax(axis=1), np.sign(sell).argmax(axis=1)  # :66-67
+        midprice_offset = (best_sell - best_buy) / 2
+        agent_spread = (best_buy + best_sell).astype(np.float64)
+        buy_com, sell_com = buy @ levels / self.active_volume, sell @ levels / self.active_volume
+        weighted_offset = (sell_com - buy_com) / 2
+        weighted_spread = buy_com + sell_com
+        if not self.enter_spread:
+            agent_spread = agent_spread + spread
+            weighted_spread = weighted_spread + spread
+        A = actions.shape[1]
+        if A in (3, 5):  # :52-56, with the post-step inventory like the reference
+            hit = np.abs(inv) > actions[:, -1]
+            self.market_order_count = self.market_order_count + hit
+            self.market_order_total_volume = self.market_order_total_volume + np.where(hit, np.round(np.abs(inv) * self.market_order_fraction_of_inventory), 0.0)
+        return dict(
+            asset_price=price, inventory=inv, cash=cash, aum=cash + price * inv, market_spread=spread, agent_spread=agent_spread,
+            agent_weighted_spread_value=weighted_spread, midprice_offset=midprice_offset, weighted_midprice_offset=weighted_offset,
+            market_order_count=self.market_order_count.copy(), market_order_total_volume=self.market_order_total_volume.copy(),
+        )
+
+    def calculate_dicts(self, sim, actions: np.ndarray) -> List[dict]:
+        """One dict per env with exactly the reference's keys (including its literal agent_weighted_spread=[1])."""
+        arr = self.calculate_arrays(sim, actions)
+        actions = np.asarray(actions, dtype=np.float64)
+        A = actions.shape[1]
+        out = []
+        for i in range(actions.shape[0]):
+            d = dict(
+                asset_price=float(arr["asset_price"][i]), inventory=int(arr["inventory"][i]), cash=int(arr["cash"][i]), aum=float(arr["aum"][i]),
+                market_spread=int(arr["market_spread"][i]), agent_spread=arr["agent_spread"][i], agent_weighted_spread=[1],
+                midprice_offset=arr["midprice_offset"][i], weighted_midprice_offset=arr["weighted_midprice_offset"][i],
+            )
+            if A in (2, 3):
+                d["bid_action"], d["ask_action"] = (actions[i][[0]],), (actions[i][[1]],)
+            else:
+                d["bid_action"], d["ask_action"] = (actions[i][[0, 1]],), (actions[i][[2, 3]],)
+            if A in (3, 5):
+                d["market_order_action"] = (actions[i][[-1]],)
+            d["market_order_count"] = int(arr["market_order_count"][i])
+            d["market_order_total_volume"] = arr["market_order_total_volume"][i]
+            out.append(d)
+        return out
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # data source
 # ---------------------------------------------------------------------------------------------------------------
@@ -314,8 +400,7 @@ class HistoricalOrderbookVectorEnv:
         assert min_start_timedelta + episode_length <= max_end_timedelta, "Episode is too long"  # :372
         if (market_order_clearing and market_order_fraction_of_inventory <= 0.0) or (not market_order_clearing and market_order_fraction_of_inventory > 0.0):
             raise Exception("market_order_fraction_of_inventory must be positive if and only if market order clearing is on")  # :376-384
-        if info_calculator is not None:
-            raise NotImplementedError("info calculators are host-side; pass None (the reference default, main_helper.py:233)")
+        self.info_calculator = info_calculator  # None (the reference default, main_helper.py:233) -> info == {}
         self.num_envs = num_envs
         self.catalog = catalog
         self.ticker, self.step_size, self.episode_length = ticker, step_size, episode_length
@@ -400,7 +485,8 @@ class HistoricalOrderbookVectorEnv:
     def vector_step(self, actions):
         obs, reward, done = self.sim.step(np.asarray(actions, dtype=np.float64), active=(~self._dones).astype(np.uint8))
         self._dones |= done.astype(bool)
-        return list(obs), list(reward), list(done.astype(bool)), [{} for _ in range(self.num_envs)]
+        infos = [{} for _ in range(self.num_envs)] if self.info_calculator is None else self.info_calculator.calculate_dicts(self.sim, actions)
+        return list(obs), list(reward), list(done.astype(bool)), infos
 
     def get_sub_environments(self):
         return []
