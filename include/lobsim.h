@@ -89,12 +89,19 @@ typedef struct lobsim_feature {
     int64_t iparam; /* TimeOfDay: bucket size in us (Features.py:528); AmihudLambda: slowing_factor */
 } lobsim_feature;
 
-enum lobsim_reward_kind { LOBSIM_R_PNL = 1 /* RewardFunctions.py:97 */, LOBSIM_R_INVENTORY_ADJUSTED = 2 /* :107 */ };
+enum lobsim_reward_kind {
+    LOBSIM_R_PNL = 1,                /* RewardFunctions.py:97 */
+    LOBSIM_R_INVENTORY_ADJUSTED = 2, /* :107 */
+    LOBSIM_R_ROLLING_SHARPE = 3      /* :38; stateful: one AUM window per env and per role (per-step / terminal) */
+};
+#define LOBSIM_SHARPE_MAX_WINDOW 128
 
 typedef struct lobsim_reward {
     int32_t kind;
     int32_t asymmetrically_dampened;
     double inventory_aversion;
+    int32_t max_window; /* RollingSharpe(max_window_size=120, min_window_size=60); max_window <= 128 */
+    int32_t min_window;
 } lobsim_reward;
 
 /* Mirrors the constructor arguments of HistoricalOrderbookEnvironment (HistoricalOrderbookEnvironment.py:54-81)

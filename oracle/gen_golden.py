@@ -48,6 +48,7 @@ from rl4mm.gym.HistoricalOrderbookEnvironment import HistoricalOrderbookEnvironm
 from rl4mm.gym.action_interpretation.OrderDistributors import BetaOrderDistributor  # noqa: E402
 from rl4mm.gym.order_tracking.InfoCalculators import SimpleInfoCalculator  # noqa: E402
 from rl4mm.gym.utils import get_reward_function  # noqa: E402
+from rl4mm.rewards.RewardFunctions import RollingSharpe  # noqa: E402
 from rl4mm.orderbook.Exchange import Exchange  # noqa: E402
 from rl4mm.orderbook.models import Cancellation, Deletion, LimitOrder, MarketOrder  # noqa: E402
 from rl4mm.simulation.HistoricalOrderGenerator import HistoricalOrderGenerator  # noqa: E402
@@ -301,9 +302,22 @@ def feature_desc(f):
     return d
 
 
+ONLY = set(sys.argv[sys.argv.index("--only") + 1].split(",")) if "--only" in sys.argv else set()  # regenerate just these trajectories
+
+
+def reward_from_spec(spec):
+    """"PnL" | "AD" | "SD" | "RS" as rl4mm.gym.utils.get_reward_function takes them, or ("RS", max_window, min_window)."""
+    if isinstance(spec, str):
+        return get_reward_function(spec)
+    assert spec[0] == "RS"
+    return RollingSharpe(max_window_size=spec[1], min_window_size=spec[2])
+
+
 def run_trajectory(name, db, ticker, date, n_levels, features, agent_fn, n_episodes, starts, episode_s, step_s=0.1,
                    step_reward="PnL", terminal_reward="PnL", enter_spread=False, inc_prev=False, moc=False, mofi=0.0,
                    concentration=None, minq=0, maxq=10, initial=(0, 1000), outer_levels=20, top_k=12, stream_file=None, info=False):  # fmt: skip
+    if ONLY and name not in ONLY:
+        return
     step = timedelta(seconds=step_s)
     episode = timedelta(seconds=episode_s)
     warm = max(f.window_size for f in features)
@@ -314,7 +328,7 @@ def run_trajectory(name, db, ticker, date, n_levels, features, agent_fn, n_episo
         features=features, ticker=ticker, step_size=step, episode_length=episode,
         initial_portfolio=Portfolio(inventory=initial[0], cash=initial[1]), min_quote_level=minq, max_quote_level=maxq,
         min_date=date, max_date=date, simulator=sim, market_order_clearing=moc, inc_prev_action_in_obs=inc_prev,
-        per_step_reward_function=get_reward_function(step_reward), terminal_reward_function=get_reward_function(terminal_reward),
+        per_step_reward_function=reward_from_spec(step_reward), terminal_reward_function=reward_from_spec(terminal_reward),
         concentration=concentration, market_order_fraction_of_inventory=mofi, enter_spread=enter_spread, n_levels=n_levels,
         info_calculator=SimpleInfoCalculator(market_order_fraction_of_inventory=mofi, enter_spread=enter_spread, concentration=concentration) if info else None,
     )  # fmt: skip
@@ -482,17 +496,18 @@ def main():
     # G0: the reference's own data file, kept as a test fixture (gzip for the wide orderbook file)
     msg = REF_DATA / "MSFT_2012-06-21_34200000_37800000_message_50.csv"
     book = REF_DATA / "MSFT_2012-06-21_34200000_37800000_orderbook_50.csv"
-    shutil.copyfile(msg, GOLD / "msft_message_50.csv")
-    with open(book, "rb") as f, gzip.GzipFile(GOLD / "msft_orderbook_50.csv.gz", "wb", mtime=0) as g:
-        g.write(f.read())
-
-    gen_beta_table()
-    gen_engine_cases()
+    if not ONLY:
+        shutil.copyfile(msg, GOLD / "msft_message_50.csv")
+        with open(book, "rb") as f, gzip.GzipFile(GOLD / "msft_orderbook_50.csv.gz", "wb", mtime=0) as g:
+            g.write(f.read())
+        gen_beta_table()
+        gen_engine_cases()
 
     date = datetime(2012, 6, 21)
     db_all = make_db(REF_DATA, "MSFT", date, 50, None, max_rows=1000, batch_size=1000)
-    gen_replay_msft(db_all)
-    gen_resync_msft(db_all)
+    if not ONLY:
+        gen_replay_msft(db_all)
+        gen_resync_msft(db_all)
 
     test_feats = lambda: [Inventory(), Spread(), PriceMove(lookback_periods=1), PriceRange(lookback_periods=1)]  # noqa: E731
     run_trajectory("msft_fixed", db_all, "MSFT", date, 50, test_feats(), fixed_agent([1, 2, 1, 2]), 2, [36001, 36001], 1.0, stream_file="msft")
@@ -513,7 +528,8 @@ def main():
         g = generate_lobster(20180221, 10, 200.0, 9.5 * 3600 + 1490, 9.5 * 3600 + 1490 + 420)  # 09:54:50 - 10:01:50
         mpath, bpath = write_lobster_csv(g, tmp, "SYN", "2018-02-21", 10)
         ps = pack_lobster(mpath, bpath, "SYN", "2018-02-21", 10, "S")
-        ps.save(GOLD / "synth_small.npz")
+        if not ONLY:
+            ps.save(GOLD / "synth_small.npz")
         print("synth_small", ps.n_msgs, "msgs", ps.n_snaps, "snaps")
         db_s = make_db(tmp, "SYN", sdate, 10, "S")
         default = lambda ep_s: HistoricalOrderbookEnvironment.get_default_features(timedelta(seconds=0.1), timedelta(seconds=ep_s))  # noqa: E731
@@ -535,6 +551,15 @@ def main():
         run_trajectory("synth_info_moc", db_s, "SYN", sdate, 10, short(), random_agent(9, high=40.0), 1, [35965], 15.0, step_reward="PnL", terminal_reward="PnL",
                        moc=True, mofi=1.0, concentration=12.0, initial=(0, 10**12), stream_file="synth_small", info=True)  # fmt: skip
         run_trajectory("synth_info_spread", db_s, "SYN", sdate, 10, short(), random_agent(10), 1, [35930], 12.0, enter_spread=True, stream_file="synth_small", info=True)
+        # RollingSharpe (RewardFunctions.py:38): the per-step window keeps filling across the two episodes (never reset by the env)
+        run_trajectory("synth_sharpe", db_s, "SYN", sdate, 10, short(), random_agent(31, high=20.0), 2, [35925, 35950], 10.0, step_reward="RS", terminal_reward="RS",
+                       enter_spread=True, initial=(25, 10**9), stream_file="synth_small")  # fmt: skip
+        # small windows so that both instances go through fill-up, full-window and wrap-around; terminal instance sees one AUM per episode
+        run_trajectory("synth_sharpe_small", db_s, "SYN", sdate, 10, short(), random_agent(32, high=20.0), 6, [35925, 35930, 35935, 35940, 35945, 35950], 2.5,
+                       step_reward=("RS", 16, 4), terminal_reward=("RS", 4, 3), enter_spread=True, initial=(-10, 10**9), stream_file="synth_small")  # fmt: skip
+        # AUM <= 0 once the window is long enough to be evaluated: get_sharpe raises
+        run_trajectory("synth_sharpe_crash", db_s, "SYN", sdate, 10, short(), fixed_agent([1, 1, 1, 1]), 1, [35925], 10.0, step_reward=("RS", 16, 5), terminal_reward="PnL",
+                       initial=(0, 0), stream_file="synth_small")  # fmt: skip
         run_trajectory("synth_q5_fixed", db_s, "SYN", sdate, 10, short(), fixed_agent([2, 5, 5, 2]), 1, [36010], 20.0, minq=2, maxq=7, stream_file="synth_small")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

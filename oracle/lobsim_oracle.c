@@ -128,6 +128,9 @@ typedef struct {
     int n_resyncs;
     double prev_action[LOBSIM_MAX_ACTION_DIM];
     int64_t cash_delta_dbg;
+    /* RollingSharpe state (RewardFunctions.py:50-59), [0] per-step instance, [1] terminal instance; never reset */
+    double rs_aum[2][LOBSIM_SHARPE_MAX_WINDOW];
+    int rs_filled[2];
 } Env;
 
 struct oracle {
@@ -277,6 +280,7 @@ typedef struct {
 } Ctx;
 
 static void process_order(Ctx* c, Order* o);
+static double np_pairwise_sum(const double* a, int n);
 static void submit_order(Ctx* c, Order* o);
 
 static int crosses(const Exchange* ex, const Order* o) { /* _does_order_cross_spread, Exchange.py:188-194 */
@@ -890,6 +894,33 @@ static void env_forward(oracle_t* h, Env* e, Order* internal, int n_internal) {
     if (!book_microprice(&e->ex.central, &e->price)) e->status |= LOBSIM_ST_EMPTY_BOOK;
 }
 
+/* get_sharpe (RewardFunctions.py:10-22) with numpy's summation order.  Returns 0 and sets *bad when min(aum) <= 0. */
+static double get_sharpe(const double* aum, int n, int* bad) {
+    double s[LOBSIM_SHARPE_MAX_WINDOW], x[LOBSIM_SHARPE_MAX_WINDOW];
+    for (int i = 0; i < n; i++) if (aum[i] <= 0) { *bad = 1; return 0.0; }
+    int m = n - 1;
+    for (int i = 0; i < m; i++) s[i] = exp(log(aum[i + 1]) - log(aum[i])) - 1;
+    double mean = np_pairwise_sum(s, m) / m;                    /* np.mean */
+    for (int i = 0; i < m; i++) { double d = s[i] - mean; x[i] = d * d; } /* np.std: mean again with the same sum */
+    double var = np_pairwise_sum(x, m) / (m - 1);
+    return mean / (sqrt(var) + 2.2250738585072014e-308);        /* + sys.float_info.min */
+}
+
+/* RollingSharpe.calculate (RewardFunctions.py:81-94) */
+static double rolling_sharpe(const lobsim_reward* r, Env* e, int role) {
+    int W = r->max_window;
+    double new_aum = (double)e->cash + e->price * (double)e->inventory; /* calculate_aum of next_state */
+    memmove(e->rs_aum[role], e->rs_aum[role] + 1, sizeof(double) * (size_t)(W - 1)); /* aum[0] = new; roll(-1) */
+    e->rs_aum[role][W - 1] = new_aum;
+    if (e->rs_filled[role] < W) e->rs_filled[role]++;
+    int n = e->rs_filled[role];
+    if (n < r->min_window) return 0.0;
+    int bad = 0;
+    double v = get_sharpe(e->rs_aum[role] + (W - n), n, &bad); /* the non-nan tail, oldest first */
+    if (bad) e->status |= LOBSIM_ST_ASSERT; /* raise Exception("AUM has gone non_positive") */
+    return v;
+}
+
 static double reward_calc(const lobsim_reward* r, int64_t inv0, int64_t cash0, double p0, int64_t inv1, int64_t cash1, double p1) {
     /* PnL.calculate, RewardFunctions.py:98-101 */
     double cur = (double)cash0 + (double)inv0 * p0;
@@ -915,9 +946,30 @@ static int64_t feature_window_us(const lobsim_feature* f) { return (int64_t)f->l
 /* ------------------------------------------------------------------------------------------------------------
  * public API (mirrors include/lobsim.h with an oracle_ prefix)
  * ---------------------------------------------------------------------------------------------------------- */
+/* test helper: feeds a sequence of (inventory=1, cash=0, price=aum[i]) states through RollingSharpe.calculate, the shape
+   of rl4mm/rewards/tests/testRewards.py:45-78.  raised[i] = 1 where the reference raises. */
+void oracle_rolling_sharpe(int max_window, int min_window, const double* aum, int n, double* out, int32_t* raised) {
+    Env* e = (Env*)calloc(1, sizeof(Env));
+    lobsim_reward r = {LOBSIM_R_ROLLING_SHARPE, 0, 0.0, max_window, min_window};
+    e->inventory = 1;
+    for (int i = 0; i < n; i++) {
+        e->price = aum[i];
+        e->status = 0;
+        out[i] = rolling_sharpe(&r, e, 0);
+        raised[i] = e->status != 0;
+    }
+    free(e);
+}
+
 int oracle_create(const lobsim_cfg* cfg, oracle_t** out) {
     if (!cfg || !out || cfg->n_envs <= 0 || cfg->n_features > LOBSIM_MAX_FEATURES) return LOBSIM_ERR_ARG;
     if (cfg->max_quote_level - cfg->min_quote_level > 128 || cfg->max_quote_level <= cfg->min_quote_level) return LOBSIM_ERR_ARG;
+    const lobsim_reward* rw[2] = {&cfg->per_step_reward, &cfg->terminal_reward};
+    for (int i = 0; i < 2; i++) {
+        if (rw[i]->kind < LOBSIM_R_PNL || rw[i]->kind > LOBSIM_R_ROLLING_SHARPE) return LOBSIM_ERR_ARG;
+        if (rw[i]->kind == LOBSIM_R_ROLLING_SHARPE && (rw[i]->min_window < 2 || rw[i]->max_window < rw[i]->min_window || rw[i]->max_window > LOBSIM_SHARPE_MAX_WINDOW))
+            return LOBSIM_ERR_ARG;
+    }
     oracle_t* h = (oracle_t*)calloc(1, sizeof(oracle_t));
     h->cfg = *cfg;
     h->env = (Env*)calloc((size_t)cfg->n_envs, sizeof(Env));
@@ -1019,10 +1071,12 @@ static void env_step(oracle_t* h, Env* e, const double* action, double* obs, dou
     for (int i = 0; i < cfg->action_dim; i++) e->prev_action[i] = action[i];
     if (e->status) { *done = 1; *reward = 0.0; if (obs) write_obs(h, e, obs, 1); return; }
     for (int f = 0; f < cfg->n_features; f++) feature_update(h, e, &e->feat[f]);
-    double r = reward_calc(&cfg->per_step_reward, inv0, cash0, p0, e->inventory, e->cash, e->price);
+    double r = cfg->per_step_reward.kind == LOBSIM_R_ROLLING_SHARPE ? rolling_sharpe(&cfg->per_step_reward, e, 0)
+                                                                  : reward_calc(&cfg->per_step_reward, inv0, cash0, p0, e->inventory, e->cash, e->price);
     int d = 0;
     if (2 * (e->terminal_us - e->now_us) < cfg->step_us) { /* terminal_time - now < step_size / 2 */
-        r = reward_calc(&cfg->terminal_reward, inv0, cash0, p0, e->inventory, e->cash, e->price);
+        r = cfg->terminal_reward.kind == LOBSIM_R_ROLLING_SHARPE ? rolling_sharpe(&cfg->terminal_reward, e, 1)
+                                                                 : reward_calc(&cfg->terminal_reward, inv0, cash0, p0, e->inventory, e->cash, e->price);
         d = 1;
     }
     if (e->status) d = 1;

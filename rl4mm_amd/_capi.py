@@ -21,7 +21,7 @@ ST_AGENT_OVERFLOW, ST_STREAM_END, ST_ASSERT, ST_NOT_RESET = 16, 32, 64, 128
 
 F_SPREAD, F_PRICE_MOVE, F_VOLATILITY, F_INVENTORY, F_EPISODE_PROPORTION, F_TIME_OF_DAY = 1, 2, 3, 4, 5, 6
 F_TRADE_DIRECTION_IMBALANCE, F_TRADE_VOLUME_IMBALANCE, F_BOOK_IMBALANCE, F_PRICE_RANGE, F_PRICE, F_AMIHUD_LAMBDA = 7, 8, 9, 10, 11, 12
-R_PNL, R_INVENTORY_ADJUSTED = 1, 2
+R_PNL, R_INVENTORY_ADJUSTED, R_ROLLING_SHARPE = 1, 2, 3
 POLICY_GIVEN, POLICY_FIXED, POLICY_TERADACTYL = 0, 1, 2
 
 
@@ -38,7 +38,8 @@ class FeatureDesc(C.Structure):
 
 
 class RewardDesc(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("asymmetrically_dampened", C.c_int32), ("inventory_aversion", C.c_double)]
+    _fields_ = [("kind", C.c_int32), ("asymmetrically_dampened", C.c_int32), ("inventory_aversion", C.c_double),
+                ("max_window", C.c_int32), ("min_window", C.c_int32)]
 
 
 class Cfg(C.Structure):
@@ -205,8 +206,12 @@ def make_cfg(
     if warmup_us is None:
         warmup_us = max([f.lookback * f.update_us for f in features] + [0])
     cfg.warmup_us = int(warmup_us)
-    cfg.per_step_reward = RewardDesc(*per_step_reward)
-    cfg.terminal_reward = RewardDesc(*terminal_reward)
+    def _rw(t):
+        t = tuple(t)
+        return RewardDesc(*(t + (120, 60)[len(t) - 3 :])) if len(t) < 5 else RewardDesc(*t)
+
+    cfg.per_step_reward = _rw(per_step_reward)
+    cfg.terminal_reward = _rw(terminal_reward)
     cfg.device_id = device_id
     return cfg
 

@@ -1027,6 +1027,66 @@ DI double reward_of(const lobsim_reward& r, int64_t inv0, int64_t cash0, double 
     return pnl - term;
 }
 
+// RollingSharpe.calculate + get_sharpe (RewardFunctions.py:10-22, :81-94).  `st` is this env's window for one role:
+// word 0 = n_filled | next << 32, then a ring of max_window AUM values (the reference rolls an array instead; the
+// values and their oldest-first order are the same).  Lanes take the log / exp of the window in parallel through the
+// (by now consumed) op list in LDS; mean and std follow numpy's pairwise summation order.  A non-positive AUM is the
+// reference's `raise Exception` -> LOBSIM_ST_ASSERT.  log/exp here are ocml's, the reference's are numpy's SIMD ones:
+// parity for this reward is to a tolerance, every other reward and feature is bit-exact.
+DI double rolling_sharpe(Lds& L, Scal& S, const lobsim_reward& r, double* st, int64_t cash, int64_t inv, double price) {
+    const int ln = lane();
+    const int W = r.max_window;
+    const int64_t word = uni64(((const int64_t*)st)[0]);
+    int filled = (int)(word & 0xffffffff), next = (int)(word >> 32);
+    double* ring = st + 1;
+    const double new_aum = (double)cash + price * (double)inv;  // calculate_aum(next_state)
+    if (ln == 0) ring[next] = new_aum;
+    next = next + 1 == W ? 0 : next + 1;
+    filled = filled + 1 < W ? filled + 1 : W;
+    if (ln == 0) ((int64_t*)st)[0] = (int64_t)filled | ((int64_t)next << 32);
+    if (filled < r.min_window) return 0.0;
+    double* scr = reinterpret_cast<double*>(L.ops);
+    static_assert(sizeof(L.ops) >= LOBSIM_SHARPE_MAX_WINDOW * sizeof(double), "op list doubles as the Sharpe scratch");
+    bool bad = false;
+    for (int k = ln; k < filled; k += WAVE) {
+        int idx = next - filled + k;
+        idx = idx < 0 ? idx + W : idx;
+        const double a = k == filled - 1 ? new_aum : ring[idx];  // the newest value was written by lane 0 just now
+        bad = bad || a <= 0;
+        scr[k] = log(a);
+    }
+    wsync();
+    if (__ballot(bad)) { S.status |= LOBSIM_ST_ASSERT; return 0.0; }
+    const int m = filled - 1;
+    double s0 = 0.0, s1 = 0.0;
+    if (ln < m) s0 = exp(scr[ln + 1] - scr[ln]) - 1;  // simple returns
+    if (ln + WAVE < m) s1 = exp(scr[ln + WAVE + 1] - scr[ln + WAVE]) - 1;
+    wsync();
+    if (ln < m) scr[ln] = s0;
+    if (ln + WAVE < m) scr[ln + WAVE] = s1;
+    wsync();
+    const double mean = np_pairwise_sum(scr, m) / (double)m;  // np.mean
+    wsync();
+    if (ln < m) scr[ln] = (s0 - mean) * (s0 - mean);  // np.std(ddof=1): sum((x - mean)^2) / (m - 1)
+    if (ln + WAVE < m) scr[ln + WAVE] = (s1 - mean) * (s1 - mean);
+    wsync();
+    const double var = np_pairwise_sum(scr, m) / (double)(m - 1);
+    wsync();
+    return mean / (sqrt(var) + 2.2250738585072014e-308);  // + sys.float_info.min
+}
+
+// per-step reward and, when the episode ends here, the terminal reward (HistoricalOrderbookEnvironment.py:169-176)
+// SHARPE selects the kernel variant that carries the RollingSharpe code: configurations without it (the default
+// rewards are PnL / inventory-adjusted PnL) run a variant whose register allocation does not pay for it.
+template <bool SHARPE>
+DI double step_reward(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, int env, bool terminal, int64_t inv0, int64_t cash0, double p0, double price) {
+    const lobsim_reward& r = terminal ? C.c.terminal_reward : C.c.per_step_reward;
+    if constexpr (SHARPE)
+        if (r.kind == LOBSIM_R_ROLLING_SHARPE)
+            return rolling_sharpe(L, S, r, P.sharpe + ((size_t)env * 2 + (terminal ? 1 : 0)) * (1 + LOBSIM_SHARPE_MAX_WINDOW), S.cash, S.inv, price);
+    return reward_of(r, inv0, cash0, p0, S.inv, S.cash, price);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // env state <-> LDS
 // ---------------------------------------------------------------------------------------------------------------
@@ -1172,6 +1232,7 @@ struct ResetArgs {
 #ifndef LOBSIM_STEP_WAVES
 #define LOBSIM_STEP_WAVES 4  // waves per SIMD the step kernel is register-budgeted for (4 = 16 envs per CU)
 #endif
+template <bool SHARPE>
 __global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg C, DevPtrs P, StepArgs A) {
     __shared__ Lds L;
     const int env = blockIdx.x, ln = lane();
@@ -1217,9 +1278,9 @@ __global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg 
             if (__ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
         }
         if (!S.status) {
-            reward = reward_of(C.c.per_step_reward, inv0, cash0, p0, S.inv, S.cash, price);
+            reward = step_reward<SHARPE>(L, S, C, P, env, false, inv0, cash0, p0, price);
             if (2 * (H.terminal_us - now) < C.c.step_us) {  // terminal_time - now < step_size / 2 (:172-174)
-                reward = reward_of(C.c.terminal_reward, inv0, cash0, p0, S.inv, S.cash, price);
+                reward = step_reward<SHARPE>(L, S, C, P, env, true, inv0, cash0, p0, price);
                 done = 1;
             }
         }
@@ -1292,6 +1353,7 @@ DI Act5 teradactyl_action(const double* p, double inventory) {
 // generate_trajectory (rl4mm/gym/utils.py:100-117) for open-loop / rule-based agents: up to T env.step()s per env in
 // one launch.  Every wave runs its env's steps back to back, so a launch no longer lasts as long as the busiest env of
 // EACH step, and the ladder / agent orders / feature scalars stay in LDS / registers between steps.
+template <bool SHARPE>
 __global__ __launch_bounds__(64, 3) void lob_rollout_kernel(DevCfg C, DevPtrs P, RolloutArgs A) {
     __shared__ Lds L;
     const int env = blockIdx.x, ln = lane();
@@ -1334,12 +1396,13 @@ __global__ __launch_bounds__(64, 3) void lob_rollout_kernel(DevCfg C, DevPtrs P,
             if (__ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
         }
         if (!S.status) {
-            reward = reward_of(C.c.per_step_reward, inv0, cash0, p0, S.inv, S.cash, price);
+            reward = step_reward<SHARPE>(L, S, C, P, env, false, inv0, cash0, p0, price);
             if (2 * (H.terminal_us - now) < C.c.step_us) {
-                reward = reward_of(C.c.terminal_reward, inv0, cash0, p0, S.inv, S.cash, price);
+                reward = step_reward<SHARPE>(L, S, C, P, env, true, inv0, cash0, p0, price);
                 done = 1;
             }
-        } else { done = 1; reward = 0.0; }
+        }
+        if (S.status) { done = 1; reward = 0.0; }
         ret += reward;
         steps++;
     }

@@ -114,6 +114,7 @@ struct DevPtrs {
     int64_t* rings;    // [env][ring_words]
     const StreamDev* streams;
     int32_t n_streams;
+    double* sharpe;    // [env][2][1 + LOBSIM_SHARPE_MAX_WINDOW] RollingSharpe windows (per-step / terminal), or null when unused
     uint64_t* prof;    // [env][8] phase cycle sums; only a -DLOBSIM_PROFILE diagnostic build allocates and writes it
 };
 

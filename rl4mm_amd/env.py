@@ -211,6 +211,16 @@ class InventoryAdjustedPnL(RewardFunction):  # :107
         return (_capi.R_INVENTORY_ADJUSTED, int(self.asymmetrically_dampened), float(self.inventory_aversion))
 
 
+class RollingSharpe(RewardFunction):  # RewardFunctions.py:38
+    def __init__(self, max_window_size: int = 120, min_window_size: int = 60):
+        assert max_window_size >= min_window_size, "Error with window sizes"
+        assert max_window_size <= 128, "the device path holds at most 128 AUM values per window"
+        self.max_window_size, self.min_window_size = max_window_size, min_window_size
+
+    def desc(self):
+        return (_capi.R_ROLLING_SHARPE, 0, 0.0, self.max_window_size, self.min_window_size)
+
+
 def get_reward_function(reward_function: str, inventory_aversion: float = 0.1) -> RewardFunction:  # rl4mm/gym/utils.py:29-39
     if reward_function == "AD":
         return InventoryAdjustedPnL(inventory_aversion=inventory_aversion, asymmetrically_dampened=True)
@@ -219,7 +229,7 @@ def get_reward_function(reward_function: str, inventory_aversion: float = 0.1) -
     if reward_function == "PnL":
         return PnL()
     if reward_function == "RS":
-        raise NotImplementedError("RollingSharpe (RewardFunctions.py:38-94) is not on the device path yet")
+        return RollingSharpe()
     raise NotImplementedError("You must specify one of 'AS', 'SD', 'PnL', or 'RS'")
 
 

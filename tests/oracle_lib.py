@@ -58,7 +58,13 @@ def oracle_peek_orders(sim, action, env=0, cap=1024) -> np.ndarray:
     return out[:n, :4]
 
 
-REWARDS = {"PnL": (_capi.R_PNL, 0, 0.0), "AD": (_capi.R_INVENTORY_ADJUSTED, 1, 0.1), "SD": (_capi.R_INVENTORY_ADJUSTED, 0, 0.1)}
+REWARDS = {"PnL": (_capi.R_PNL, 0, 0.0), "AD": (_capi.R_INVENTORY_ADJUSTED, 1, 0.1), "SD": (_capi.R_INVENTORY_ADJUSTED, 0, 0.1),
+           "RS": (_capi.R_ROLLING_SHARPE, 0, 0.0, 120, 60)}  # RollingSharpe() defaults, RewardFunctions.py:39
+
+
+def reward_desc(spec):
+    """Golden reward spec: a get_reward_function name, or ["RS", max_window, min_window]."""
+    return REWARDS[spec] if isinstance(spec, str) else (_capi.R_ROLLING_SHARPE, 0, 0.0, int(spec[1]), int(spec[2]))
 
 
 def cfg_from_golden(g: dict, n_envs: int = 1) -> _capi.Cfg:
@@ -71,7 +77,7 @@ def cfg_from_golden(g: dict, n_envs: int = 1) -> _capi.Cfg:
         max_quote_level=g["max_quote_level"], concentration=g["concentration"] if g["use_concentration"] else None,
         market_order_clearing=g["market_order_clearing"], market_order_fraction_of_inventory=g["market_order_fraction_of_inventory"],
         enter_spread=g["enter_spread"], inc_prev_action_in_obs=g["inc_prev_action_in_obs"],
-        per_step_reward=REWARDS[g["per_step_reward"]], terminal_reward=REWARDS[g["terminal_reward"]],
+        per_step_reward=reward_desc(g["per_step_reward"]), terminal_reward=reward_desc(g["terminal_reward"]),
     )  # fmt: skip
 
 

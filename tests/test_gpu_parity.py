@@ -54,6 +54,52 @@ def test_trajectory_matches_reference(name):
     sim.close()
 
 
+@pytest.mark.parametrize("name", ["synth_sharpe", "synth_sharpe_small", "synth_sharpe_crash"])
+def test_rolling_sharpe_trajectory(name):
+    """RollingSharpe (RewardFunctions.py:38-94) recorded from the reference.  State, fills and book are bit-exact; the
+    reward is compared at rtol 1e-6: the reference's exp/log are numpy's SIMD routines, the kernel's are ocml's."""
+    g, z = ol.load_traj(name)
+    sim = _lib.new_sim(ol.cfg_from_golden(g))
+    sid = sim.add_stream(ol.golden_stream(g["stream_file"]))
+    replay_and_check(sim, g, z, sid, obs_rtol=RTOL, obs_atol=ATOL, label=name, reward_rtol=1e-6)
+    if name == "synth_sharpe_crash":
+        assert sim.env_state(0)["status"] & _capi.ST_ASSERT
+    sim.close()
+
+
+def test_rolling_sharpe_batch_matches_oracle():
+    """256 envs x 150 steps with RollingSharpe rewards (window 32/8 per step, 120/60-default terminal), random actions,
+    rollout kernel and step kernel against the oracle: rewards within 1e-6 relative, state bit-exact."""
+    g, _ = ol.load_traj("synth_sharpe")
+    g = dict(g, per_step_reward=["RS", 32, 8], terminal_reward="RS")
+    n, T = 256, 150
+    cfg = ol.cfg_from_golden(g, n_envs=n)
+    ps = ol.golden_stream(g["stream_file"])
+    rng = np.random.default_rng(5)
+    starts = (35925 + rng.integers(0, 20, n)) * 10**6
+    actions = rng.uniform(0.5, 20.0, (T, n, g["action_dim"]))
+    outs = []
+    for make in (_lib.new_sim, ol.oracle_sim):
+        sim = make(cfg)
+        sid = sim.add_stream(ps)
+        sim.set_portfolio(np.full(n, 25, dtype=np.int64), np.full(n, 10**9, dtype=np.int64))
+        sim.reset(starts, np.full(n, sid, dtype=np.int32))
+        rew = np.zeros((T, n))
+        for t in range(T):
+            _, r, d = sim.step(actions[t])
+            rew[t] = r
+            if d.any():
+                idx = np.flatnonzero(d).astype(np.int32)
+                sim.reset(starts[idx], np.full(len(idx), sid, dtype=np.int32), env_ids=idx)
+        inv, cash, price = sim.portfolios()
+        outs.append((rew, inv.copy(), cash.copy(), price.copy()))
+        sim.close()
+    (r0, i0, c0, p0), (r1, i1, c1, p1) = outs
+    assert np.array_equal(i0, i1) and np.array_equal(c0, c1) and np.array_equal(p0, p1)
+    assert (r1 != 0).mean() > 0.5
+    assert np.allclose(r0, r1, rtol=1e-6, atol=1e-12), np.abs(r0 - r1).max()
+
+
 def test_beta_volumes_match_scipy_table():
     """G5 through the kernel: one env per action; after one step from an empty internal book the agent's resting
     volume at quote level k IS the Beta volume (levels whose volume rounds to 0 get no order)."""

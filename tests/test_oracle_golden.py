@@ -103,6 +103,40 @@ def test_trajectory_bit_exact(name):
     replay_and_check(sim, g, z, sid, check_fills=check_fills, label=name)
 
 
+SHARPE_RTOL = 1e-6  # RollingSharpe: np.exp/np.log (AVX-512 kernels in numpy) vs libm differ in the last ulp of ~1e-9-sized returns
+
+
+@pytest.mark.parametrize("name", ["synth_sharpe", "synth_sharpe_small", "synth_sharpe_crash"])
+def test_rolling_sharpe_trajectory(name):
+    """RewardFunctions.py:38-94 as per-step and terminal reward: windows filling, full and wrapping, persisting over
+    episodes; a non-positive AUM raises in the reference and flags the env here.  Everything but the reward value is
+    bit-exact; the reward is held to SHARPE_RTOL."""
+    g, z = ol.load_traj(name)
+    sim = ol.oracle_sim(ol.cfg_from_golden(g))
+    sid = sim.add_stream(ol.golden_stream(g["stream_file"]))
+    replay_and_check(sim, g, z, sid, label=name, reward_rtol=SHARPE_RTOL)
+    if name == "synth_sharpe_crash":
+        assert sim.env_state(0)["status"] & _capi.ST_ASSERT
+    else:
+        assert (z["reward"] != 0).sum() > 100
+
+
+def test_rolling_sharpe_known_answer_of_reference_test():
+    """rl4mm/rewards/tests/testRewards.py:45-78: AUM 100, 110, 100 with a 3-window -> 0, 0, 0.03367175 (7 places, the
+    reference's assertAlmostEqual); a zero AUM raises; a constant AUM gives 0."""
+    lib = ol.oracle_binding().lib
+    aum = np.array([100.0, 110.0, 100.0, 0.0])
+    out, raised = np.zeros(4), np.zeros(4, dtype=np.int32)
+    lib.oracle_rolling_sharpe(3, 3, aum.ctypes.data_as(C.POINTER(C.c_double)), 4, out.ctypes.data_as(C.POINTER(C.c_double)), raised.ctypes.data_as(C.POINTER(C.c_int32)))
+    assert out[0] == 0 and out[1] == 0 and round(out[2] - 0.03367175, 7) == 0
+    assert list(raised) == [0, 0, 0, 1]
+    rets = np.array([110 / 100, 100 / 110]) - 1
+    assert np.isclose(out[2], rets.mean() / rets.std(ddof=1), rtol=1e-12)
+    aum = np.full(3, 100.0)
+    lib.oracle_rolling_sharpe(3, 3, aum.ctypes.data_as(C.POINTER(C.c_double)), 3, out.ctypes.data_as(C.POINTER(C.c_double)), raised.ctypes.data_as(C.POINTER(C.c_int32)))
+    assert out[2] == 0 and not raised[:3].any()
+
+
 def test_known_answers_from_reference_tests():
     """Numbers the reference's own test-suite asserts: reset obs of the env test
     (rl4mm/gym/tests/testHistoricalOrderbookEnvironment.py:59-64) and the Beta(1,1)/Beta(1,2) volumes (:80-89)."""
