@@ -99,6 +99,9 @@ struct Scal {
     Mask<NA / 64> agent_free;
     Mask<NA / 64> agent_pending;  // entries freed during this step: not reused before the step ends
     Slot* slots;                  // this env's slabs
+#ifdef LOBSIM_PROFILE
+    uint64_t pm_cycles[8], pm_count[8];  // per message class (diagnostic build only)
+#endif
 };
 
 DI int lane() { return (int)threadIdx.x; }
@@ -153,6 +156,24 @@ DI int find_level(const Lds& L, const Scal& S, int side, int64_t price) {
     uint64_t b0 = __ballot(m0), b1 = __ballot(m1);
     if (b0) return ffs64(b0);
     if (b1) return 64 + ffs64(b1);
+    return -1;
+}
+
+// find_level + the level's packed meta word in one LDS round trip: each lane reads the price and the meta word of its
+// level together, the hit lane's meta is broadcast with readlane (no second, dependent ds_read)
+DI int find_level_meta(const Lds& L, const Scal& S, int side, int64_t price, uint64_t& meta) {
+    int n = S.n_lv[side], ln = lane();
+    int64_t p0 = L.price[side][ln];
+    uint64_t q0 = L.meta[side][ln];
+    uint64_t b0 = __ballot(ln < n && p0 == price);
+    if (b0) { int i = ffs64(b0); meta = (uint64_t)rl64((int64_t)q0, i); return i; }
+    if (n > 64) {
+        int64_t p1 = L.price[side][ln + 64];
+        uint64_t q1 = L.meta[side][ln + 64];
+        uint64_t b1 = __ballot(ln + 64 < n && p1 == price);
+        if (b1) { int i = ffs64(b1); meta = (uint64_t)rl64((int64_t)q1, i); return 64 + i; }
+    }
+    meta = 0;
     return -1;
 }
 
@@ -240,8 +261,7 @@ DI uint64_t compact_level(Lds& L, Scal& S, int side, int idx, uint64_t m) {
     return mk_meta(slab, 0, out, m_live(m));
 }
 
-DI void level_append(Lds& L, Scal& S, int side, int idx, int64_t id, int32_t vol, int32_t kind) {
-    uint64_t m = (uint64_t)uni64((int64_t)L.meta[side][idx]);
+DI void level_append(Lds& L, Scal& S, int side, int idx, int64_t id, int32_t vol, int32_t kind, uint64_t m) {
     if (m_tail(m) == SLOTS || m_tail(m) - m_head(m) - m_live(m) >= 64) {  // full, or a chunk's worth of tombstones
         m = compact_level(L, S, side, idx, m);
         if (m_tail(m) == SLOTS) { S.status |= LOBSIM_ST_QUEUE_OVERFLOW; return; }
@@ -252,7 +272,7 @@ DI void level_append(Lds& L, Scal& S, int side, int idx, int64_t id, int32_t vol
         S.slots[(size_t)m_slab(m) * SLOTS + tail] = s;
         if (kind == K_AGENT) L.apos[id] = (uint16_t)tail;
         L.meta[side][idx] = mk_meta(m_slab(m), live == 0 ? tail : m_head(m), tail + 1, live + 1);
-        L.vol[side][idx] += vol;
+        atomicAdd(&L.vol[side][idx], vol);  // ds_add, no read-modify-write round trip
     }
     wsync();
 }
@@ -282,7 +302,7 @@ DI void reduce_slot(Lds& L, Scal& S, int side, int idx, uint64_t m, int pos, int
     // heads are advanced lazily: `head` is only a lower bound of the first live slot (every reader skips
     // tombstones), so removing the head order costs no dependent re-scan of the slab
     const int new_head = (gone && pos == head) ? head + 1 : head;
-    if (ln == 0) { L.meta[side][idx] = mk_meta(m_slab(m), new_head, tail, live); L.vol[side][idx] -= rv; }
+    if (ln == 0) { L.meta[side][idx] = mk_meta(m_slab(m), new_head, tail, live); atomicAdd(&L.vol[side][idx], -rv); }
     wsync();
 }
 
@@ -290,10 +310,10 @@ DI void reduce_slot(Lds& L, Scal& S, int side, int idx, uint64_t m, int pos, int
 // (K_EXT, external id) for historical messages, (K_AGENT, agent index) for the agent's own cancellations.
 // vol < 0 means "Deletion without volume".
 DI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, int64_t id, int32_t vol) {
-    int idx = find_level(L, S, side, price);
+    uint64_t m;
+    int idx = find_level_meta(L, S, side, price, m);
     if (idx < 0) return;  // warn + KeyError -> continue
     int ln = lane();
-    uint64_t m = (uint64_t)uni64((int64_t)L.meta[side][idx]);
     int head = m_head(m), tail = m_tail(m);
     const Slot* sl = S.slots + (size_t)m_slab(m) * SLOTS;
     int pos = -1;
@@ -396,7 +416,7 @@ DI int32_t execute(Lds& L, Scal& S, int side, bool is_agent, bool is_market, int
         int live_left = m_live(m) - n_removed;
         wsync();
         if (live_left == 0) { ladder_remove(L, S, opp, 0); continue; }
-        if (ln == 0) { L.meta[opp][0] = mk_meta(m_slab(m), first_survivor, tail, live_left); L.vol[opp][0] -= E + deleted_agent_vol; }
+        if (ln == 0) { L.meta[opp][0] = mk_meta(m_slab(m), first_survivor, tail, live_left); atomicAdd(&L.vol[opp][0], -(E + deleted_agent_vol)); }
         wsync();
         if (S.status) break;
     }
@@ -406,16 +426,19 @@ DI int32_t execute(Lds& L, Scal& S, int side, bool is_agent, bool is_market, int
 // submit_order (Exchange.py:71-83): cross -> execute, remainder rests at the back of its level's queue
 DI void submit_limit(Lds& L, Scal& S, int side, int64_t price, int32_t vol, bool is_agent, int64_t ext_id) {
     const int opp = side ^ 1;
-    bool cross = false;
-    if (S.n_lv[opp] > 0) { int64_t bp = uni64(L.price[opp][0]); cross = side == LOBSIM_BUY ? price >= bp : price <= bp; }
+    // one LDS round trip serves both questions: does it cross (best opposite price), and where does it rest
+    const int64_t bp = uni64(L.price[opp][0]);
+    uint64_t m;
+    int idx = find_level_meta(L, S, side, price, m);
+    const bool cross = S.n_lv[opp] > 0 && (side == LOBSIM_BUY ? price >= bp : price <= bp);
     if (cross) {
         vol = execute(L, S, side, is_agent, false, price, vol);
         if (S.status || vol <= 0) return;
     }
-    int idx = find_level(L, S, side, price);
     if (idx < 0) {
         idx = insert_pos(L, S, side, price);
         if (!ladder_insert(L, S, side, idx, price)) return;
+        m = (uint64_t)uni64((int64_t)L.meta[side][idx]);
     }
     int64_t id = ext_id;
     if (is_agent) {
@@ -425,7 +448,7 @@ DI void submit_limit(Lds& L, Scal& S, int side, int64_t price, int32_t vol, bool
         S.agent_seq++;
         id = a;
     }
-    level_append(L, S, side, idx, id, vol, is_agent ? K_AGENT : K_EXT);
+    level_append(L, S, side, idx, id, vol, is_agent ? K_AGENT : K_EXT, m);
 }
 
 // process_order (Exchange.py:58-69) for one historical message
@@ -824,27 +847,62 @@ DI void resync_outer_levels(Lds& L, Scal& S, const DevCfg& C, const StreamDev& s
     if ((double)ws > R.max_sell) R.max_sell = (double)ws;
 }
 
-// the window (now, until] of historical messages, in stream order (OrderbookSimulator.py:70-85)
-DI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, int64_t until_us) {
-    int ln = lane();
+// One batch of the message stream: lane ln holds message cursor + ln (t = INT64_MAX past the end of the stream).
+struct MsgBatch { int64_t t, eid, price, meta; };
+typedef long long ll2_t __attribute__((ext_vector_type(2)));
+typedef const ll2_t __attribute__((address_space(1)))* GlobalI64x2;  // global (not flat) loads of the packed stream
+
+DI MsgBatch fetch_messages(const StreamDev& st, int64_t cursor) {
+    MsgBatch b = {INT64_MAX, 0, 0, 0};
+    const int64_t i = cursor + lane();
+    if (i < st.n_msgs) {
+        GlobalI64x2 m = (GlobalI64x2)(st.msgs + i * LOBSIM_MSG_WORDS);
+        ll2_t a = m[0], c = m[1];  // 2 x dwordx4, 32 contiguous bytes per lane
+        b.t = a.x; b.eid = a.y; b.price = c.x; b.meta = c.y;
+    }
+    return b;
+}
+
+// the window (now, until] of historical messages, in stream order (OrderbookSimulator.py:70-85).  `b` is the batch
+// at `cursor`, requested by the caller as early as it knew the cursor (the step kernel asks for it before it builds
+// the agent's orders, so the stream's HBM latency hides behind that work).
+DI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, int64_t until_us, MsgBatch b) {
     while (!S.status) {
-        int64_t i = cursor + ln;
-        int64_t t = 0, eid = 0, price = 0, meta = 0;
-        bool in = false;
-        if (i < st.n_msgs) {
-            const I64x2* m = reinterpret_cast<const I64x2*>(st.msgs + i * LOBSIM_MSG_WORDS);
-            I64x2 a = m[0], b = m[1];  // 2 x dwordx4, 32 contiguous bytes per lane
-            t = a.x; eid = a.y; price = b.x; meta = b.y;
-            in = t <= until_us;
-        }
-        uint64_t bm = __ballot(in);
+        uint64_t bm = __ballot(b.t <= until_us);
         int cnt = popc64(bm);  // the stream is time-sorted: the in-window lanes are a prefix
         for (int j = 0; j < cnt && !S.status; j++) {
-            int64_t mm = rl64(meta, j);
-            process_message(L, S, (int)((mm >> LOBSIM_TYPE_SHIFT) & 0xf), (int)((mm >> LOBSIM_SIDE_SHIFT) & 1), rl64(price, j), mm & LOBSIM_VOL_MASK, rl64(eid, j));
+            int64_t mm = rl64(b.meta, j);
+#ifdef LOBSIM_PROFILE
+            // classes: 0 limit at an existing level, 1 limit opening a level, 2 crossing limit, 3 cancel, 4 delete,
+            // 5 delete/cancel that empties its level, 6 market, 7 other
+            const int ty = (int)((mm >> LOBSIM_TYPE_SHIFT) & 0xf), sd = (int)((mm >> LOBSIM_SIDE_SHIFT) & 1);
+            const int nl0 = S.n_lv[0] + S.n_lv[1];
+            bool crossing = false;
+            if (ty == LOBSIM_LIMIT && S.n_lv[sd ^ 1] > 0) { int64_t bp = uni64(L.price[sd ^ 1][0]); crossing = sd == LOBSIM_BUY ? rl64(b.price, j) >= bp : rl64(b.price, j) <= bp; }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
+            const uint64_t t0 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            process_message(L, S, (int)((mm >> LOBSIM_TYPE_SHIFT) & 0xf), (int)((mm >> LOBSIM_SIDE_SHIFT) & 1), rl64(b.price, j), mm & LOBSIM_VOL_MASK, rl64(b.eid, j));
+#ifdef LOBSIM_PROFILE
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
+            const uint64_t t1 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
+            const int nl1 = S.n_lv[0] + S.n_lv[1];
+            int cls = 7;
+            if (ty == LOBSIM_LIMIT) cls = crossing ? 2 : (nl1 > nl0 ? 1 : 0);
+            else if (ty == LOBSIM_CANCELLATION || ty == LOBSIM_DELETION) cls = nl1 < nl0 ? 5 : (ty == LOBSIM_CANCELLATION ? 3 : 4);
+            else if (ty == LOBSIM_MARKET) cls = 6;
+            S.pm_cycles[cls] += t1 - t0;
+            S.pm_count[cls] += 1;
+#endif
         }
         cursor += cnt;
         if (cnt < 64) break;
+        b = fetch_messages(st, cursor);
     }
 }
 
@@ -1177,10 +1235,10 @@ DI void run_agent_ops(Lds& L, Scal& S, const DevCfg& C) {
 // OrderbookSimulator.forward_step (:70-88) + update_internal_state (HistoricalOrderbookEnvironment.py:199-204):
 // agent ops first, then the message window, clock, resync check, new price.
 DI void advance_one_step(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, int stream_id, int64_t& cursor, int64_t& now_us,
-                         Ranges& R, int& n_resyncs, double& price, bool with_ops) {
+                         Ranges& R, int& n_resyncs, double& price, bool with_ops, const MsgBatch& first) {
     if (with_ops) run_agent_ops(L, S, C);
     int64_t until = now_us + C.c.step_us;
-    if (stream_id >= 0 && !S.status) replay_messages(L, S, P.streams[stream_id], cursor, until);
+    if (stream_id >= 0 && !S.status) replay_messages(L, S, P.streams[stream_id], cursor, until, first);
     now_us = until;
     if (S.status) return;
     if (stream_id >= 0 && now_us % 1000000 == 0) {
@@ -1244,6 +1302,9 @@ __global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg 
 #endif
     STAMP(0);
     Scal S;
+#ifdef LOBSIM_PROFILE
+    for (int k = 0; k < 8; k++) { S.pm_cycles[k] = 0; S.pm_count[k] = 0; }
+#endif
     load_env(L, S, P, env, H);
     STAMP(1);
     const double* ap = A.actions + (size_t)env * AD;
@@ -1252,6 +1313,8 @@ __global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg 
     act.v2 = AD > 2 ? ap[2] : 0.0; act.v3 = AD > 3 ? ap[3] : 0.0; act.v4 = AD > 4 ? ap[4] : 0.0;
     int64_t now = H.now_us, cursor = H.msg_cursor;
     int stream_id = H.stream_id;
+    MsgBatch first = {INT64_MAX, 0, 0, 0};
+    if (stream_id >= 0) first = fetch_messages(P.streams[stream_id], cursor);  // in flight while the agent's orders are built
     Ranges R = {H.min_buy, H.max_sell, H.init_buy_range, H.init_sell_range};
     int n_resyncs = H.n_resyncs;
     double price = H.price, reward = 0.0;
@@ -1265,9 +1328,9 @@ __global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg 
 #ifdef LOBSIM_PROFILE
         if (!S.status) run_agent_ops(L, S, C);
         STAMP(3);
-        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, false);
+        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, false, first);
 #else
-        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true);
+        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true, first);
 #endif
         STAMP(4);
         if (ln < F) fs = P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln];  // loaded late: not live across the order loops
@@ -1309,6 +1372,8 @@ __global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg 
         for (int k = 0; k < 6; k++) P.prof[(size_t)env * 8 + k] += prof_t[k + 1] - prof_t[k];
         P.prof[(size_t)env * 8 + 6] += S.n_ops;
         P.prof[(size_t)env * 8 + 7] += 1;
+        uint64_t* pm = P.prof + (size_t)gridDim.x * 8 + (size_t)env * 16;
+        for (int k = 0; k < 8; k++) { pm[k] += S.pm_cycles[k]; pm[8 + k] += S.pm_count[k]; }
     }
 #endif
 }
@@ -1387,8 +1452,10 @@ __global__ __launch_bounds__(64, 3) void lob_rollout_kernel(DevCfg C, DevPtrs P,
         const int64_t inv0 = S.inv, cash0 = S.cash;
         const double p0 = price;
         reward = 0.0;
+        MsgBatch first = {INT64_MAX, 0, 0, 0};
+        if (stream_id >= 0) first = fetch_messages(P.streams[stream_id], cursor);
         build_agent_ops(L, S, C, act);
-        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true);
+        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true, first);
         if (!S.status) {
             StepView v = make_view(L, S, price, now);
             bool ok = true;
@@ -1476,7 +1543,7 @@ __global__ __launch_bounds__(64, 4) void lob_reset_kernel(DevCfg C, DevPtrs P, R
     const int64_t n_warm = C.c.warmup_us / C.c.step_us;
     for (int64_t s = 0; s < n_warm && !S.status; s++) {
         clear_step_fills(S);
-        advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, false);
+        advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, false, fetch_messages(st, cursor));
         if (S.status) break;
         StepView v = make_view(L, S, price, now);
         bool ok = true;

@@ -1,0 +1,66 @@
+"""Diagnostic: what makes the slowest wave of each launch slow?  (-DLOBSIM_PROFILE build, s_memtime stamps.)
+A launch lasts as long as its busiest env, so the step rate is set by the per-launch MAX over envs, not the mean."""
+import ctypes as C, subprocess, sys
+from pathlib import Path
+import numpy as np, torch
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import bench
+from rl4mm_amd import _capi, _lib
+
+so = ROOT / "gpurun_out" / "liblobsim_prof.so"
+so.parent.mkdir(exist_ok=True)
+subprocess.check_call(["hipcc", *_lib.HIPCC_FLAGS, "-DLOBSIM_PROFILE", "-o", str(so), str(_lib.SOURCES[0])])
+b = _capi.Binding(so)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+K = 120
+cfg = _capi.make_cfg(N, 10, bench.default_features(_capi), step_us=100_000, episode_us=1_800_000_000)
+sim = _capi.Sim(b, cfg)
+ps = bench.build_stream(60)
+sim.add_stream(ps); sim.set_portfolio(0, 10**12)
+starts = (36_000 + np.random.default_rng(1).integers(0, 60, size=N)) * 1_000_000
+sim.reset(starts, 0)
+dev = torch.device("cuda", 0)
+acts = torch.from_numpy(np.random.default_rng(2).uniform(0, 10, size=(K, N, 4))).to(dev)
+obs = torch.zeros((N, sim.obs_dim), dtype=torch.float64, device=dev)
+reward = torch.zeros(N, dtype=torch.float64, device=dev); done = torch.zeros(N, dtype=torch.uint8, device=dev)
+out = np.zeros((N, 8), dtype=np.uint64)
+b.lib.lobsim_prof_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+tus = ps.msgs[:, 0]
+names = ["load_env", "build_ops", "agent_ops", "messages+resync", "features+reward", "outputs+store"]
+rows = []
+for t in range(K):
+    sim.step_device(acts[t].data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr(), 0)
+    b.lib.lobsim_prof_read(sim.h, out.ctypes.data, 1)
+    if t < 20: continue
+    ph = out[:, :6].astype(np.float64)
+    tot = ph.sum(axis=1)
+    lo, hi = starts + t * 100_000, starts + (t + 1) * 100_000
+    nmsg = np.searchsorted(tus, hi, side="right") - np.searchsorted(tus, lo, side="right")
+    sec_cross = (hi // 1_000_000) != (lo // 1_000_000)
+    order = np.argsort(tot)
+    i = order[-1]
+    rows.append(dict(max=tot[i], mean=tot.mean(), p50=np.median(tot), p99=np.percentile(tot, 99), p999=np.percentile(tot, 99.9), ph_max=ph[i], ph_mean=ph.mean(axis=0), n_max=nmsg[i], n_mean=nmsg.mean(), n_top=nmsg.max(),
+                     cpm=ph[:, 3] / np.maximum(nmsg, 1), nmsg=nmsg.copy(), msgc=ph[:, 3].copy(), tot=tot.copy(), sec=sec_cross.copy(), ops=out[:, 6].astype(float)))
+A = lambda k: np.array([r[k] for r in rows])
+print(f"{N} envs, {len(rows)} launches: wave cycles  mean {A('mean').mean():.0f}  p50 {A('p50').mean():.0f}  p99 {A('p99').mean():.0f}  p99.9 {A('p999').mean():.0f}  MAX {A('max').mean():.0f}")
+print(f"messages in the slowest env {A('n_max').mean():.1f} (mean env {A('n_mean').mean():.1f}, busiest env {A('n_top').mean():.1f})")
+pm, pa = np.array([r['ph_max'] for r in rows]).mean(axis=0), np.array([r['ph_mean'] for r in rows]).mean(axis=0)
+for k, n in enumerate(names): print(f"  {n:18s} slowest env {pm[k]:8.0f}   mean env {pa[k]:8.0f}")
+nm, mc, tt, sc, ops = np.concatenate(A('nmsg')), np.concatenate(A('msgc')), np.concatenate(A('tot')), np.concatenate(A('sec')), np.concatenate(A('ops'))
+fit = np.polyfit(nm, mc, 1)
+print(f"message phase cycles ~ {fit[0]:.0f} * n_msgs + {fit[1]:.0f};  residual std {np.std(mc - np.polyval(fit, nm)):.0f}")
+res = mc - np.polyval(fit, nm)
+print(f"message-phase residual percentiles 50/99/99.9/max: {np.percentile(res, [50, 99, 99.9, 100]).round(0).tolist()}")
+print(f"second-boundary steps: share {sc.mean():.3f}; mean total cycles with {tt[sc].mean():.0f} / without {tt[~sc].mean():.0f}")
+other = tt - mc
+fo = np.polyfit(ops, other, 1)
+print(f"non-message cycles ~ {fo[0]:.0f} * agent_ops + {fo[1]:.0f}; percentiles 50/99/max {np.percentile(other, [50, 99, 100]).round(0).tolist()}; agent ops mean {ops.mean():.1f} max {ops.max():.0f}")
+pmsg = np.zeros((N, 16), dtype=np.uint64)
+b.lib.lobsim_prof_read_messages.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+b.lib.lobsim_prof_read_messages(sim.h, pmsg.ctypes.data, 0)
+cls = ["limit, level exists", "limit, opens level", "limit, crossing", "cancel", "delete", "delete/cancel emptying level", "market", "other"]
+cyc, cnt = pmsg[:, :8].sum(axis=0).astype(float), pmsg[:, 8:].sum(axis=0).astype(float)
+print("per message class (stamps drain the memory queue before and after: upper bounds):")
+for k, n in enumerate(cls):
+    if cnt[k]: print(f"  {n:30s} share {100 * cnt[k] / cnt.sum():5.1f} %   {cyc[k] / cnt[k]:7.0f} cycles each   {100 * cyc[k] / cyc.sum():5.1f} % of message time")
