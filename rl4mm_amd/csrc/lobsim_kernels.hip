@@ -47,6 +47,16 @@ struct Lds {
     double pdf[2][QMAX];
     uint16_t apos[NA];             // slot index of each live agent order inside its level's slab
     unsigned long long freed[NA / 64];  // agent entries freed by the lane-parallel cancel pass (OR-ed by lanes)
+    // Wave-uniform state that is touched rarely (a level opens or empties, the agent trades, an execution is counted).
+    // It lives here and not in scalar registers: the replay loop would otherwise carry ~35 SGPRs through every one of
+    // its merge points (copies and spills on the scalar unit, which is what bounds this kernel at 16 waves per CU).
+    // Lane 0 writes, everyone reads after a wavefront fence (LDS is in order within a wave).
+    unsigned long long slab_free[NSLAB / 64];
+    unsigned long long agent_free[NA / 64];
+    unsigned long long agent_pending[NA / 64];  // entries freed during this step: not reused before the step ends
+    long long inv, cash;
+    int32_t ag_cnt, ag_vol[2], ext_cnt[2], ext_vol[2];  // fills of the current step
+    uint32_t agent_seq;
 };
 
 DI uint64_t mk_meta(int slab, int head, int tail, int live) {
@@ -67,38 +77,12 @@ struct Pair {  // two wave-uniform values selected by side; kept as two register
     DI void set(int i, T v) { a = i ? a : v; b = i ? v : b; }
     DI void add(int i, T v) { a += i ? T(0) : v; b += i ? v : T(0); }
 };
-template <int N>
-struct Mask {  // N x 64-bit mask with uniform bit access through unrolled selects
-    uint64_t w[N];
-    DI void fill(uint64_t v) {
-#pragma unroll
-        for (int i = 0; i < N; i++) w[i] = v;
-    }
-    DI void set(int bit) {
-#pragma unroll
-        for (int i = 0; i < N; i++) w[i] |= (bit >> 6) == i ? 1ull << (bit & 63) : 0ull;  // unconditional: no w[bit >> 6]
-    }
-    DI int take_first() {  // clears and returns the lowest set bit, -1 if empty
-        int r = -1;
-#pragma unroll
-        for (int i = 0; i < N; i++)
-            if (r < 0 && w[i]) { int b = __ffsll((unsigned long long)w[i]) - 1; w[i] &= ~(1ull << b); r = i * 64 + b; }
-        return r;
-    }
-};
 struct Scal {
     Pair<int32_t> n_lv;
     int32_t status;
     int32_t n_ops;
-    int64_t inv, cash;
-    int32_t ag_cnt;  // fills of the current step
-    Pair<int32_t> ag_vol, ext_cnt, ext_vol;
-    uint32_t agent_seq;
     int64_t q_buy, q_sell;  // best prices the current op list was built against (_get_best_prices)
-    Mask<NSLAB / 64> slab_free;
-    Mask<NA / 64> agent_free;
-    Mask<NA / 64> agent_pending;  // entries freed during this step: not reused before the step ends
-    Slot* slots;                  // this env's slabs
+    Slot* slots;            // this env's slabs
 #ifdef LOBSIM_PROFILE
     uint64_t pm_cycles[8], pm_count[8];  // per message class (diagnostic build only)
 #endif
@@ -146,6 +130,31 @@ DI int popc64(uint64_t m) { return __popcll(m); }
 DI int ffs64(uint64_t m) { return __ffsll((unsigned long long)m) - 1; }     // lowest set bit, -1 if none
 DI int fls64(uint64_t m) { return m ? 63 - __clzll((long long)m) : -1; }   // highest set bit
 
+// bit masks kept in LDS (see Lds): uniform reads, lane 0 writes
+DI uint64_t lds_u64(const unsigned long long& w) { return (uint64_t)uni64((int64_t)w); }
+template <int N>
+DI int mask_take_first(unsigned long long (&w)[N]) {
+    int r = -1;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        if (r >= 0) break;
+        const uint64_t v = lds_u64(w[i]);
+        if (v) { r = i * 64 + ffs64(v); if (lane() == 0) w[i] = v & (v - 1); }
+    }
+    wsync();
+    return r;
+}
+DI void mask_set(unsigned long long* w, int bit) {
+    if (lane() == 0) w[bit >> 6] |= 1ull << (bit & 63);
+}
+// portfolio and per-step fill counters (in LDS, see Lds)
+DI int64_t cur_inv(const Lds& L) { return uni64(L.inv); }
+DI int64_t cur_cash(const Lds& L) { return uni64(L.cash); }
+DI void trade(Lds& L, int64_t dinv, int64_t dcash) {
+    if (lane() == 0) { L.inv += dinv; L.cash += dcash; }
+}
+
+
 // ---------------------------------------------------------------------------------------------------------------
 // price ladder (LDS): sorted best first; SortedDict of rl4mm/orderbook/models.py:64-69
 // ---------------------------------------------------------------------------------------------------------------
@@ -188,7 +197,7 @@ DI int insert_pos(const Lds& L, const Scal& S, int side, int64_t price) {
 DI bool ladder_insert(Lds& L, Scal& S, int side, int pos, int64_t price) {
     int n = S.n_lv[side], ln = lane();
     if (n >= LV) { S.status |= LOBSIM_ST_LEVEL_OVERFLOW; return false; }
-    int slab = S.slab_free.take_first();
+    int slab = mask_take_first(L.slab_free);
     int64_t p[2]; uint64_t m[2]; int32_t v[2]; bool take[2];
 #pragma unroll
     for (int r = 0; r < 2; r++) {
@@ -210,7 +219,7 @@ DI bool ladder_insert(Lds& L, Scal& S, int side, int pos, int64_t price) {
 
 DI void ladder_remove(Lds& L, Scal& S, int side, int pos) {
     int n = S.n_lv[side], ln = lane();
-    S.slab_free.set(m_slab((uint64_t)uni64((int64_t)L.meta[side][pos])));
+    mask_set(L.slab_free, m_slab((uint64_t)uni64((int64_t)L.meta[side][pos])));
     int64_t p[2]; uint64_t m[2]; int32_t v[2]; bool take[2];
 #pragma unroll
     for (int r = 0; r < 2; r++) {
@@ -277,8 +286,8 @@ DI void level_append(Lds& L, Scal& S, int side, int idx, int64_t id, int32_t vol
     wsync();
 }
 
-DI int alloc_agent(Scal& S) {
-    int a = S.agent_free.take_first();
+DI int alloc_agent(Lds& L, Scal& S) {
+    int a = mask_take_first(L.agent_free);
     if (a < 0) S.status |= LOBSIM_ST_AGENT_OVERFLOW;
     return a;
 }
@@ -296,7 +305,7 @@ DI void reduce_slot(Lds& L, Scal& S, int side, int idx, uint64_t m, int pos, int
         sl[pos] = w;
         if (pk == K_AGENT) L.agent[pid].vol = nv;
     }
-    if (gone && pk == K_AGENT) S.agent_pending.set((int)pid);
+    if (gone && pk == K_AGENT) mask_set(L.agent_pending, (int)pid);
     int live = m_live(m) - (gone ? 1 : 0);
     if (gone && live == 0) { wsync(); ladder_remove(L, S, side, idx); return; }
     // heads are advanced lazily: `head` is only a lower bound of the first live slot (every reader skips
@@ -385,7 +394,7 @@ DI int32_t execute(Lds& L, Scal& S, int side, bool is_agent, bool is_market, int
                 while (gone_agent) {  // freed agent entries (uniform bookkeeping): ids live in lanes, gather them
                     int b = ffs64(gone_agent);
                     gone_agent &= gone_agent - 1;
-                    S.agent_pending.set((int)rl64(s.id, b));
+                    mask_set(L.agent_pending, (int)rl64(s.id, b));
                 }
                 n_agent += popc64(__ballot(reached && is_ag && !own));
                 exec_agent += wave_sum((reached && is_ag && !own) ? ex : 0);
@@ -402,16 +411,16 @@ DI int32_t execute(Lds& L, Scal& S, int side, bool is_agent, bool is_market, int
         int32_t exec_ext = E - exec_agent;
         rem -= E;
         // fills: resting side = opp (Q10: external fills are counted by the resting order's direction)
-        S.ext_cnt.add(opp, n_ext); S.ext_vol.add(opp, exec_ext);
+        if (ln == 0) { L.ext_cnt[opp] += n_ext; L.ext_vol[opp] += exec_ext; }
         if (n_agent) {  // an external aggressor hit resting agent orders (executed_internal_orders, :107-109)
-            S.ag_cnt += n_agent; S.ag_vol.add(opp, exec_agent);
-            if (opp == LOBSIM_SELL) { S.inv -= exec_agent; S.cash += (int64_t)exec_agent * bp; }
-            else { S.inv += exec_agent; S.cash -= (int64_t)exec_agent * bp; }
+            if (ln == 0) { L.ag_cnt += n_agent; L.ag_vol[opp] += exec_agent; }
+            if (opp == LOBSIM_SELL) trade(L, -(int64_t)exec_agent, (int64_t)exec_agent * bp);
+            else trade(L, exec_agent, -(int64_t)exec_agent * bp);
         }
         if (is_agent) {  // the agent's own aggressing fills, one MarketOrder copy per resting fill (:110-115)
-            S.ag_cnt += n_ext; S.ag_vol.add(side, exec_ext);
-            if (side == LOBSIM_SELL) { S.inv -= exec_ext; S.cash += (int64_t)exec_ext * bp; }
-            else { S.inv += exec_ext; S.cash -= (int64_t)exec_ext * bp; }
+            if (ln == 0) { L.ag_cnt += n_ext; L.ag_vol[side] += exec_ext; }
+            if (side == LOBSIM_SELL) trade(L, -(int64_t)exec_ext, (int64_t)exec_ext * bp);
+            else trade(L, exec_ext, -(int64_t)exec_ext * bp);
         }
         int live_left = m_live(m) - n_removed;
         wsync();
@@ -442,10 +451,9 @@ DI void submit_limit(Lds& L, Scal& S, int side, int64_t price, int32_t vol, bool
     }
     int64_t id = ext_id;
     if (is_agent) {
-        int a = alloc_agent(S);
+        int a = alloc_agent(L, S);
         if (a < 0) return;
-        if (lane() == 0) { AgentOrd o; o.price = price; o.vol = vol; o.seq_side = (S.agent_seq & 0x7fffffffu) | ((uint32_t)side << 31); L.agent[a] = o; }
-        S.agent_seq++;
+        if (lane() == 0) { AgentOrd o; o.price = price; o.vol = vol; o.seq_side = (L.agent_seq & 0x7fffffffu) | ((uint32_t)side << 31); L.agent[a] = o; L.agent_seq++; }
         id = a;
     }
     level_append(L, S, side, idx, id, vol, is_agent ? K_AGENT : K_EXT, m);
@@ -535,7 +543,8 @@ DI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action) {
         double s = np_pairwise_sum(L.pdf[my_side], Q);
         desired = (int32_t)rint(L.pdf[my_side][my_k] / s * 100.0);  // np.round(dist * active_volume).astype(int)
     }
-    int64_t abs_inv = S.inv < 0 ? -S.inv : S.inv;
+    const int64_t inv = cur_inv(L);
+    int64_t abs_inv = inv < 0 ? -inv : inv;
     bool clearing = c.market_order_clearing && (double)abs_inv > act_at(action, c.action_dim - 1);
     if (clearing) desired = 0;
     // ---- _get_best_prices (:298-322)
@@ -627,7 +636,7 @@ DI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action) {
     S.n_ops = base;
     if (clearing) {  // _get_inventory_clearing_market_order (:260-266)
         double v = rint((double)abs_inv * c.market_order_fraction_of_inventory);
-        push_op(L, S, LOBSIM_MARKET, S.inv < 0 ? LOBSIM_BUY : LOBSIM_SELL, 0, (int32_t)v);
+        push_op(L, S, LOBSIM_MARKET, inv < 0 ? LOBSIM_BUY : LOBSIM_SELL, 0, (int32_t)v);
     }
     if (S.n_ops > OPS_MAX) S.status |= LOBSIM_ST_AGENT_OVERFLOW;
     wsync();
@@ -674,10 +683,12 @@ DI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
     bool lim_ok = is_limit && li >= 0 && m_tail(m) < SLOTS && m_tail(m) - m_head(m) - m_live(m) < 64;
     uint64_t lim_mask = __ballot(lim_ok);
     int R = popc64(lim_mask);
-    if (R > popc64(S.agent_free.w[0]) + popc64(S.agent_free.w[1])) { lim_ok = false; lim_mask = 0; R = 0; }  // sequential path reports the overflow
+    uint64_t free0 = lds_u64(L.agent_free[0]), free1 = lds_u64(L.agent_free[1]);
+    const uint32_t seq0 = (uint32_t)uni((int32_t)L.agent_seq);
+    if (R > popc64(free0) + popc64(free1)) { lim_ok = false; lim_mask = 0; R = 0; }  // sequential path reports the overflow
     if (lim_ok) {
         int r = popc64(lim_mask & below);  // my rank among the appenders -> the r-th free agent entry
-        uint64_t w0 = S.agent_free.w[0], w1 = S.agent_free.w[1];
+        uint64_t w0 = free0, w1 = free1;
         int c0 = popc64(w0), aidx;
         if (r < c0) { for (int t = 0; t < r; t++) w0 &= w0 - 1; aidx = ffs64(w0); }
         else { r -= c0; for (int t = 0; t < r; t++) w1 &= w1 - 1; aidx = 64 + ffs64(w1); }
@@ -687,14 +698,14 @@ DI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
         L.meta[side][li] = mk_meta(m_slab(m), live == 0 ? tail : m_head(m), tail + 1, live + 1);
         L.vol[side][li] += op.vol;
         AgentOrd o; o.price = price; o.vol = op.vol;
-        o.seq_side = ((S.agent_seq + (uint32_t)popc64(lim_mask & below)) & 0x7fffffffu) | ((uint32_t)side << 31);
+        o.seq_side = ((seq0 + (uint32_t)popc64(lim_mask & below)) & 0x7fffffffu) | ((uint32_t)side << 31);
         L.agent[aidx] = o;
         L.apos[aidx] = (uint16_t)tail;
     }
     for (int t = 0; t < R; t++) {  // the R lowest free entries are now taken
-        if (S.agent_free.w[0]) S.agent_free.w[0] &= S.agent_free.w[0] - 1; else S.agent_free.w[1] &= S.agent_free.w[1] - 1;
+        if (free0) free0 &= free0 - 1; else free1 &= free1 - 1;
     }
-    S.agent_seq += (uint32_t)R;
+    if (ln == 0 && R) { L.agent_free[0] = free0; L.agent_free[1] = free1; L.agent_seq = seq0 + (uint32_t)R; }
     // ---- cancellations: straight to the recorded slot
     bool can_ok = is_cancel && li >= 0;
     const int pos = can_ok ? L.apos[idx] : 0;
@@ -716,10 +727,8 @@ DI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
         }
     }
     wsync();
-    S.agent_pending.w[0] |= (uint64_t)uni64((int64_t)L.freed[0]);
-    S.agent_pending.w[1] |= (uint64_t)uni64((int64_t)L.freed[1]);
+    if (ln == 0) { L.agent_pending[0] |= L.freed[0]; L.agent_pending[1] |= L.freed[1]; L.freed[0] = 0; L.freed[1] = 0; }
     wsync();
-    if (ln == 0) { L.freed[0] = 0; L.freed[1] = 0; }
     // levels emptied by the cancellations leave the ladder (rare; sequential, looked up again by price)
     bool emptied = can_ok && gone && m_live(L.meta[side][li]) == 0;
     uint64_t em = __ballot(emptied);
@@ -739,15 +748,14 @@ DI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
 // ---------------------------------------------------------------------------------------------------------------
 DI void ladder_clear(Lds& L, Scal& S) {
     S.n_lv.a = S.n_lv.b = 0;
-    S.slab_free.fill(~0ull);
-    S.agent_free.fill(~0ull);
-    S.agent_pending.fill(0);
+    if (lane() < NSLAB / 64) L.slab_free[lane()] = ~0ull;
+    if (lane() < NA / 64) { L.agent_free[lane()] = ~0ull; L.agent_pending[lane()] = 0; }
     L.agent[lane()].vol = 0;
     L.agent[lane() + 64].vol = 0;
     L.apos[lane()] = 0;
     L.apos[lane() + 64] = 0;
     if (lane() < NA / 64) L.freed[lane()] = 0;
-    S.agent_seq = 0;
+    if (lane() == 0) L.agent_seq = 0;
     wsync();
 }
 
@@ -1141,8 +1149,8 @@ DI double step_reward(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, int en
     const lobsim_reward& r = terminal ? C.c.terminal_reward : C.c.per_step_reward;
     if constexpr (SHARPE)
         if (r.kind == LOBSIM_R_ROLLING_SHARPE)
-            return rolling_sharpe(L, S, r, P.sharpe + ((size_t)env * 2 + (terminal ? 1 : 0)) * (1 + LOBSIM_SHARPE_MAX_WINDOW), S.cash, S.inv, price);
-    return reward_of(r, inv0, cash0, p0, S.inv, S.cash, price);
+            return rolling_sharpe(L, S, r, P.sharpe + ((size_t)env * 2 + (terminal ? 1 : 0)) * (1 + LOBSIM_SHARPE_MAX_WINDOW), cur_cash(L), cur_inv(L), price);
+    return reward_of(r, inv0, cash0, p0, cur_inv(L), cur_cash(L), price);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1164,13 +1172,14 @@ DI void load_env(Lds& L, Scal& S, const DevPtrs& P, int env, const EnvHdr& H) {
     L.apos[ln] = AP[ln];
     L.apos[ln + 64] = AP[ln + 64];
     if (ln < NA / 64) L.freed[ln] = 0;
-    S.status = H.status; S.inv = H.inventory; S.cash = H.cash; S.agent_seq = H.agent_seq; S.n_ops = 0;
-#pragma unroll
-    for (int w = 0; w < NSLAB / 64; w++) S.slab_free.w[w] = H.slab_free[w];
-#pragma unroll
-    for (int w = 0; w < NA / 64; w++) { S.agent_free.w[w] = H.agent_free[w]; S.agent_pending.w[w] = 0; }
+    S.status = H.status; S.n_ops = 0;
+    if (ln < NSLAB / 64) L.slab_free[ln] = H.slab_free[ln];
+    if (ln < NA / 64) { L.agent_free[ln] = H.agent_free[ln]; L.agent_pending[ln] = 0; }
+    if (ln == 0) {
+        L.inv = H.inventory; L.cash = H.cash; L.agent_seq = H.agent_seq;
+        L.ag_cnt = 0; L.ag_vol[0] = L.ag_vol[1] = 0; L.ext_cnt[0] = L.ext_cnt[1] = 0; L.ext_vol[0] = L.ext_vol[1] = 0;
+    }
     S.slots = P.slots + (size_t)env * NSLAB * SLOTS;
-    S.ag_cnt = 0; S.ag_vol.a = S.ag_vol.b = 0; S.ext_cnt.a = S.ext_cnt.b = 0; S.ext_vol.a = S.ext_vol.b = 0;
     wsync();
 }
 
@@ -1191,28 +1200,27 @@ DI void store_env(const Lds& L, const Scal& S, const DevPtrs& P, int env, EnvHdr
     AP[ln + 64] = L.apos[ln + 64];
     if (ln == 0) {
         H.n_lv[0] = S.n_lv[0]; H.n_lv[1] = S.n_lv[1];
-        H.status = S.status; H.inventory = S.inv; H.cash = S.cash; H.agent_seq = S.agent_seq;
-#pragma unroll
-        for (int w = 0; w < NSLAB / 64; w++) H.slab_free[w] = S.slab_free.w[w];
-#pragma unroll
-        for (int w = 0; w < NA / 64; w++) H.agent_free[w] = S.agent_free.w[w] | S.agent_pending.w[w];
-        H.agent_fill_count = S.ag_cnt; H.agent_vol[0] = S.ag_vol[0]; H.agent_vol[1] = S.ag_vol[1];
-        H.ext_count[0] = S.ext_cnt[0]; H.ext_count[1] = S.ext_cnt[1]; H.ext_vol[0] = S.ext_vol[0]; H.ext_vol[1] = S.ext_vol[1];
+        H.status = S.status; H.inventory = L.inv; H.cash = L.cash; H.agent_seq = L.agent_seq;
+        H.agent_fill_count = L.ag_cnt; H.agent_vol[0] = L.ag_vol[0]; H.agent_vol[1] = L.ag_vol[1];
+        H.ext_count[0] = L.ext_cnt[0]; H.ext_count[1] = L.ext_cnt[1]; H.ext_vol[0] = L.ext_vol[0]; H.ext_vol[1] = L.ext_vol[1];
     }
+    if (ln < NSLAB / 64) H.slab_free[ln] = L.slab_free[ln];
+    if (ln < NA / 64) H.agent_free[ln] = L.agent_free[ln] | L.agent_pending[ln];
 }
 
-DI void clear_step_fills(Scal& S) {
-    S.ag_cnt = 0; S.ag_vol.a = S.ag_vol.b = 0; S.ext_cnt.a = S.ext_cnt.b = 0; S.ext_vol.a = S.ext_vol.b = 0;
-#pragma unroll
-    for (int w = 0; w < NA / 64; w++) { S.agent_free.w[w] |= S.agent_pending.w[w]; S.agent_pending.w[w] = 0; }
+DI void clear_step_fills(Lds& L) {
+    wsync();
+    if (lane() == 0) { L.ag_cnt = 0; L.ag_vol[0] = L.ag_vol[1] = 0; L.ext_cnt[0] = L.ext_cnt[1] = 0; L.ext_vol[0] = L.ext_vol[1] = 0; }
+    if (lane() < NA / 64) { L.agent_free[lane()] |= L.agent_pending[lane()]; L.agent_pending[lane()] = 0; }
+    wsync();
 }
 
 DI StepView make_view(const Lds& L, const Scal& S, double price, int64_t now_us) {
     StepView v;
-    v.price = price; v.now_us = now_us; v.inventory = S.inv;
+    v.price = price; v.now_us = now_us; v.inventory = cur_inv(L);
     v.now_mod_min = (uint32_t)(now_us % 60000000ll);
     v.spread = best_sell_d(L, S) - best_buy_d(L, S);
-    v.ext_cnt[0] = S.ext_cnt[0]; v.ext_cnt[1] = S.ext_cnt[1]; v.ext_vol[0] = S.ext_vol[0]; v.ext_vol[1] = S.ext_vol[1];
+    v.ext_cnt[0] = uni(L.ext_cnt[0]); v.ext_cnt[1] = uni(L.ext_cnt[1]); v.ext_vol[0] = uni(L.ext_vol[0]); v.ext_vol[1] = uni(L.ext_vol[1]);
     v.book_ok = S.n_lv[0] && S.n_lv[1];
     v.bv = v.book_ok ? uni(L.vol[0][0]) : 0; v.av = v.book_ok ? uni(L.vol[1][0]) : 0;
     if (v.bv + v.av == 0) v.book_ok = false;
@@ -1321,7 +1329,7 @@ __global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg 
     int done = 0;
     FeatState fs = FeatState();
     if (!S.status) {
-        const int64_t inv0 = S.inv, cash0 = S.cash;
+        const int64_t inv0 = cur_inv(L), cash0 = cur_cash(L);
         const double p0 = price;
         build_agent_ops(L, S, C, act);  // convert_action_to_orders on the pre-step state
         STAMP(2);
@@ -1448,8 +1456,8 @@ __global__ __launch_bounds__(64, 3) void lob_rollout_kernel(DevCfg C, DevPtrs P,
         } else {
             act = teradactyl_action(A.params, rld(fs.current_value, (int)A.params[5]));  // obs[inventory_index]
         }
-        clear_step_fills(S);
-        const int64_t inv0 = S.inv, cash0 = S.cash;
+        clear_step_fills(L);
+        const int64_t inv0 = cur_inv(L), cash0 = cur_cash(L);
         const double p0 = price;
         reward = 0.0;
         MsgBatch first = {INT64_MAX, 0, 0, 0};
@@ -1504,9 +1512,10 @@ __global__ __launch_bounds__(64, 4) void lob_reset_kernel(DevCfg C, DevPtrs P, R
     const int F = C.c.n_features, D = C.obs_dim, Lv = C.c.n_levels;
     Scal S;
     S.slots = P.slots + (size_t)env * NSLAB * SLOTS;
-    S.status = 0; S.inv = H.inventory; S.cash = H.cash; S.n_ops = 0;  // the portfolio is NOT reset (Q7)
+    S.status = 0; S.n_ops = 0;
+    if (ln == 0) { L.inv = H.inventory; L.cash = H.cash; }  // the portfolio is NOT reset (Q7)
     ladder_clear(L, S);
-    clear_step_fills(S);
+    clear_step_fills(L);
     const int stream_id = A.stream_ids[k];
     const StreamDev& st = P.streams[stream_id];
     const int64_t start = A.start_us[k];
@@ -1542,7 +1551,7 @@ __global__ __launch_bounds__(64, 4) void lob_reset_kernel(DevCfg C, DevPtrs P, R
     }
     const int64_t n_warm = C.c.warmup_us / C.c.step_us;
     for (int64_t s = 0; s < n_warm && !S.status; s++) {
-        clear_step_fills(S);
+        clear_step_fills(L);
         advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, false, fetch_messages(st, cursor));
         if (S.status) break;
         StepView v = make_view(L, S, price, now);
@@ -1567,9 +1576,10 @@ __global__ __launch_bounds__(64) void lob_set_book_kernel(DevCfg C, DevPtrs P, i
     EnvHdr& H = P.hdr[env];
     Scal S;
     S.slots = P.slots + (size_t)env * NSLAB * SLOTS;
-    S.status = 0; S.inv = H.inventory; S.cash = H.cash; S.n_ops = 0;
+    S.status = 0; S.n_ops = 0;
+    if (lane() == 0) { L.inv = H.inventory; L.cash = H.cash; }
     ladder_clear(L, S);
-    clear_step_fills(S);
+    clear_step_fills(L);
     if (row) load_snapshot_book(L, S, row, C.c.n_levels, true);
     store_env(L, S, P, env, H);
     if (lane() == 0) {
@@ -1587,8 +1597,8 @@ __global__ __launch_bounds__(64) void lob_process_orders_kernel(DevCfg C, DevPtr
     const int ln = lane();
     Scal S;
     load_env(L, S, P, env, H);
-    clear_step_fills(S);
-    const int64_t cash0 = S.cash;
+    clear_step_fills(L);
+    const int64_t cash0 = cur_cash(L);
     for (int k = 0; k < n && !S.status; k++) {
         const int64_t* r = orders + 6 * (size_t)k;
         int type = (int)r[0], side = (int)r[1];
@@ -1626,9 +1636,9 @@ __global__ __launch_bounds__(64) void lob_process_orders_kernel(DevCfg C, DevPtr
         // make entries freed by this order reusable, like the reference (no step boundary at this level)
     }
     if (ln == 0 && fills_out) {
-        fills_out[0] = S.ag_cnt; fills_out[1] = S.ag_vol[0]; fills_out[2] = S.ag_vol[1];
-        fills_out[3] = S.ext_cnt[0]; fills_out[4] = S.ext_cnt[1]; fills_out[5] = S.ext_vol[0]; fills_out[6] = S.ext_vol[1];
-        fills_out[7] = S.cash - cash0;
+        fills_out[0] = L.ag_cnt; fills_out[1] = L.ag_vol[0]; fills_out[2] = L.ag_vol[1];
+        fills_out[3] = L.ext_cnt[0]; fills_out[4] = L.ext_cnt[1]; fills_out[5] = L.ext_vol[0]; fills_out[6] = L.ext_vol[1];
+        fills_out[7] = L.cash - cash0;
     }
     store_env(L, S, P, env, H);
 }
