@@ -77,8 +77,14 @@ struct Pair {  // two wave-uniform values selected by side; kept as two register
     DI void set(int i, T v) { a = i ? a : v; b = i ? v : b; }
     DI void add(int i, T v) { a += i ? T(0) : v; b += i ? v : T(0); }
 };
+struct LevelCounts {  // live price levels per side, packed in one scalar register (buy in bits 0-15, sell in 16-31)
+    uint32_t v;
+    DI int operator[](int side) const { return (int)((v >> (side * 16)) & 0xffffu); }
+    DI void set(int side, int n) { v = (v & ~(0xffffu << (side * 16))) | ((uint32_t)n << (side * 16)); }
+    DI void bump(int side, int d) { v += (uint32_t)d << (side * 16); }  // +-1: never carries across the halves
+};
 struct Scal {
-    Pair<int32_t> n_lv;
+    LevelCounts n_lv;
     int32_t status;
     int32_t n_ops;
     int64_t q_buy, q_sell;  // best prices the current op list was built against (_get_best_prices)
@@ -89,6 +95,12 @@ struct Scal {
 };
 
 DI int lane() { return (int)threadIdx.x; }
+// lane mask of a predicate; the builtin takes the compare's own mask (HIP's __ballot(int) round-trips through a VGPR)
+DI uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// signed 64-bit order tests for WAVE-UNIFORM values: the scalar unit has no 64-bit ordered compare, the compiler would
+// move both operands to vector registers.  Valid while |a - b| < 2^63 (prices, times, ids here are far inside that).
+DI bool lt64(int64_t a, int64_t b) { return (int32_t)(((uint64_t)a - (uint64_t)b) >> 32) < 0; }
+DI bool le64(int64_t a, int64_t b) { return !lt64(b, a); }
 // Lanes of ONE wave exchange data through LDS and through the env's own slabs.  A wavefront's LDS instructions and
 // its vector-memory instructions each execute in program order, so a later instruction of the same wave observes an
 // earlier one's write without any s_waitcnt; what must be prevented is the COMPILER moving or caching accesses
@@ -162,7 +174,7 @@ DI int find_level(const Lds& L, const Scal& S, int side, int64_t price) {
     int n = S.n_lv[side], ln = lane();
     bool m0 = ln < n && L.price[side][ln] == price;
     bool m1 = ln + 64 < n && L.price[side][ln + 64] == price;
-    uint64_t b0 = __ballot(m0), b1 = __ballot(m1);
+    uint64_t b0 = ballot(m0), b1 = ballot(m1);
     if (b0) return ffs64(b0);
     if (b1) return 64 + ffs64(b1);
     return -1;
@@ -174,12 +186,12 @@ DI int find_level_meta(const Lds& L, const Scal& S, int side, int64_t price, uin
     int n = S.n_lv[side], ln = lane();
     int64_t p0 = L.price[side][ln];
     uint64_t q0 = L.meta[side][ln];
-    uint64_t b0 = __ballot(ln < n && p0 == price);
+    uint64_t b0 = ballot(ln < n && p0 == price);
     if (b0) { int i = ffs64(b0); meta = (uint64_t)rl64((int64_t)q0, i); return i; }
     if (n > 64) {
         int64_t p1 = L.price[side][ln + 64];
         uint64_t q1 = L.meta[side][ln + 64];
-        uint64_t b1 = __ballot(ln + 64 < n && p1 == price);
+        uint64_t b1 = ballot(ln + 64 < n && p1 == price);
         if (b1) { int i = ffs64(b1); meta = (uint64_t)rl64((int64_t)q1, i); return 64 + i; }
     }
     meta = 0;
@@ -190,7 +202,7 @@ DI int insert_pos(const Lds& L, const Scal& S, int side, int64_t price) {
     int n = S.n_lv[side], ln = lane();
     bool m0 = ln < n && (side == LOBSIM_BUY ? L.price[side][ln] > price : L.price[side][ln] < price);
     bool m1 = ln + 64 < n && (side == LOBSIM_BUY ? L.price[side][ln + 64] > price : L.price[side][ln + 64] < price);
-    return popc64(__ballot(m0)) + popc64(__ballot(m1));
+    return popc64(ballot(m0)) + popc64(ballot(m1));
 }
 
 // open an empty level at sorted position pos; returns false on overflow
@@ -212,7 +224,7 @@ DI bool ladder_insert(Lds& L, Scal& S, int side, int pos, int64_t price) {
         if (take[r]) { L.price[side][i] = p[r]; L.meta[side][i] = m[r]; L.vol[side][i] = v[r]; }
     }
     if (ln == 0) { L.price[side][pos] = price; L.meta[side][pos] = mk_meta(slab, 0, 0, 0); L.vol[side][pos] = 0; }
-    S.n_lv.set(side, n + 1);
+    S.n_lv.bump(side, 1);
     wsync();
     return true;
 }
@@ -233,7 +245,7 @@ DI void ladder_remove(Lds& L, Scal& S, int side, int pos) {
         int i = ln + 64 * r;
         if (take[r]) { L.price[side][i] = p[r]; L.meta[side][i] = m[r]; L.vol[side][i] = v[r]; }
     }
-    S.n_lv.set(side, n - 1);
+    S.n_lv.bump(side, -1);
     wsync();
 }
 
@@ -257,7 +269,7 @@ DI uint64_t compact_level(Lds& L, Scal& S, int side, int idx, uint64_t m) {
     int out = 0;
     for (int c = head >> 6; c * 64 < tail; c++) {
         Slot s = load_slot(sl, c * 64 + ln, head, tail);
-        uint64_t b = __ballot(s.kind != K_DEAD);
+        uint64_t b = ballot(s.kind != K_DEAD);
         wsync();  // every lane's load has landed before any lane stores
         if (s.kind != K_DEAD) {
             int np = out + popc64(b & below);
@@ -329,7 +341,7 @@ DI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, int
     int32_t pv = 0;
     for (int c = head >> 6; c * 64 < tail; c++) {  // independent 1 KiB loads: one ballot per chunk finds the order
         Slot s = load_slot(sl, c * 64 + ln, head, tail);
-        uint64_t b = __ballot(s.kind == kind && s.id == id);
+        uint64_t b = ballot(s.kind == kind && s.id == id);
         if (b) { int l = fls64(b); pos = c * 64 + l; pv = rl32(s.vol, l); }
     }
     int32_t pk = kind;
@@ -341,7 +353,7 @@ DI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, int
         int32_t hk = K_DEAD, hv = 0;
         for (int c = head >> 6; c * 64 < tail && first_live < 0; c++) {
             Slot s = load_slot(sl, c * 64 + ln, head, tail);
-            uint64_t lv = __ballot(s.kind != K_DEAD);
+            uint64_t lv = ballot(s.kind != K_DEAD);
             if (lv) { int l = ffs64(lv); first_live = c * 64 + l; hk = rl32(s.kind, l); hv = rl32(s.vol, l); }
         }
         if (hk != K_SNAP) return;
@@ -364,7 +376,7 @@ DI int32_t execute(Lds& L, Scal& S, int side, bool is_agent, bool is_market, int
             break;
         }
         int64_t bp = uni64(L.price[opp][0]);
-        if (!is_market && !(side == LOBSIM_BUY ? price >= bp : price <= bp)) break;
+        if (!is_market && !(side == LOBSIM_BUY ? le64(bp, price) : le64(price, bp))) break;
         uint64_t m = (uint64_t)uni64((int64_t)L.meta[opp][0]);
         int head = m_head(m), tail = m_tail(m);
         Slot* sl = S.slots + (size_t)m_slab(m) * SLOTS;
@@ -388,22 +400,22 @@ DI int32_t execute(Lds& L, Scal& S, int side, bool is_agent, bool is_market, int
                 sl[i] = w;
                 if (is_ag) L.agent[s.id].vol = nv;
             }
-            uint64_t reached_agent = __ballot(reached && is_ag);
+            uint64_t reached_agent = ballot(reached && is_ag);
             if (reached_agent) {  // rare: resting agent orders in the swept range
-                uint64_t gone_agent = __ballot(gone && is_ag);
+                uint64_t gone_agent = ballot(gone && is_ag);
                 while (gone_agent) {  // freed agent entries (uniform bookkeeping): ids live in lanes, gather them
                     int b = ffs64(gone_agent);
                     gone_agent &= gone_agent - 1;
                     mask_set(L.agent_pending, (int)rl64(s.id, b));
                 }
-                n_agent += popc64(__ballot(reached && is_ag && !own));
+                n_agent += popc64(ballot(reached && is_ag && !own));
                 exec_agent += wave_sum((reached && is_ag && !own) ? ex : 0);
                 deleted_agent_vol += wave_sum((reached && own) ? s.vol : 0);
             }
-            n_ext += popc64(__ballot(reached && !is_ag));
-            n_removed += popc64(__ballot(gone));
+            n_ext += popc64(ballot(reached && !is_ag));
+            n_removed += popc64(ballot(gone));
             carry += rl32(incl, 63);
-            uint64_t surv = __ballot(live && !gone);
+            uint64_t surv = ballot(live && !gone);
             if (surv) { first_survivor = c * 64 + ffs64(surv); break; }  // a survivor means the sweep ended in this chunk
         }
         // fills are a FIFO prefix of the (non-own) resting volume: everything up to min(rem, volume seen)
@@ -439,7 +451,7 @@ DI void submit_limit(Lds& L, Scal& S, int side, int64_t price, int32_t vol, bool
     const int64_t bp = uni64(L.price[opp][0]);
     uint64_t m;
     int idx = find_level_meta(L, S, side, price, m);
-    const bool cross = S.n_lv[opp] > 0 && (side == LOBSIM_BUY ? price >= bp : price <= bp);
+    const bool cross = S.n_lv[opp] > 0 && (side == LOBSIM_BUY ? le64(bp, price) : le64(price, bp));
     if (cross) {
         vol = execute(L, S, side, is_agent, false, price, vol);
         if (S.status || vol <= 0) return;
@@ -461,8 +473,8 @@ DI void submit_limit(Lds& L, Scal& S, int side, int64_t price, int32_t vol, bool
 
 // process_order (Exchange.py:58-69) for one historical message
 DI void process_message(Lds& L, Scal& S, int type, int side, int64_t price, int64_t vol64, int64_t ext_id) {
-    if (!(vol64 > 0)) { S.status |= LOBSIM_ST_ASSERT; return; }  // assert order.volume > 0
-    int32_t vol = vol64 > 0x7fffffffll ? 0x7fffffff : (int32_t)vol64;
+    if (vol64 == 0) { S.status |= LOBSIM_ST_ASSERT; return; }  // assert order.volume > 0 (the packed field is unsigned)
+    int32_t vol = (vol64 >> 31) ? 0x7fffffff : (int32_t)vol64;
     switch (type) {
     case LOBSIM_LIMIT: submit_limit(L, S, side, price, vol, false, ext_id); break;
     case LOBSIM_MARKET: execute(L, S, side, false, true, 0, vol); break;
@@ -599,7 +611,7 @@ DI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action) {
         const uint32_t q0 = ao[0].seq_side & 0x7fffffffu, q1 = ao[1].seq_side & 0x7fffffffu;
 #pragma unroll
         for (int r = 0; r < 2; r++) {  // broadcast every candidate once: volume of same-level orders newer than mine
-            uint64_t bb = __ballot(cand[r]);
+            uint64_t bb = ballot(cand[r]);
             while (bb) {
                 const int t = ffs64(bb);
                 bb &= bb - 1;
@@ -622,13 +634,13 @@ DI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action) {
     int base = 0;
     for (int side = 0; side < 2; side++) {
         const bool lim = quoting && my_side == side && diff > 0;
-        const uint64_t lm = __ballot(lim);
+        const uint64_t lm = ballot(lim);
         if (lim) { const int at = base + popc64(lm & below); if (at < OPS_MAX) { Op8 op; op.vol = diff; op.code = LOBSIM_LIMIT | (side << 4) | (my_k << 8); L.ops[at] = op; } }
         base += popc64(lm);
 #pragma unroll
         for (int r = 0; r < 2; r++) {
             const bool cn = cvol[r] > 0 && (int)(ao[r].seq_side >> 31) == side;
-            const uint64_t cm = __ballot(cn);
+            const uint64_t cm = ballot(cn);
             if (cn) { const int at = base + popc64(cm & below); if (at < OPS_MAX) { Op8 op; op.vol = cvol[r]; op.code = LOBSIM_CANCELLATION | (side << 4) | ((ln + 64 * r) << 8); L.ops[at] = op; } }
             base += popc64(cm);
         }
@@ -675,13 +687,13 @@ DI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
         price = side == LOBSIM_BUY ? S.q_buy - off : S.q_sell + off;
     }
     if (is_cancel) price = L.agent[idx].price;
-    const int nlv = side ? S.n_lv.b : S.n_lv.a;
+    const int nlv = S.n_lv[side];
     const int li = (is_limit || is_cancel) ? lane_find_level(L, side, nlv, price) : -1;
     const uint64_t m = li >= 0 ? L.meta[side][li] : 0;
     Slot* sl = S.slots + (size_t)m_slab(m) * SLOTS;
     // ---- new orders: append at the tail of an existing level that has room
     bool lim_ok = is_limit && li >= 0 && m_tail(m) < SLOTS && m_tail(m) - m_head(m) - m_live(m) < 64;
-    uint64_t lim_mask = __ballot(lim_ok);
+    uint64_t lim_mask = ballot(lim_ok);
     int R = popc64(lim_mask);
     uint64_t free0 = lds_u64(L.agent_free[0]), free1 = lds_u64(L.agent_free[1]);
     const uint32_t seq0 = (uint32_t)uni((int32_t)L.agent_seq);
@@ -731,7 +743,7 @@ DI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
     wsync();
     // levels emptied by the cancellations leave the ladder (rare; sequential, looked up again by price)
     bool emptied = can_ok && gone && m_live(L.meta[side][li]) == 0;
-    uint64_t em = __ballot(emptied);
+    uint64_t em = ballot(emptied);
     while (em) {
         int j = ffs64(em);
         em &= em - 1;
@@ -740,14 +752,14 @@ DI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
         if (ix >= 0 && m_live((uint64_t)uni64((int64_t)L.meta[sd][ix])) == 0) ladder_remove(L, S, sd, ix);
     }
     wsync();
-    return __ballot(have && !(lim_ok || can_ok));
+    return ballot(have && !(lim_ok || can_ok));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // simulator: snapshot -> book, outer-level resync, message replay
 // ---------------------------------------------------------------------------------------------------------------
 DI void ladder_clear(Lds& L, Scal& S) {
-    S.n_lv.a = S.n_lv.b = 0;
+    S.n_lv.v = 0;
     if (lane() < NSLAB / 64) L.slab_free[lane()] = ~0ull;
     if (lane() < NA / 64) { L.agent_free[lane()] = ~0ull; L.agent_pending[lane()] = 0; }
     L.agent[lane()].vol = 0;
@@ -779,8 +791,8 @@ DI void set_level_to_snapshot(Lds& L, Scal& S, int side, int64_t price, int32_t 
 DI bool price_range(const Lds& L, const Scal& S, int64_t& worst_buy, int64_t& worst_sell) {
     int ln = lane();
     int nb = S.n_lv[0], ns = S.n_lv[1];
-    uint64_t b0 = __ballot(ln < nb && L.price[0][ln] > 0), b1 = __ballot(ln + 64 < nb && L.price[0][ln + 64] > 0);
-    uint64_t s0 = __ballot(ln < ns && L.price[1][ln] < DUMMY_PRICE), s1 = __ballot(ln + 64 < ns && L.price[1][ln + 64] < DUMMY_PRICE);
+    uint64_t b0 = ballot(ln < nb && L.price[0][ln] > 0), b1 = ballot(ln + 64 < nb && L.price[0][ln + 64] > 0);
+    uint64_t s0 = ballot(ln < ns && L.price[1][ln] < DUMMY_PRICE), s1 = ballot(ln + 64 < ns && L.price[1][ln + 64] < DUMMY_PRICE);
     int ib = b1 ? 64 + fls64(b1) : fls64(b0), is = s1 ? 64 + fls64(s1) : fls64(s0);
     if (ib < 0 || is < 0) return false;  // StopIteration
     worst_buy = uni64(L.price[0][ib]);
@@ -814,7 +826,7 @@ DI void resync_outer_levels(Lds& L, Scal& S, const DevCfg& C, const StreamDev& s
                     v = side == LOBSIM_BUY ? row[4 * l + 3] : row[4 * l + 1];
                     pass = side == LOBSIM_BUY ? (double)p < R.min_buy : (double)p > R.max_sell;  // _initial_prices_filter_function
                 }
-                uint64_t pm = __ballot(pass);
+                uint64_t pm = ballot(pass);
                 while (pm && !S.status) {
                     int j = ffs64(pm);
                     pm &= pm - 1;
@@ -824,7 +836,7 @@ DI void resync_outer_levels(Lds& L, Scal& S, const DevCfg& C, const StreamDev& s
                     for (int r = 0; r < 2 && !S.status; r++) {
                         AgentOrd o = L.agent[ln + 64 * r];
                         bool hit = o.vol > 0 && (int)(o.seq_side >> 31) == side && o.price == price;
-                        uint64_t hm = __ballot(hit);
+                        uint64_t hm = ballot(hit);
                         // process in submission order
                         while (hm && !S.status) {
                             uint32_t myq = hit ? (o.seq_side & 0x7fffffffu) : 0xffffffffu;
@@ -876,7 +888,7 @@ DI MsgBatch fetch_messages(const StreamDev& st, int64_t cursor) {
 // the agent's orders, so the stream's HBM latency hides behind that work).
 DI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, int64_t until_us, MsgBatch b) {
     while (!S.status) {
-        uint64_t bm = __ballot(b.t <= until_us);
+        uint64_t bm = ballot(b.t <= until_us);
         int cnt = popc64(bm);  // the stream is time-sorted: the in-window lanes are a prefix
         for (int j = 0; j < cnt && !S.status; j++) {
             int64_t mm = rl64(b.meta, j);
@@ -1122,7 +1134,7 @@ DI double rolling_sharpe(Lds& L, Scal& S, const lobsim_reward& r, double* st, in
         scr[k] = log(a);
     }
     wsync();
-    if (__ballot(bad)) { S.status |= LOBSIM_ST_ASSERT; return 0.0; }
+    if (ballot(bad)) { S.status |= LOBSIM_ST_ASSERT; return 0.0; }
     const int m = filled - 1;
     double s0 = 0.0, s1 = 0.0;
     if (ln < m) s0 = exp(scr[ln + 1] - scr[ln]) - 1;  // simple returns
@@ -1159,7 +1171,7 @@ DI double step_reward(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, int en
 DI void load_env(Lds& L, Scal& S, const DevPtrs& P, int env, const EnvHdr& H) {
     int ln = lane();
     const Ladder& G = P.ladder[env];
-    S.n_lv.a = H.n_lv[0]; S.n_lv.b = H.n_lv[1];
+    S.n_lv.v = (uint32_t)H.n_lv[0] | ((uint32_t)H.n_lv[1] << 16);
 #pragma unroll
     for (int s = 0; s < 2; s++)
         for (int i = ln; i < S.n_lv[s]; i += 64) {
@@ -1346,7 +1358,7 @@ __global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg 
             StepView v = make_view(L, S, price, now);
             bool ok = true;
             if (ln < F) ok = feature_update(C.c.features[ln], fs, P.rings + (size_t)env * C.ring_words + C.ring_off[ln], v);
-            if (__ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
+            if (ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
         }
         if (!S.status) {
             reward = step_reward<SHARPE>(L, S, C, P, env, false, inv0, cash0, p0, price);
@@ -1468,7 +1480,7 @@ __global__ __launch_bounds__(64, 3) void lob_rollout_kernel(DevCfg C, DevPtrs P,
             StepView v = make_view(L, S, price, now);
             bool ok = true;
             if (ln < F) ok = feature_update(C.c.features[ln], fs, ring, v);
-            if (__ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
+            if (ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
         }
         if (!S.status) {
             reward = step_reward<SHARPE>(L, S, C, P, env, false, inv0, cash0, p0, price);
@@ -1547,7 +1559,7 @@ __global__ __launch_bounds__(64, 4) void lob_reset_kernel(DevCfg C, DevPtrs P, R
             const lobsim_feature& d = C.c.features[ln];
             ok = feature_reset(d, fs, ring, v, start - (int64_t)d.lookback * d.update_us);
         }
-        if (__ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
+        if (ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
     }
     const int64_t n_warm = C.c.warmup_us / C.c.step_us;
     for (int64_t s = 0; s < n_warm && !S.status; s++) {
@@ -1557,7 +1569,7 @@ __global__ __launch_bounds__(64, 4) void lob_reset_kernel(DevCfg C, DevPtrs P, R
         StepView v = make_view(L, S, price, now);
         bool ok = true;
         if (ln < F) ok = feature_update(C.c.features[ln], fs, ring, v);
-        if (__ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
+        if (ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
     }
     if (ln < D && A.obs) A.obs[(size_t)k * D + ln] = ln < F ? fs.current_value : 0.0;  // zeros for the previous action (:158-159)
     if (ln < F) P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln] = fs;
@@ -1617,7 +1629,7 @@ __global__ __launch_bounds__(64) void lob_process_orders_kernel(DevCfg C, DevPtr
             bool m0 = o0.vol > 0 && (int)(o0.seq_side >> 31) == side && o0.price == price;
             bool m1 = o1.vol > 0 && (int)(o1.seq_side >> 31) == side && o1.price == price;
             uint32_t q0 = o0.seq_side & 0x7fffffffu, q1 = o1.seq_side & 0x7fffffffu;
-            uint64_t b0 = __ballot(m0), b1 = __ballot(m1);
+            uint64_t b0 = ballot(m0), b1 = ballot(m1);
             int older0 = 0, older1 = 0;
             for (int rr = 0; rr < 2; rr++) {
                 uint64_t bb = rr ? b1 : b0;
@@ -1629,7 +1641,7 @@ __global__ __launch_bounds__(64) void lob_process_orders_kernel(DevCfg C, DevPtr
                     if (tq < q1) older1++;
                 }
             }
-            uint64_t h0 = __ballot(m0 && older0 == id), h1 = __ballot(m1 && older1 == id);
+            uint64_t h0 = ballot(m0 && older0 == id), h1 = ballot(m1 && older1 == id);
             int aidx = h0 ? ffs64(h0) : (h1 ? 64 + ffs64(h1) : NA + 1000);
             remove_order(L, S, side, price, K_AGENT, aidx, (int32_t)vol);
         }
