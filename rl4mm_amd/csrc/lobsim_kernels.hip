@@ -545,8 +545,10 @@ DI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action) {
         double a, b;
         if (c.use_concentration) { a = act_at(action, my_side) + EPS; b = c.concentration - a + EPS; }
         else { a = act_at(action, 2 * my_side) + EPS; b = act_at(action, 2 * my_side + 1) + EPS; }
-        double x = 1.0 / Q * (my_k + 0.5);
-        L.pdf[my_side][my_k] = pow(x, a - 1.0) * pow(1.0 - x, b - 1.0);  // beta.pdf up to the 1/B(a,b) that cancels below
+        // beta.pdf up to the 1/B(a,b) that cancels in the normalisation below; x^(a-1) (1-x)^(b-1) as one exp over
+        // host-tabulated logs (two pow() calls were a quarter of this kernel's fixed VALU work).  Only the integer
+        // volumes after rounding are observable: tests pin them against a 320k-value scipy table.
+        L.pdf[my_side][my_k] = exp((a - 1.0) * C.log_x[my_k] + (b - 1.0) * C.log_1mx[my_k]);
     }
     if (ln < 2 * QMAX) L.cur[ln / QMAX][ln % QMAX] = 0;
     wsync();

@@ -102,6 +102,8 @@ struct DevCfg {
     int32_t obs_dim;
     int32_t ring_off[LOBSIM_MAX_FEATURES];  // offset of feature f's ring (in 8-byte words) inside an env's ring block
     int32_t ring_words;         // ring words per env
+    // ln(x_k), ln(1 - x_k) at the Q quote-level midpoints x_k = (k + 0.5) / Q: Beta pdf = exp((a-1) ln x + (b-1) ln(1-x))
+    double log_x[QMAX], log_1mx[QMAX];
 };
 
 struct DevPtrs {
