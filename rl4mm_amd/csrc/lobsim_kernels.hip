@@ -30,6 +30,11 @@ namespace lobk {
 #else
 #define STAMP(k) do { } while (0)
 #endif
+#ifdef LOBSIM_PROFILE
+#define EVENT(field) (S.field++)
+#else
+#define EVENT(field) do { } while (0)
+#endif
 
 struct Op8 {  // one agent order waiting to be processed (built from the pre-step state, then replayed)
     int32_t vol;
@@ -89,8 +94,11 @@ struct Scal {
     int32_t n_ops;
     int64_t q_buy, q_sell;  // best prices the current op list was built against (_get_best_prices)
     Slot* slots;            // this env's slabs
-#ifdef LOBSIM_PROFILE
+#ifdef LOBSIM_PROFILE_MSG
     uint64_t pm_cycles[8], pm_count[8];  // per message class (diagnostic build only)
+#endif
+#ifdef LOBSIM_PROFILE
+    uint32_t ev_chunks, ev_compact, ev_ladder, ev_exec_levels, ev_rare;  // event counts (diagnostic build only)
 #endif
 };
 
@@ -208,6 +216,7 @@ DI int insert_pos(const Lds& L, const Scal& S, int side, int64_t price) {
 // open an empty level at sorted position pos; returns false on overflow
 DI bool ladder_insert(Lds& L, Scal& S, int side, int pos, int64_t price) {
     int n = S.n_lv[side], ln = lane();
+    EVENT(ev_ladder);
     if (n >= LV) { S.status |= LOBSIM_ST_LEVEL_OVERFLOW; return false; }
     int slab = mask_take_first(L.slab_free);
     int64_t p[2]; uint64_t m[2]; int32_t v[2]; bool take[2];
@@ -231,6 +240,7 @@ DI bool ladder_insert(Lds& L, Scal& S, int side, int pos, int64_t price) {
 
 DI void ladder_remove(Lds& L, Scal& S, int side, int pos) {
     int n = S.n_lv[side], ln = lane();
+    EVENT(ev_ladder);
     mask_set(L.slab_free, m_slab((uint64_t)uni64((int64_t)L.meta[side][pos])));
     int64_t p[2]; uint64_t m[2]; int32_t v[2]; bool take[2];
 #pragma unroll
@@ -263,6 +273,7 @@ DI Slot load_slot(const Slot* sl, int i, int head, int tail) {
 // at or below the chunk's own first slot, so nothing unread is overwritten.  Returns the new meta word.
 DI uint64_t compact_level(Lds& L, Scal& S, int side, int idx, uint64_t m) {
     int ln = lane();
+    EVENT(ev_compact);
     int slab = m_slab(m), head = m_head(m), tail = m_tail(m);
     Slot* sl = S.slots + (size_t)slab * SLOTS;
     uint64_t below = (1ull << ln) - 1;
@@ -340,6 +351,7 @@ DI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, int
     int pos = -1;
     int32_t pv = 0;
     for (int c = head >> 6; c * 64 < tail; c++) {  // independent 1 KiB loads: one ballot per chunk finds the order
+        EVENT(ev_chunks);
         Slot s = load_slot(sl, c * 64 + ln, head, tail);
         uint64_t b = ballot(s.kind == kind && s.id == id);
         if (b) { int l = fls64(b); pos = c * 64 + l; pv = rl32(s.vol, l); }
@@ -352,6 +364,7 @@ DI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, int
         int first_live = -1;
         int32_t hk = K_DEAD, hv = 0;
         for (int c = head >> 6; c * 64 < tail && first_live < 0; c++) {
+            EVENT(ev_rare);
             Slot s = load_slot(sl, c * 64 + ln, head, tail);
             uint64_t lv = ballot(s.kind != K_DEAD);
             if (lv) { int l = ffs64(lv); first_live = c * 64 + l; hk = rl32(s.kind, l); hv = rl32(s.vol, l); }
@@ -382,7 +395,9 @@ DI int32_t execute(Lds& L, Scal& S, int side, bool is_agent, bool is_market, int
         Slot* sl = S.slots + (size_t)m_slab(m) * SLOTS;
         int32_t carry = 0, exec_agent = 0, deleted_agent_vol = 0, n_ext = 0, n_agent = 0, n_removed = 0;
         int first_survivor = tail;
+        EVENT(ev_exec_levels);
         for (int c = head >> 6; c * 64 < tail; c++) {
+            EVENT(ev_chunks);
             int i = c * 64 + ln;
             Slot s = load_slot(sl, i, head, tail);
             bool live = s.kind != K_DEAD;
@@ -894,7 +909,7 @@ DI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, i
         int cnt = popc64(bm);  // the stream is time-sorted: the in-window lanes are a prefix
         for (int j = 0; j < cnt && !S.status; j++) {
             int64_t mm = rl64(b.meta, j);
-#ifdef LOBSIM_PROFILE
+#ifdef LOBSIM_PROFILE_MSG
             // classes: 0 limit at an existing level, 1 limit opening a level, 2 crossing limit, 3 cancel, 4 delete,
             // 5 delete/cancel that empties its level, 6 market, 7 other
             const int ty = (int)((mm >> LOBSIM_TYPE_SHIFT) & 0xf), sd = (int)((mm >> LOBSIM_SIDE_SHIFT) & 1);
@@ -907,7 +922,7 @@ DI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, i
             __builtin_amdgcn_sched_barrier(0);
 #endif
             process_message(L, S, (int)((mm >> LOBSIM_TYPE_SHIFT) & 0xf), (int)((mm >> LOBSIM_SIDE_SHIFT) & 1), rl64(b.price, j), mm & LOBSIM_VOL_MASK, rl64(b.eid, j));
-#ifdef LOBSIM_PROFILE
+#ifdef LOBSIM_PROFILE_MSG
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_sched_barrier(0);
             const uint64_t t1 = __builtin_amdgcn_s_memtime();
@@ -1325,6 +1340,9 @@ __global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg 
     STAMP(0);
     Scal S;
 #ifdef LOBSIM_PROFILE
+    S.ev_chunks = S.ev_compact = S.ev_ladder = S.ev_exec_levels = S.ev_rare = 0;
+#endif
+#ifdef LOBSIM_PROFILE_MSG
     for (int k = 0; k < 8; k++) { S.pm_cycles[k] = 0; S.pm_count[k] = 0; }
 #endif
     load_env(L, S, P, env, H);
@@ -1394,8 +1412,12 @@ __global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg 
         for (int k = 0; k < 6; k++) P.prof[(size_t)env * 8 + k] += prof_t[k + 1] - prof_t[k];
         P.prof[(size_t)env * 8 + 6] += S.n_ops;
         P.prof[(size_t)env * 8 + 7] += 1;
+        uint64_t* ev = P.prof + (size_t)gridDim.x * 8 + (size_t)env * 16;  // event counts share the message-class block
+        ev[0] += S.ev_chunks; ev[1] += S.ev_compact; ev[2] += S.ev_ladder; ev[3] += S.ev_exec_levels; ev[4] += S.ev_rare;
+#ifdef LOBSIM_PROFILE_MSG
         uint64_t* pm = P.prof + (size_t)gridDim.x * 8 + (size_t)env * 16;
-        for (int k = 0; k < 8; k++) { pm[k] += S.pm_cycles[k]; pm[8 + k] += S.pm_count[k]; }
+        for (int k = 0; k < 8; k++) { pm[k] = S.pm_cycles[k]; pm[8 + k] += S.pm_count[k]; }  // (overwrites the event counts)
+#endif
     }
 #endif
 }

@@ -10,9 +10,9 @@ from rl4mm_amd import _capi, _lib
 
 so = ROOT / "gpurun_out" / "liblobsim_prof.so"
 so.parent.mkdir(exist_ok=True)
-subprocess.check_call(["hipcc", *_lib.HIPCC_FLAGS, "-DLOBSIM_PROFILE", "-o", str(so), str(_lib.SOURCES[0])])
+subprocess.check_call(["hipcc", *_lib.HIPCC_FLAGS, "-DLOBSIM_PROFILE", *(["-DLOBSIM_PROFILE_MSG"] if "msg" in sys.argv else []), "-o", str(so), str(_lib.SOURCES[0])])
 b = _capi.Binding(so)
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+N = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 4096
 K = 120
 cfg = _capi.make_cfg(N, 10, bench.default_features(_capi), step_us=100_000, episode_us=1_800_000_000)
 sim = _capi.Sim(b, cfg)
@@ -26,12 +26,15 @@ obs = torch.zeros((N, sim.obs_dim), dtype=torch.float64, device=dev)
 reward = torch.zeros(N, dtype=torch.float64, device=dev); done = torch.zeros(N, dtype=torch.uint8, device=dev)
 out = np.zeros((N, 8), dtype=np.uint64)
 b.lib.lobsim_prof_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+b.lib.lobsim_prof_read_messages.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 tus = ps.msgs[:, 0]
 names = ["load_env", "build_ops", "agent_ops", "messages+resync", "features+reward", "outputs+store"]
 rows = []
 for t in range(K):
     sim.step_device(acts[t].data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr(), 0)
     b.lib.lobsim_prof_read(sim.h, out.ctypes.data, 1)
+    evb = np.zeros((N, 16), dtype=np.uint64)
+    if "msg" not in sys.argv: b.lib.lobsim_prof_read_messages(sim.h, evb.ctypes.data, 1)
     if t < 20: continue
     ph = out[:, :6].astype(np.float64)
     tot = ph.sum(axis=1)
@@ -41,7 +44,7 @@ for t in range(K):
     order = np.argsort(tot)
     i = order[-1]
     rows.append(dict(max=tot[i], mean=tot.mean(), p50=np.median(tot), p99=np.percentile(tot, 99), p999=np.percentile(tot, 99.9), ph_max=ph[i], ph_mean=ph.mean(axis=0), n_max=nmsg[i], n_mean=nmsg.mean(), n_top=nmsg.max(),
-                     cpm=ph[:, 3] / np.maximum(nmsg, 1), nmsg=nmsg.copy(), msgc=ph[:, 3].copy(), tot=tot.copy(), sec=sec_cross.copy(), ops=out[:, 6].astype(float)))
+                     cpm=ph[:, 3] / np.maximum(nmsg, 1), nmsg=nmsg.copy(), msgc=ph[:, 3].copy(), tot=tot.copy(), sec=sec_cross.copy(), ops=out[:, 6].astype(float), ev=evb[:, :5].astype(float), ev_max=evb[i, :5].astype(float)))
 A = lambda k: np.array([r[k] for r in rows])
 print(f"{N} envs, {len(rows)} launches: wave cycles  mean {A('mean').mean():.0f}  p50 {A('p50').mean():.0f}  p99 {A('p99').mean():.0f}  p99.9 {A('p999').mean():.0f}  MAX {A('max').mean():.0f}")
 print(f"messages in the slowest env {A('n_max').mean():.1f} (mean env {A('n_mean').mean():.1f}, busiest env {A('n_top').mean():.1f})")
@@ -56,6 +59,14 @@ print(f"second-boundary steps: share {sc.mean():.3f}; mean total cycles with {tt
 other = tt - mc
 fo = np.polyfit(ops, other, 1)
 print(f"non-message cycles ~ {fo[0]:.0f} * agent_ops + {fo[1]:.0f}; percentiles 50/99/max {np.percentile(other, [50, 99, 100]).round(0).tolist()}; agent ops mean {ops.mean():.1f} max {ops.max():.0f}")
+ev = np.concatenate(A('ev')); evm = np.array([r['ev_max'] for r in rows])
+evn = ["slab chunks read", "compactions", "ladder inserts+removes", "levels swept by executions", "snapshot-head lookups"]
+print("events per env-step (whole step: agent ops + messages):")
+for k, n in enumerate(evn): print(f"  {n:28s} mean env {ev[:, k].mean():7.2f}   slowest env {evm[:, k].mean():7.2f}")
+X = np.column_stack([nm, ev[:, 0], ev[:, 1], ev[:, 2], np.ones(len(nm))])
+coef = np.linalg.lstsq(X, mc, rcond=None)[0]
+print("message-phase cycles ~ " + " + ".join(f"{c:.0f}*{n}" for c, n in zip(coef, ["msgs", "chunks", "compactions", "ladder_ops", "1"])))
+if "msg" not in sys.argv: sys.exit(0)
 pmsg = np.zeros((N, 16), dtype=np.uint64)
 b.lib.lobsim_prof_read_messages.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 b.lib.lobsim_prof_read_messages(sim.h, pmsg.ctypes.data, 0)
