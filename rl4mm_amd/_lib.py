@@ -15,7 +15,10 @@ from . import _capi
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = CSRC / "liblobsim.so"
 SOURCES = [CSRC / "lobsim_kernels.hip", CSRC / "lobsim_host.inc", CSRC / "lobsim_layout.h", CSRC.parent.parent / "include" / "lobsim.h"]
-HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+# -amdgpu-atomic-optimizer-strategy=None: the LDS adds in the kernels are issued by one lane on purpose; the optimizer's
+# wave-reduction prologue (mbcnt / exec juggling, ~12 instructions per add) only costs scalar-unit time there.
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+               "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
 
 _binding = None
 
