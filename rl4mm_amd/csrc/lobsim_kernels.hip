@@ -907,6 +907,14 @@ DI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, i
     while (!S.status) {
         uint64_t bm = ballot(b.t <= until_us);
         int cnt = popc64(bm);  // the stream is time-sorted: the in-window lanes are a prefix
+        // A launch lasts as long as its busiest env.  The instruction arbiter of a SIMD serves its higher-priority
+        // waves first, so the wave with the longest window runs closer to its single-wave speed while its SIMD-mates
+        // (shorter windows, done earlier anyway) take the contention: longest-job-first.  (Thresholds in messages
+        // per window; only the order among the four waves of a SIMD matters.)
+        if (cnt >= 36) __builtin_amdgcn_s_setprio(3);
+        else if (cnt >= 24) __builtin_amdgcn_s_setprio(2);
+        else if (cnt >= 12) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
         for (int j = 0; j < cnt && !S.status; j++) {
             int64_t mm = rl64(b.meta, j);
 #ifdef LOBSIM_PROFILE_MSG
