@@ -53,6 +53,22 @@ def build_stream(sim_seconds):
     return synthetic_stream(20180221, 10, 200.0, 9.5 * 3600 + 1490, 9.5 * 3600 + 1800 + 60 + max(sim_seconds, 105) + 5)
 
 
+def pmc_traffic(n_envs):
+    """HBM bytes per launch of the step kernel from the committed rocprofv3 --pmc passes of this same command
+    (tools/pmc_passes.sh -> profiles/r1/e_pmc_step_kernel.csv; counters cannot be collected from inside the timed
+    run).  FETCH_SIZE / WRITE_SIZE are in KB per dispatch; on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes
+    for wide reads, so it is doubled (MI355X_MICROARCH.md, HBM section): an upper bound for this kernel's mix of
+    8- and 16-byte-per-lane loads.  None when the file is absent or was taken at another batch size."""
+    f = ROOT / "profiles" / "r1" / "e_pmc_step_kernel.csv"
+    try:
+        rows = {r.split(",")[1]: float(r.split(",")[2]) for r in f.read_text().splitlines()[1:] if r.count(",") >= 3}
+        if int(rows["SQ_WAVES"]) != n_envs:
+            return None, None
+        return (2.0 * rows["FETCH_SIZE"] + rows["WRITE_SIZE"]) * 1024.0, str(f.relative_to(ROOT))
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def cpu_baseline(capi, stream, n_envs, n_steps):
     """The CPU oracle (a port: the reference itself is Python and cannot travel) on the host cores, same stream,
     same features, same action distribution."""
@@ -188,6 +204,7 @@ def main():
         achieved = N * b_step / (kernel_ms * 1e-3)
         inv, cash, _ = sim.portfolios()
         st_bad = sum(sim.env_state(int(e))["status"] != 0 for e in range(0, N, max(1, N // 64)))
+        traffic, traffic_src = pmc_traffic(N)
         out = {
             "metric": "env-steps/sec (batched LOB sims)", "value": world * N * K / elapsed, "unit": "env-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
@@ -200,7 +217,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
-                "traffic": None, "kernel": "lob_step_kernel", "kernel_ms": kernel_ms, "kernel_ms_sampled_pairs": kernel_ms_sampled, "algorithmic_bytes_per_env_step": round(b_step, 1),
+                "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src, "kernel": "lob_step_kernel", "kernel_ms": kernel_ms, "kernel_ms_sampled_pairs": kernel_ms_sampled, "algorithmic_bytes_per_env_step": round(b_step, 1),
             },
         }  # fmt: skip
         out["open_loop_rollout"] = {
