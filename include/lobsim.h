@@ -87,6 +87,11 @@ typedef struct lobsim_feature {
     double min_value, max_value;
     double dparam;  /* EpisodeProportion: update_frequency / episode_length (Features.py:505) */
     int64_t iparam; /* TimeOfDay: bucket size in us (Features.py:528); AmihudLambda: slowing_factor */
+    /* normalisation_on (Features.py:60-74): > 0 = capacity of the value history (deque(maxlen=max_norm_len)); every
+     * update then returns scipy.stats.zscore(history)[-1], an O(len) pass in numpy's summation order.  0 = off (the
+     * reference's default).  Memory: 8 * norm_len bytes per env and feature - pass the number of updates an episode
+     * plus its warm-up can make when that is smaller than max_norm_len (the history is cleared at every reset). */
+    int64_t norm_len;
 } lobsim_feature;
 
 enum lobsim_reward_kind {

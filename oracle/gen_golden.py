@@ -292,6 +292,7 @@ def feature_desc(f):
     d = dict(
         kind=FEATURE_KINDS[type(f).__name__], lookback=int(f.lookback_periods), update_us=int(f.update_frequency / timedelta(microseconds=1)),
         min_value=float(f.min_value), max_value=float(f.max_value), dparam=0.0, iparam=0,
+        norm_len=int(f.max_norm_len) if f.normalisation_on else 0,
     )  # fmt: skip
     if isinstance(f, EpisodeProportion):
         d["dparam"] = float(f.step_size)
@@ -560,6 +561,15 @@ def main():
         # AUM <= 0 once the window is long enough to be evaluated: get_sharpe raises
         run_trajectory("synth_sharpe_crash", db_s, "SYN", sdate, 10, short(), fixed_agent([1, 1, 1, 1]), 1, [35925], 10.0, step_reward=("RS", 16, 5), terminal_reward="PnL",
                        initial=(0, 0), stream_file="synth_small")  # fmt: skip
+        # normalisation_on (Features.py:67-74): z-scores over the growing history; Spread's max_norm_len=40 makes its deque
+        # wrap, two episodes show the history being cleared by reset (the 20 s warm-up replays with normalisation too)
+        normed = lambda: [Spread(normalisation_on=True, max_norm_len=40), PriceMove(name="pm1", update_frequency=timedelta(seconds=0.1), lookback_periods=1, normalisation_on=True),  # noqa: E731
+                          Volatility(name="v", update_frequency=timedelta(seconds=0.1), lookback_periods=20, normalisation_on=True), Inventory(normalisation_on=True),
+                          EpisodeProportion(update_frequency=timedelta(seconds=0.1), episode_length=timedelta(seconds=15), normalisation_on=True), TimeOfDay(normalisation_on=True),
+                          TradeDirectionImbalance(update_frequency=timedelta(seconds=0.1), lookback_periods=30, normalisation_on=True),
+                          TradeVolumeImbalance(update_frequency=timedelta(seconds=0.2), lookback_periods=30, normalisation_on=True)]  # fmt: skip
+        run_trajectory("synth_norm", db_s, "SYN", sdate, 10, normed(), random_agent(33, high=20.0), 2, [35925, 35945], 15.0, step_reward="PnL", terminal_reward="PnL",
+                       enter_spread=True, initial=(5, 10**9), stream_file="synth_small")  # fmt: skip
         run_trajectory("synth_q5_fixed", db_s, "SYN", sdate, 10, short(), fixed_agent([2, 5, 5, 2]), 1, [36010], 20.0, minq=2, maxq=7, stream_file="synth_small")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

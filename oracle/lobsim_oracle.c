@@ -103,6 +103,9 @@ typedef struct {
     double partial_price_sum;
     int64_t partial_dollar_volume;
     int steps_until_update;
+    /* normalisation history, deque(maxlen=max_norm_len) (Features.py:60-61): oldest first */
+    double* hist;
+    int64_t n_hist;
 } Feature;
 
 typedef struct {
@@ -591,8 +594,9 @@ static void feature_alloc(Feature* f) {
     f->buys = (int64_t*)calloc((size_t)lb + 1, 8);
     f->sells = (int64_t*)calloc((size_t)lb + 1, 8);
     f->dvols = (int64_t*)calloc((size_t)lb + 1, 8);
+    f->hist = f->d.norm_len > 0 ? (double*)calloc((size_t)f->d.norm_len, sizeof(double)) : NULL;
 }
-static void feature_free(Feature* f) { free(f->prices); free(f->buys); free(f->sells); free(f->dvols); }
+static void feature_free(Feature* f) { free(f->prices); free(f->buys); free(f->sells); free(f->dvols); free(f->hist); }
 
 static void trades_append(Feature* f, int64_t b, int64_t s) { /* deque(maxlen=lookback).append */
     int lb = f->d.lookback;
@@ -746,7 +750,49 @@ static int feature_raw_update(const oracle_t* h, Env* e, Feature* f) {
     return 0;
 }
 
+/* numpy's add.reduce over a contiguous f64 vector of any length, optionally of (x - mean)^2: pairwise summation
+ * (8 accumulators up to 128 elements, halves rounded down to a multiple of 8 above) inside chunks of the ufunc
+ * buffer size (np.getbufsize() = 8192 elements), the chunks added left to right.  Checked against numpy for lengths
+ * up to 1e5 (oracle/gen_golden.py pins it through scipy.stats.zscore). */
+static double np_pw(const double* a, int64_t n, int centered, double mean) {
+#define NPT(i) (centered ? (a[i] - mean) * (a[i] - mean) : a[i])
+    if (n < 8) { double r = 0.; for (int64_t i = 0; i < n; i++) r += NPT(i); return r; }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; j++) r[j] = NPT(j);
+        int64_t i;
+        for (i = 8; i < n - (n % 8); i += 8) for (int j = 0; j < 8; j++) r[j] += NPT(i + j);
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += NPT(i);
+        return res;
+    }
+#undef NPT
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pw(a, n2, centered, mean) + np_pw(a + n2, n - n2, centered, mean);
+}
+static double np_sum(const double* a, int64_t n, int centered, double mean) {
+    double total = 0.;
+    for (int64_t off = 0; off < n; off += 8192) total = total + np_pw(a + off, n - off < 8192 ? n - off : 8192, centered, mean);
+    return total;
+}
+
+/* Feature.normalise (Features.py:67-74): history.append(value) [preceded by value + 1e-06 when the history is empty],
+ * then scipy.stats.zscore(history)[-1] = (value - mean) / std with numpy's mean and std(ddof=0). */
+static double feature_normalise(Feature* f, double value) {
+    const int64_t cap = f->d.norm_len;
+    for (int k = f->n_hist == 0 ? 0 : 1; k < 2; k++) {
+        if (f->n_hist == cap) { memmove(f->hist, f->hist + 1, sizeof(double) * (size_t)(cap - 1)); f->n_hist--; }
+        f->hist[f->n_hist++] = k == 0 ? value + 1e-06 : value;
+    }
+    const int64_t n = f->n_hist;
+    const double mean = np_sum(f->hist, n, 0, 0.) / (double)n;
+    const double var = np_sum(f->hist, n, 1, mean) / (double)n;
+    return (value - mean) / sqrt(var);
+}
+
 static void feature_reset(const oracle_t* h, Env* e, Feature* f, int64_t first_usage_us) { /* reset/_reset, :92-96 */
+    f->n_hist = 0; /* history.clear() */
     f->n_prices = 0; f->n_trades = 0; f->total = 0; f->diff = 0;
     f->n_dvols = 0; f->partial_price_sum = 0; f->partial_dollar_volume = 0;
     f->steps_until_update = f->d.kind == LOBSIM_F_AMIHUD_LAMBDA ? (int)f->d.iparam - 1 : 0; /* :278-283 */
@@ -760,6 +806,7 @@ static void feature_update(const oracle_t* h, Env* e, Feature* f) { /* update, :
     if ((e->now_us % 60000000ll) % f->d.update_us != 0) return;
     if (!feature_raw_update(h, e, f)) { e->status |= LOBSIM_ST_EMPTY_BOOK; return; }
     f->current_value = clampd(f->current_value, f->d.min_value, f->d.max_value);
+    if (f->d.norm_len > 0) f->current_value = feature_normalise(f, f->current_value); /* :86 */
 }
 
 /* ------------------------------------------------------------------------------------------------------------

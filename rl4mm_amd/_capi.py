@@ -34,6 +34,7 @@ class FeatureDesc(C.Structure):
         ("max_value", C.c_double),
         ("dparam", C.c_double),
         ("iparam", C.c_int64),
+        ("norm_len", C.c_int64),
     ]
 
 
@@ -164,8 +165,8 @@ class Binding:
             self.fn[name] = f
 
 
-def make_feature(kind, lookback=0, update_us=100_000, min_value=0.0, max_value=0.0, dparam=0.0, iparam=0) -> FeatureDesc:
-    return FeatureDesc(int(kind), int(lookback), int(update_us), float(min_value), float(max_value), float(dparam), int(iparam))
+def make_feature(kind, lookback=0, update_us=100_000, min_value=0.0, max_value=0.0, dparam=0.0, iparam=0, norm_len=0) -> FeatureDesc:
+    return FeatureDesc(int(kind), int(lookback), int(update_us), float(min_value), float(max_value), float(dparam), int(iparam), int(norm_len))
 
 
 def make_cfg(

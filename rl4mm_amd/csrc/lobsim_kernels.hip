@@ -1102,7 +1102,74 @@ DI bool feature_raw(const lobsim_feature& d, FeatState& f, int64_t* ring, const 
     return false;
 }
 
-DI bool feature_reset(const lobsim_feature& d, FeatState& f, int64_t* ring, const StepView& v, int64_t first_usage) {  // _reset, :92-96
+// lane f's normalisation history, or null when feature f is not normalised
+DI double* norm_history(const DevCfg& C, const DevPtrs& P, int env, int f) {
+    if (!P.norm || f >= C.c.n_features || C.c.features[f].norm_len <= 0) return nullptr;
+    return P.norm + (size_t)env * C.norm_words + C.norm_off[f];
+}
+
+// ---- normalisation_on (Features.py:60-74): z-score of the newest value against the feature's whole history.
+// numpy's add.reduce over n contiguous f64 values, optionally of (x - mean)^2: pairwise summation (8 accumulators up to
+// 128 elements, halves rounded down to a multiple of 8 above) inside chunks of the ufunc buffer size (8192 elements)
+// that are added left to right.  The history is a ring (deque(maxlen)): element i is a[(start + i) mod cap].  One lane
+// per feature walks it serially, as everywhere in the feature phase; the explicit stacks make this the part of the
+// EXTRAS kernel variants that uses private memory.
+DI double np_leaf_ring(const double* a, int cap, int first, int n, bool centered, double mean) {
+    auto at = [&](int i) { int k = first + i; k = k >= cap ? k - cap : k; const double x = a[k]; return centered ? (x - mean) * (x - mean) : x; };
+    if (n < 8) { double r = 0.; for (int i = 0; i < n; i++) r += at(i); return r; }
+    double r0 = at(0), r1 = at(1), r2 = at(2), r3 = at(3), r4 = at(4), r5 = at(5), r6 = at(6), r7 = at(7);
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) { r0 += at(i); r1 += at(i + 1); r2 += at(i + 2); r3 += at(i + 3); r4 += at(i + 4); r5 += at(i + 5); r6 += at(i + 6); r7 += at(i + 7); }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; i++) res += at(i);
+    return res;
+}
+DI double np_sum_ring(const double* a, int cap, int start, int n, bool centered, double mean) {
+    double total = 0.;
+    for (int coff = 0; coff < n; coff += 8192) {
+        // depth-first over the pairwise tree of this chunk; `red` = additions owed once the subtree's sum is known
+        int off[8], len[8], red[8], sp = 1, vp = 0;
+        double val[9];
+        off[0] = coff; len[0] = n - coff < 8192 ? n - coff : 8192; red[0] = 0;
+        while (sp) {
+            sp--;
+            const int o = off[sp], l = len[sp];
+            int r = red[sp];
+            if (l > 128) {
+                int n2 = l / 2;
+                n2 -= n2 % 8;
+                off[sp] = o + n2; len[sp] = l - n2; red[sp] = r + 1; sp++;  // right half: completes this node
+                off[sp] = o; len[sp] = n2; red[sp] = 0; sp++;               // left half first
+                continue;
+            }
+            int first = start + o;
+            first = first >= cap ? first - cap : first;
+            val[vp++] = np_leaf_ring(a, cap, first, l, centered, mean);
+            for (; r > 0; r--) { vp--; val[vp - 1] = val[vp - 1] + val[vp]; }
+        }
+        total = total + val[0];
+    }
+    return total;
+}
+// Feature.normalise: history.append(value) [preceded by value + 1e-06 when the history is empty], then
+// scipy.stats.zscore(history)[-1] = (value - mean) / std, numpy mean and std(ddof=0).  hist[0] = count | start << 32.
+DI double feature_normalise(double* hist, int cap, double value) {
+    int64_t* hw = reinterpret_cast<int64_t*>(hist);
+    int n = (int)(hw[0] & 0xffffffff), start = (int)(hw[0] >> 32);
+    double* a = hist + 1;
+    for (int k = n == 0 ? 0 : 1; k < 2; k++) {
+        const double x = k == 0 ? value + 1e-06 : value;
+        if (n == cap) { a[start] = x; start = start + 1 == cap ? 0 : start + 1; }  // the oldest value falls out
+        else { int idx = start + n; idx = idx >= cap ? idx - cap : idx; a[idx] = x; n++; }
+    }
+    hw[0] = (int64_t)n | ((int64_t)start << 32);
+    const double mean = np_sum_ring(a, cap, start, n, false, 0.) / (double)n;
+    const double var = np_sum_ring(a, cap, start, n, true, mean) / (double)n;
+    return (value - mean) / sqrt(var);
+}
+
+DI bool feature_reset(const lobsim_feature& d, FeatState& f, int64_t* ring, const StepView& v, int64_t first_usage, double* hist) {  // _reset, :92-96
+    if (hist) reinterpret_cast<int64_t*>(hist)[0] = 0;  // history.clear()
     f.count = 0; f.pos = 0; f.total = 0; f.diff = 0; f.acc = 0.0; f.p_first = 0.0; f.p_last = 0.0;
     f.first_usage_us = first_usage;
     if (d.kind == LOBSIM_F_AMIHUD_LAMBDA) f.diff = d.iparam - 1;  // steps_until_update (Features.py:278-283)
@@ -1111,11 +1178,14 @@ DI bool feature_reset(const lobsim_feature& d, FeatState& f, int64_t* ring, cons
     return ok;
 }
 
-DI bool feature_update(const lobsim_feature& d, FeatState& f, int64_t* ring, const StepView& v) {  // update, :80-86
+template <bool EXTRAS>
+DI bool feature_update(const lobsim_feature& d, FeatState& f, int64_t* ring, const StepView& v, double* hist) {  // update, :80-86
     if (v.now_us < f.first_usage_us) return true;
     if (d.update_us <= 0xffffffffll ? (v.now_mod_min % (uint32_t)d.update_us != 0) : ((int64_t)v.now_mod_min % d.update_us != 0)) return true;  // _now_is_multiple_of_update_freq
     if (!feature_raw(d, f, ring, v)) return false;
     f.current_value = clampd(f.current_value, d.min_value, d.max_value);
+    if constexpr (EXTRAS)
+        if (hist) f.current_value = feature_normalise(hist, (int)d.norm_len, f.current_value);  // :86
     return true;
 }
 
@@ -1179,12 +1249,12 @@ DI double rolling_sharpe(Lds& L, Scal& S, const lobsim_reward& r, double* st, in
 }
 
 // per-step reward and, when the episode ends here, the terminal reward (HistoricalOrderbookEnvironment.py:169-176)
-// SHARPE selects the kernel variant that carries the RollingSharpe code: configurations without it (the default
+// EXTRAS selects the kernel variant that carries the RollingSharpe and the normalisation code: configurations without them (the default
 // rewards are PnL / inventory-adjusted PnL) run a variant whose register allocation does not pay for it.
-template <bool SHARPE>
+template <bool EXTRAS>
 DI double step_reward(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, int env, bool terminal, int64_t inv0, int64_t cash0, double p0, double price) {
     const lobsim_reward& r = terminal ? C.c.terminal_reward : C.c.per_step_reward;
-    if constexpr (SHARPE)
+    if constexpr (EXTRAS)
         if (r.kind == LOBSIM_R_ROLLING_SHARPE)
             return rolling_sharpe(L, S, r, P.sharpe + ((size_t)env * 2 + (terminal ? 1 : 0)) * (1 + LOBSIM_SHARPE_MAX_WINDOW), cur_cash(L), cur_inv(L), price);
     return reward_of(r, inv0, cash0, p0, cur_inv(L), cur_cash(L), price);
@@ -1335,7 +1405,7 @@ struct ResetArgs {
 #ifndef LOBSIM_STEP_WAVES
 #define LOBSIM_STEP_WAVES 4  // waves per SIMD the step kernel is register-budgeted for (4 = 16 envs per CU)
 #endif
-template <bool SHARPE>
+template <bool EXTRAS>
 __global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg C, DevPtrs P, StepArgs A) {
     __shared__ Lds L;
     const int env = blockIdx.x, ln = lane();
@@ -1385,13 +1455,13 @@ __global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg 
         if (!S.status) {
             StepView v = make_view(L, S, price, now);
             bool ok = true;
-            if (ln < F) ok = feature_update(C.c.features[ln], fs, P.rings + (size_t)env * C.ring_words + C.ring_off[ln], v);
+            if (ln < F) ok = feature_update<EXTRAS>(C.c.features[ln], fs, P.rings + (size_t)env * C.ring_words + C.ring_off[ln], v, norm_history(C, P, env, ln));
             if (ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
         }
         if (!S.status) {
-            reward = step_reward<SHARPE>(L, S, C, P, env, false, inv0, cash0, p0, price);
+            reward = step_reward<EXTRAS>(L, S, C, P, env, false, inv0, cash0, p0, price);
             if (2 * (H.terminal_us - now) < C.c.step_us) {  // terminal_time - now < step_size / 2 (:172-174)
-                reward = step_reward<SHARPE>(L, S, C, P, env, true, inv0, cash0, p0, price);
+                reward = step_reward<EXTRAS>(L, S, C, P, env, true, inv0, cash0, p0, price);
                 done = 1;
             }
         }
@@ -1470,7 +1540,7 @@ DI Act5 teradactyl_action(const double* p, double inventory) {
 // generate_trajectory (rl4mm/gym/utils.py:100-117) for open-loop / rule-based agents: up to T env.step()s per env in
 // one launch.  Every wave runs its env's steps back to back, so a launch no longer lasts as long as the busiest env of
 // EACH step, and the ladder / agent orders / feature scalars stay in LDS / registers between steps.
-template <bool SHARPE>
+template <bool EXTRAS>
 __global__ __launch_bounds__(64, 3) void lob_rollout_kernel(DevCfg C, DevPtrs P, RolloutArgs A) {
     __shared__ Lds L;
     const int env = blockIdx.x, ln = lane();
@@ -1511,13 +1581,13 @@ __global__ __launch_bounds__(64, 3) void lob_rollout_kernel(DevCfg C, DevPtrs P,
         if (!S.status) {
             StepView v = make_view(L, S, price, now);
             bool ok = true;
-            if (ln < F) ok = feature_update(C.c.features[ln], fs, ring, v);
+            if (ln < F) ok = feature_update<EXTRAS>(C.c.features[ln], fs, ring, v, norm_history(C, P, env, ln));
             if (ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
         }
         if (!S.status) {
-            reward = step_reward<SHARPE>(L, S, C, P, env, false, inv0, cash0, p0, price);
+            reward = step_reward<EXTRAS>(L, S, C, P, env, false, inv0, cash0, p0, price);
             if (2 * (H.terminal_us - now) < C.c.step_us) {
-                reward = step_reward<SHARPE>(L, S, C, P, env, true, inv0, cash0, p0, price);
+                reward = step_reward<EXTRAS>(L, S, C, P, env, true, inv0, cash0, p0, price);
                 done = 1;
             }
         }
@@ -1548,6 +1618,7 @@ __global__ __launch_bounds__(64, 3) void lob_rollout_kernel(DevCfg C, DevPtrs P,
 
 // env.reset(): snapshot book at (episode_start - warmup), features reset, warm-up replay without agent orders
 // (HistoricalOrderbookEnvironment.py:147-161)
+template <bool EXTRAS>
 __global__ __launch_bounds__(64, 4) void lob_reset_kernel(DevCfg C, DevPtrs P, ResetArgs A) {
     __shared__ Lds L;
     const int k = blockIdx.x, ln = lane();
@@ -1589,7 +1660,7 @@ __global__ __launch_bounds__(64, 4) void lob_reset_kernel(DevCfg C, DevPtrs P, R
         bool ok = true;
         if (ln < F) {
             const lobsim_feature& d = C.c.features[ln];
-            ok = feature_reset(d, fs, ring, v, start - (int64_t)d.lookback * d.update_us);
+            ok = feature_reset(d, fs, ring, v, start - (int64_t)d.lookback * d.update_us, norm_history(C, P, env, ln));
         }
         if (ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
     }
@@ -1600,7 +1671,7 @@ __global__ __launch_bounds__(64, 4) void lob_reset_kernel(DevCfg C, DevPtrs P, R
         if (S.status) break;
         StepView v = make_view(L, S, price, now);
         bool ok = true;
-        if (ln < F) ok = feature_update(C.c.features[ln], fs, ring, v);
+        if (ln < F) ok = feature_update<EXTRAS>(C.c.features[ln], fs, ring, v, norm_history(C, P, env, ln));
         if (ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
     }
     if (ln < D && A.obs) A.obs[(size_t)k * D + ln] = ln < F ? fs.current_value : 0.0;  // zeros for the previous action (:158-159)

@@ -102,6 +102,8 @@ struct DevCfg {
     int32_t obs_dim;
     int32_t ring_off[LOBSIM_MAX_FEATURES];  // offset of feature f's ring (in 8-byte words) inside an env's ring block
     int32_t ring_words;         // ring words per env
+    int32_t norm_off[LOBSIM_MAX_FEATURES];  // offset (8-byte words) of feature f's normalisation history inside an env's block
+    int32_t norm_words;                     // history words per env (0: no feature is normalised)
     // ln(x_k), ln(1 - x_k) at the Q quote-level midpoints x_k = (k + 0.5) / Q: Beta pdf = exp((a-1) ln x + (b-1) ln(1-x))
     double log_x[QMAX], log_1mx[QMAX];
 };
@@ -116,6 +118,7 @@ struct DevPtrs {
     int64_t* rings;    // [env][ring_words]
     const StreamDev* streams;
     int32_t n_streams;
+    double* norm;      // [env][norm_words]: per normalised feature one header word (count | start << 32) + norm_len values
     double* sharpe;    // [env][2][1 + LOBSIM_SHARPE_MAX_WINDOW] RollingSharpe windows (per-step / terminal), or null when unused
     uint64_t* prof;    // [env][8] phase cycle sums; only a -DLOBSIM_PROFILE diagnostic build allocates and writes it
 };

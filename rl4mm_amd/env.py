@@ -73,18 +73,26 @@ class Feature:
 
     def __init__(self, name, min_value, max_value, update_frequency, lookback_periods, normalisation_on=False, max_norm_len=10000):
         assert update_frequency <= timedelta(minutes=1), "HFT update frequency must be less than 1 minute."  # Features.py:53
-        if normalisation_on:
-            raise NotImplementedError("z-score normalisation (Features.py:67-74) is not on the device path yet")
         self.name, self.min_value, self.max_value = name, min_value, max_value
         self.update_frequency, self.lookback_periods = update_frequency, lookback_periods
-        self.normalisation_on = normalisation_on
+        self.normalisation_on, self.max_norm_len = normalisation_on, max_norm_len  # Features.py:56-61
 
     @property
     def window_size(self) -> timedelta:
         return self.lookback_periods * self.update_frequency
 
     def desc(self) -> _capi.FeatureDesc:
-        return _capi.make_feature(self.kind, self.lookback_periods, _us(self.update_frequency), self.min_value, self.max_value)
+        return _capi.make_feature(self.kind, self.lookback_periods, _us(self.update_frequency), self.min_value, self.max_value,
+                                  norm_len=self.max_norm_len if self.normalisation_on else 0)
+
+    def desc_for(self, horizon_us: int) -> _capi.FeatureDesc:
+        """desc() with the normalisation history sized to what one reset-to-terminal stretch (warm-up + episode) can
+        append: the reference clears the deque at every reset, so a longer max_norm_len is never reached and the
+        device would only reserve memory for it."""
+        d = self.desc()
+        if d.norm_len:
+            d.norm_len = min(d.norm_len, horizon_us // _us(self.update_frequency) + 4)
+        return d
 
 
 class Spread(Feature):  # Features.py:113
@@ -97,8 +105,8 @@ class Spread(Feature):  # Features.py:113
 class BookImbalance(Feature):  # :132
     kind = _capi.F_BOOK_IMBALANCE
 
-    def __init__(self, update_frequency=timedelta(seconds=0.1)):
-        super().__init__("BookImbalance", -1, 1, update_frequency, 0, False, 0)
+    def __init__(self, update_frequency=timedelta(seconds=0.1), normalisation_on=False, max_norm_len=10000):
+        super().__init__("BookImbalance", -1, 1, update_frequency, 0, normalisation_on, max_norm_len)
 
 
 class PriceMove(Feature):  # :151
@@ -429,7 +437,7 @@ class HistoricalOrderbookVectorEnv:
         self.observation_space = Box(low=low, high=high, dtype=np.float32)  # :125-135
         self.max_feature_window_size = max(f.window_size for f in self.features)
         cfg = _capi.make_cfg(
-            num_envs, n_levels, [f.desc() for f in self.features], step_us=_us(step_size), episode_us=_us(episode_length),
+            num_envs, n_levels, [f.desc_for(_us(self.max_feature_window_size) + _us(episode_length)) for f in self.features], step_us=_us(step_size), episode_us=_us(episode_length),
             warmup_us=_us(self.max_feature_window_size), outer_levels=outer_levels, min_quote_level=min_quote_level, max_quote_level=max_quote_level,
             concentration=concentration, market_order_clearing=market_order_clearing, market_order_fraction_of_inventory=market_order_fraction_of_inventory,
             enter_spread=enter_spread, inc_prev_action_in_obs=inc_prev_action_in_obs, per_step_reward=self.per_step_reward_function.desc(),

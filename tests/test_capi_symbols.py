@@ -24,9 +24,9 @@ def test_library_exports_every_symbol():
 def test_struct_sizes_match_header():
     import ctypes as C
 
-    assert C.sizeof(_capi.FeatureDesc) == 48
+    assert C.sizeof(_capi.FeatureDesc) == 56
     assert C.sizeof(_capi.RewardDesc) == 24
-    assert C.sizeof(_capi.Cfg) == 14 * 4 + 3 * 8 + 2 * 8 + 2 * 24 + 16 * 48
+    assert C.sizeof(_capi.Cfg) == 14 * 4 + 3 * 8 + 2 * 8 + 2 * 24 + 16 * 56
     assert C.sizeof(_capi.EnvState) == 11 * 8 + 6 * 4 + 7 * 8
     assert C.sizeof(_capi.OrderView) == 24
 

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 RTOL, ATOL = 1e-12, 1e-9
 TRAJ = ["msft_fixed", "msft_teradactyl_ad", "msft_random_allfeat", "synth_default_random", "synth_teradactyl_ad_spread", "synth_amihud", "synth_info_moc", "synth_info_spread",
-        "synth_moc_conc", "synth_moc_crash", "synth_q5_fixed"]  # fmt: skip
+        "synth_moc_conc", "synth_moc_crash", "synth_q5_fixed", "synth_norm"]  # fmt: skip
 
 
 def _small_cfg(n_envs=1, n_levels=8, **kw):
@@ -98,6 +98,36 @@ def test_rolling_sharpe_batch_matches_oracle():
     assert np.array_equal(i0, i1) and np.array_equal(c0, c1) and np.array_equal(p0, p1)
     assert (r1 != 0).mean() > 0.5
     assert np.allclose(r0, r1, rtol=1e-6, atol=1e-12), np.abs(r0 - r1).max()
+
+
+def test_normalised_features_batch_matches_oracle():
+    """normalisation_on (Features.py:60-74) on 96 envs x 120 steps, random actions and start times, histories that wrap
+    (Spread, 40 values) and histories that only grow: every observation bit-exact against the oracle (which is pinned to
+    the reference by the synth_norm trajectory), NaNs of constant histories included."""
+    g, _ = ol.load_traj("synth_norm")
+    g = dict(g, features=[dict(f, norm_len=min(f["norm_len"], 600)) for f in g["features"]])
+    n, T = 96, 120
+    cfg = ol.cfg_from_golden(g, n_envs=n)
+    ps = ol.golden_stream(g["stream_file"])
+    rng = np.random.default_rng(11)
+    starts = (35925 + rng.integers(0, 20, n)) * 10**6
+    actions = rng.uniform(0.5, 20.0, (T, n, g["action_dim"]))
+    outs = []
+    for make in (_lib.new_sim, ol.oracle_sim):
+        sim = make(cfg)
+        sid = sim.add_stream(ps)
+        sim.set_portfolio(np.full(n, 5, dtype=np.int64), np.full(n, 10**9, dtype=np.int64))
+        obs = [sim.reset(starts, np.full(n, sid, dtype=np.int32)).copy()]
+        for t in range(T):
+            o, r, d = sim.step(actions[t])
+            obs.append(o.copy())
+            if d.any():
+                idx = np.flatnonzero(d).astype(np.int32)
+                sim.reset(starts[idx], np.full(len(idx), sid, dtype=np.int32), env_ids=idx)
+        outs.append(np.array(obs))
+        sim.close()
+    assert np.isfinite(outs[1]).mean() > 0.5
+    assert np.array_equal(outs[0], outs[1], equal_nan=True), np.nanmax(np.abs(outs[0] - outs[1]))
 
 
 def test_beta_volumes_match_scipy_table():
@@ -290,6 +320,48 @@ def test_env_facade_reproduces_reference_trajectory():
         k += n
     inv, cash, _ = e._venv.portfolios()
     assert inv[0] == z["inventory"][-1] and cash[0] == z["cash"][-1]
+    e.close()
+
+
+def test_env_facade_normalised_features_and_sharpe_reward():
+    """`-n True` and `-psr RS` through the Gym surface: feature classes built with normalisation_on=True (history sized by
+    the env to warm-up + episode), the reference's normalised trajectory replayed action by action; then an env with the
+    RollingSharpe reward object steps without error flags."""
+    from datetime import datetime, timedelta
+
+    from rl4mm_amd import env as E
+
+    g, z = ol.load_traj("synth_norm")
+    cat = E.StreamCatalog().add(ol.golden_stream("synth_small"))
+    ms = timedelta(seconds=0.1)
+    feats = [E.Spread(normalisation_on=True, max_norm_len=40), E.PriceMove(name="pm1", update_frequency=ms, lookback_periods=1, normalisation_on=True),
+             E.Volatility(name="v", update_frequency=ms, lookback_periods=20, normalisation_on=True), E.Inventory(normalisation_on=True),
+             E.EpisodeProportion(update_frequency=ms, episode_length=timedelta(seconds=15), normalisation_on=True), E.TimeOfDay(normalisation_on=True),
+             E.TradeDirectionImbalance(update_frequency=ms, lookback_periods=30, normalisation_on=True),
+             E.TradeVolumeImbalance(update_frequency=timedelta(seconds=0.2), lookback_periods=30, normalisation_on=True)]  # fmt: skip
+    start = timedelta(microseconds=g["starts_us"][0])
+    e = E.HistoricalOrderbookEnvironment(
+        catalog=cat, features=feats, ticker="SYN", step_size=ms, episode_length=timedelta(seconds=15), min_date=datetime(2018, 2, 21), max_date=datetime(2018, 2, 21),
+        min_start_timedelta=start, max_end_timedelta=start + timedelta(seconds=15), n_levels=10, enter_spread=True, initial_portfolio=E.Portfolio(inventory=5, cash=10**9),
+        per_step_reward_function=E.get_reward_function("PnL"), terminal_reward_function=E.get_reward_function("PnL"),
+    )  # fmt: skip
+    assert 0 < e._venv.sim.cfg.features[1].norm_len <= 400  # capped to what warm-up + episode can append
+    obs = e.reset()
+    assert np.array_equal(obs, z["reset_obs"][0].astype(obs.dtype), equal_nan=True) or np.allclose(obs, z["reset_obs"][0], rtol=1e-6, equal_nan=True)
+    for k in range(150):
+        obs, reward, done, info = e.step(z["actions"][k])
+        assert np.allclose(obs, z["obs"][k], rtol=1e-6, atol=1e-9, equal_nan=True), k
+        assert reward == z["reward"][k] and done == bool(z["done"][k])
+    assert done
+    e.close()
+    e = E.HistoricalOrderbookEnvironment(
+        catalog=cat, features=[E.Spread(), E.Inventory()], ticker="SYN", step_size=ms, episode_length=timedelta(seconds=15), min_date=datetime(2018, 2, 21),
+        max_date=datetime(2018, 2, 21), min_start_timedelta=start, max_end_timedelta=start + timedelta(seconds=15), n_levels=10,
+        initial_portfolio=E.Portfolio(inventory=5, cash=10**9), per_step_reward_function=E.get_reward_function("RS"), terminal_reward_function=E.get_reward_function("RS"),
+    )  # fmt: skip
+    e.reset()
+    rewards = [e.step(np.array([2.0, 5.0, 2.0, 5.0]))[1] for _ in range(100)]
+    assert all(r == 0 for r in rewards[:59]) and any(r != 0 for r in rewards[59:]) and np.all(np.isfinite(rewards))
     e.close()
 
 

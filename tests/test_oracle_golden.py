@@ -10,7 +10,7 @@ from rl4mm_amd import _capi
 from traj_util import replay_and_check, run_engine_case
 
 TRAJ = ["msft_fixed", "msft_teradactyl_ad", "msft_random_allfeat", "synth_default_random", "synth_teradactyl_ad_spread", "synth_amihud", "synth_info_moc", "synth_info_spread",
-        "synth_moc_conc", "synth_moc_crash", "synth_q5_fixed"]  # fmt: skip
+        "synth_moc_conc", "synth_moc_crash", "synth_q5_fixed", "synth_norm"]  # fmt: skip
 
 
 def _small_cfg(n_levels=8, **kw):
