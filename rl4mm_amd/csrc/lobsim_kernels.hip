@@ -377,12 +377,25 @@ DI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, int
     reduce_slot(L, S, side, idx, m, pos, rv, pv, pk, pid);
 }
 
+// cuts strictly inside the executed interval (from, from + ex) of one resting order (all lanes run the same trip count)
+DI int32_t cuts_inside(const int32_t* cuts, int n_cuts, int32_t from, int32_t ex) {
+    int32_t k = 0;
+    for (int i = 0; i < n_cuts; i++) { const int32_t c = cuts[i]; k += (c > from && c < from + ex) ? 1 : 0; }
+    return k;
+}
+
 // execute_order (Exchange.py:85-120): the aggressor (side, limit price or market) sweeps the opposite side level by
 // level; inside a level all FIFO slots are matched at once with a prefix sum of the volume ahead.  Returns the
 // unfilled remainder.
-DI int32_t execute(Lds& L, Scal& S, int side, bool is_agent, bool is_market, int64_t price, int32_t rem) {
+// `n_cuts` > 0: `rem` is the total of a run of n_cuts + 1 consecutive external market orders on the same side, replayed as
+// one sweep (identical book: each order of the run continues where the previous one stopped); L.cur holds the cumulative
+// volumes at which one order of the run ends and the next begins.  The reference records one fill per (aggressor,
+// resting order) pair, so a resting order whose executed interval contains a cut counts once more per cut.
+DI int32_t execute(Lds& L, Scal& S, int side, bool is_agent, bool is_market, int64_t price, int32_t rem, int n_cuts = 0) {
     const int opp = side ^ 1;
     int ln = lane();
+    const int32_t total = rem;
+    const int32_t* cuts = &L.cur[0][0];
     while (rem > 0) {
         if (S.n_lv[opp] == 0) {
             if (is_market) S.status |= LOBSIM_ST_EMPTY_BOOK;  // EmptyOrderbookError (:180-186); a limit just stops crossing
@@ -424,10 +437,12 @@ DI int32_t execute(Lds& L, Scal& S, int side, bool is_agent, bool is_market, int
                     mask_set(L.agent_pending, (int)rl64(s.id, b));
                 }
                 n_agent += popc64(ballot(reached && is_ag && !own));
+                if (n_cuts) n_agent += wave_sum((reached && is_ag) ? cuts_inside(cuts, n_cuts, total - rem + ahead, ex) : 0);
                 exec_agent += wave_sum((reached && is_ag && !own) ? ex : 0);
                 deleted_agent_vol += wave_sum((reached && own) ? s.vol : 0);
             }
             n_ext += popc64(ballot(reached && !is_ag));
+            if (n_cuts) n_ext += wave_sum((reached && !is_ag) ? cuts_inside(cuts, n_cuts, total - rem + ahead, ex) : 0);
             n_removed += popc64(ballot(gone));
             carry += rl32(incl, 63);
             uint64_t surv = ballot(live && !gone);
@@ -904,6 +919,7 @@ DI MsgBatch fetch_messages(const StreamDev& st, int64_t cursor) {
 // at `cursor`, requested by the caller as early as it knew the cursor (the step kernel asks for it before it builds
 // the agent's orders, so the stream's HBM latency hides behind that work).
 DI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, int64_t until_us, MsgBatch b) {
+    const int ln = lane();
     while (!S.status) {
         uint64_t bm = ballot(b.t <= until_us);
         int cnt = popc64(bm);  // the stream is time-sorted: the in-window lanes are a prefix
@@ -917,6 +933,23 @@ DI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, i
         else __builtin_amdgcn_s_setprio(0);
         for (int j = 0; j < cnt && !S.status; j++) {
             int64_t mm = rl64(b.meta, j);
+            if ((int)((mm >> LOBSIM_TYPE_SHIFT) & 0xf) == LOBSIM_MARKET) {
+                // A marketable order arrives as a run of execution messages, one per resting order it consumed; the
+                // longest windows of a launch are such bursts.  Runs of >= 2 on one side are replayed as one sweep.
+                const int64_t lv = b.meta & LOBSIM_VOL_MASK;
+                const bool same = ln >= j && ln < cnt && (int)((b.meta >> LOBSIM_TYPE_SHIFT) & 0xf) == LOBSIM_MARKET &&
+                                  (((b.meta ^ mm) >> LOBSIM_SIDE_SHIFT) & 1) == 0 && lv > 0 && lv < (1 << 24);
+                const uint64_t sm = ballot(same) >> j;
+                const int run = sm == ~0ull ? 64 - j : ffs64(~sm);  // consecutive lanes from j on
+                if (run >= 2) {
+                    const int32_t pre = wave_incl_scan((ln >= j && ln < j + run) ? (int32_t)lv : 0);
+                    if (ln >= j && ln < j + run - 1) L.cur[0][ln - j] = pre;
+                    wsync();
+                    execute(L, S, (int)((mm >> LOBSIM_SIDE_SHIFT) & 1), false, true, 0, rl32(pre, j + run - 1), run - 1);
+                    j += run - 1;
+                    continue;
+                }
+            }
 #ifdef LOBSIM_PROFILE_MSG
             // classes: 0 limit at an existing level, 1 limit opening a level, 2 crossing limit, 3 cancel, 4 delete,
             // 5 delete/cancel that empties its level, 6 market, 7 other
