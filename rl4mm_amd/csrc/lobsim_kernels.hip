@@ -36,6 +36,9 @@ namespace lobk {
 #define EVENT(field) do { } while (0)
 #endif
 
+#ifndef LOBSIM_TOMB
+#define LOBSIM_TOMB 24  // tombstones a level may hold before its slab is squeezed (measured: 8 .. 128, best 16-32)
+#endif
 struct Op8 {  // one agent order waiting to be processed (built from the pre-step state, then replayed)
     int32_t vol;
     int32_t code;  // type (bits 0-3) | side << 4 | from_agent << 5 | idx << 8; idx = quote level (limit) or agent index
@@ -294,7 +297,7 @@ DI uint64_t compact_level(Lds& L, Scal& S, int side, int idx, uint64_t m) {
 }
 
 DI void level_append(Lds& L, Scal& S, int side, int idx, int64_t id, int32_t vol, int32_t kind, uint64_t m) {
-    if (m_tail(m) == SLOTS || m_tail(m) - m_head(m) - m_live(m) >= 64) {  // full, or a chunk's worth of tombstones
+    if (m_tail(m) == SLOTS || m_tail(m) - m_head(m) - m_live(m) >= LOBSIM_TOMB) {  // full, or a chunk's worth of tombstones
         m = compact_level(L, S, side, idx, m);
         if (m_tail(m) == SLOTS) { S.status |= LOBSIM_ST_QUEUE_OVERFLOW; return; }
     }
@@ -350,11 +353,13 @@ DI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, int
     const Slot* sl = S.slots + (size_t)m_slab(m) * SLOTS;
     int pos = -1;
     int32_t pv = 0;
-    for (int c = head >> 6; c * 64 < tail; c++) {  // independent 1 KiB loads: one ballot per chunk finds the order
+    for (int c = head >> 6; c * 64 < tail; c += 2) {  // 1 KiB chunks, two loads in flight; a ballot per chunk finds the order
         EVENT(ev_chunks);
-        Slot s = load_slot(sl, c * 64 + ln, head, tail);
-        uint64_t b = ballot(s.kind == kind && s.id == id);
-        if (b) { int l = fls64(b); pos = c * 64 + l; pv = rl32(s.vol, l); }
+        const Slot s0 = load_slot(sl, c * 64 + ln, head, tail);
+        const Slot s1 = load_slot(sl, c * 64 + 64 + ln, head, tail);  // beyond the tail: no lane loads
+        const uint64_t b0 = ballot(s0.kind == kind && s0.id == id), b1 = ballot(s1.kind == kind && s1.id == id);
+        if (b0) { int l = fls64(b0); pos = c * 64 + l; pv = rl32(s0.vol, l); }
+        if (b1) { int l = fls64(b1); pos = c * 64 + 64 + l; pv = rl32(s1.vol, l); }
     }
     int32_t pk = kind;
     int64_t pid = id;
@@ -724,7 +729,7 @@ DI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
     const uint64_t m = li >= 0 ? L.meta[side][li] : 0;
     Slot* sl = S.slots + (size_t)m_slab(m) * SLOTS;
     // ---- new orders: append at the tail of an existing level that has room
-    bool lim_ok = is_limit && li >= 0 && m_tail(m) < SLOTS && m_tail(m) - m_head(m) - m_live(m) < 64;
+    bool lim_ok = is_limit && li >= 0 && m_tail(m) < SLOTS && m_tail(m) - m_head(m) - m_live(m) < LOBSIM_TOMB;
     uint64_t lim_mask = ballot(lim_ok);
     int R = popc64(lim_mask);
     uint64_t free0 = lds_u64(L.agent_free[0]), free1 = lds_u64(L.agent_free[1]);
@@ -934,7 +939,7 @@ DI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt, 
     bool cross = false;
     if (is_lim && S.n_lv[side ^ 1] > 0) { const int64_t bp = L.price[side ^ 1][0]; cross = side == LOBSIM_BUY ? b.price >= bp : b.price <= bp; }
     const bool plain = is_lim && vol64 > 0 && vol64 < (1ll << 31) && li >= 0 && !cross && m_live(m) > 0 &&
-                       m_tail(m) <= SLOTS - WAVE && m_tail(m) - m_head(m) - m_live(m) < 64;
+                       m_tail(m) <= SLOTS - WAVE && m_tail(m) - m_head(m) - m_live(m) < LOBSIM_TOMB;
     const uint64_t stop = ballot(in && !(plain || (is_rem && vol64 > 0)));
     seg_end = stop ? ffs64(stop) : cnt;
     const bool app = plain && ln < seg_end;
