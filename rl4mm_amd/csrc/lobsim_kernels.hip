@@ -1068,6 +1068,14 @@ DI double clampd(double x, double lo, double hi) { double m = x < hi ? x : hi; r
 DI bool feature_raw(const lobsim_feature& d, FeatState& f, int64_t* ring, const StepView& v) {
     const int lb = d.lookback;
     double* pr = reinterpret_cast<double*>(ring);
+    // The ring words the steady-state branches below read, requested for all feature lanes at once: the switch runs
+    // one feature kind after the other (each lane group waiting for its own loads), this way the HBM latency is paid
+    // once.  i0 / i1 default to word 0 (always allocated); the branches that do not use them ignore the values.
+    int i0 = 0, i1 = 0;
+    if (d.kind == LOBSIM_F_PRICE_MOVE) { const int cap = lb + 1; i0 = f.count + 1 < cap ? 0 : (f.pos + 1 == cap ? 0 : f.pos + 1); }
+    else if (d.kind == LOBSIM_F_VOLATILITY && f.count > lb) { const int cap = lb + 1; i0 = f.pos; i1 = f.pos + 1 == cap ? 0 : f.pos + 1; }
+    else if ((d.kind == LOBSIM_F_TRADE_DIRECTION_IMBALANCE || d.kind == LOBSIM_F_TRADE_VOLUME_IMBALANCE) && f.count >= lb && lb > 0) { i0 = f.pos; i1 = lb + f.pos; }
+    const int64_t w0 = ring[i0], w1 = ring[i1];
     switch (d.kind) {
     case LOBSIM_F_SPREAD: f.current_value = v.spread; return true;
     case LOBSIM_F_BOOK_IMBALANCE:
@@ -1091,7 +1099,10 @@ DI bool feature_raw(const lobsim_feature& d, FeatState& f, int64_t* ring, const 
         if (f.count < cap) f.count++;
         f.pos = f.pos + 1 == cap ? 0 : f.pos + 1;
         if (d.kind == LOBSIM_F_PRICE_MOVE) {
-            double oldest = pr[f.count < cap ? 0 : f.pos];
+            const int io = f.count < cap ? 0 : f.pos;
+            // (w0 was read before this step's price was stored: when the oldest slot is the one just written - a window
+            // of one value - the value is the new price itself)
+            double oldest = io == (f.pos == 0 ? cap - 1 : f.pos - 1) ? v.price : __longlong_as_double(w0);
             f.current_value = v.price - oldest;
         } else {
             double mx = v.price, mn = v.price;
@@ -1112,8 +1123,8 @@ DI bool feature_raw(const lobsim_feature& d, FeatState& f, int64_t* ring, const 
             f.pos = f.pos + 1 == cap ? 0 : f.pos + 1;
             f.current_value = closing ? f.acc / lb : 0.0;
         } else {
-            double oldest = pr[f.pos];
-            double next_oldest = pr[f.pos + 1 == cap ? 0 : f.pos + 1];
+            double oldest = __longlong_as_double(w0);
+            double next_oldest = __longlong_as_double(w1);
             double old_ret = (next_oldest - oldest) / oldest;
             double new_ret = (v.price - f.p_last) / f.p_last;
             pr[f.pos] = v.price;
@@ -1178,7 +1189,7 @@ DI bool feature_raw(const lobsim_feature& d, FeatState& f, int64_t* ring, const 
             f.pos = f.pos + 1 == lb ? 0 : f.pos + 1;
             f.current_value = 0.0;
         } else {
-            int64_t ob = ring[f.pos], os = ring[lb + f.pos];
+            int64_t ob = w0, os = w1;
             ring[f.pos] = nb; ring[lb + f.pos] = ns;
             f.total += (nb + ns) - (ob + os); f.diff += (nb - ns) - (ob - os);
             f.pos = f.pos + 1 == lb ? 0 : f.pos + 1;
