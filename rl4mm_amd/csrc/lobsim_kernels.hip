@@ -1639,8 +1639,11 @@ DI Act5 teradactyl_action(const double* p, double inventory) {
 // generate_trajectory (rl4mm/gym/utils.py:100-117) for open-loop / rule-based agents: up to T env.step()s per env in
 // one launch.  Every wave runs its env's steps back to back, so a launch no longer lasts as long as the busiest env of
 // EACH step, and the ladder / agent orders / feature scalars stay in LDS / registers between steps.
+#ifndef LOBSIM_ROLLOUT_WAVES
+#define LOBSIM_ROLLOUT_WAVES 4
+#endif
 template <bool EXTRAS>
-__global__ __launch_bounds__(64, 3) void lob_rollout_kernel(DevCfg C, DevPtrs P, RolloutArgs A) {
+__global__ __launch_bounds__(64, LOBSIM_ROLLOUT_WAVES) void lob_rollout_kernel(DevCfg C, DevPtrs P, RolloutArgs A) {
     __shared__ Lds L;
     const int env = blockIdx.x, ln = lane();
     if (A.active && !A.active[env]) return;
@@ -1648,9 +1651,12 @@ __global__ __launch_bounds__(64, 3) void lob_rollout_kernel(DevCfg C, DevPtrs P,
     const int F = C.c.n_features, AD = C.c.action_dim, D = C.obs_dim, N = gridDim.x;
     Scal S;
     load_env(L, S, P, env, H);
-    FeatState fs = FeatState();
-    int64_t* ring = nullptr;
-    if (ln < F) { fs = P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln]; ring = P.rings + (size_t)env * C.ring_words + C.ring_off[ln]; }
+    // Between steps only the ladder / agent state (LDS) and a handful of scalars stay live; the per-feature state is
+    // read and written back around each step's feature phase like in the step kernel (64 B per feature lane).  That
+    // keeps the kernel inside 128 VGPRs with moderate spilling, i.e. four waves per SIMD and all 4096 envs resident at
+    // once: with the earlier 168-VGPR version a quarter of the envs waited for a second round (83 -> 113 M env-steps/s).
+    double fval = 0.0;  // this lane's feature value (the observation entry)
+    if (ln < F) fval = P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln].current_value;
     int64_t now = H.now_us, cursor = H.msg_cursor;
     const int stream_id = H.stream_id;
     Ranges R = {H.min_buy, H.max_sell, H.init_buy_range, H.init_sell_range};
@@ -1667,7 +1673,7 @@ __global__ __launch_bounds__(64, 3) void lob_rollout_kernel(DevCfg C, DevPtrs P,
         } else if (A.policy == LOBSIM_POLICY_FIXED) {
             act.v0 = A.params[0]; act.v1 = A.params[1]; act.v2 = A.params[2]; act.v3 = A.params[3]; act.v4 = A.params[4];
         } else {
-            act = teradactyl_action(A.params, rld(fs.current_value, (int)A.params[5]));  // obs[inventory_index]
+            act = teradactyl_action(A.params, rld(fval, (int)A.params[5]));  // obs[inventory_index]
         }
         clear_step_fills(L);
         const int64_t inv0 = cur_inv(L), cash0 = cur_cash(L);
@@ -1680,7 +1686,12 @@ __global__ __launch_bounds__(64, 3) void lob_rollout_kernel(DevCfg C, DevPtrs P,
         if (!S.status) {
             StepView v = make_view(L, S, price, now);
             bool ok = true;
-            if (ln < F) ok = feature_update<EXTRAS>(C.c.features[ln], fs, ring, v, norm_history(C, P, env, ln));
+            if (ln < F) {
+                FeatState fs = P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln];
+                ok = feature_update<EXTRAS>(C.c.features[ln], fs, P.rings + (size_t)env * C.ring_words + C.ring_off[ln], v, norm_history(C, P, env, ln));
+                P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln] = fs;
+                fval = fs.current_value;
+            }
             if (ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
         }
         if (!S.status) {
@@ -1695,7 +1706,7 @@ __global__ __launch_bounds__(64, 3) void lob_rollout_kernel(DevCfg C, DevPtrs P,
         steps++;
     }
     double val = 0.0;
-    if (ln < F) val = fs.current_value;
+    if (ln < F) val = fval;
     else if (ln < D) val = act_at(act, ln - F);
     if (ln < D) {
         if (A.obs) A.obs[(size_t)env * D + ln] = val;
@@ -1706,7 +1717,6 @@ __global__ __launch_bounds__(64, 3) void lob_rollout_kernel(DevCfg C, DevPtrs P,
         if (A.return_acc) A.return_acc[env] += ret;
         if (A.steps_taken) A.steps_taken[env] = steps;
     }
-    if (ln < F) P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln] = fs;
     store_env(L, S, P, env, H);
     if (ln == 0) {
         H.now_us = now; H.msg_cursor = cursor; H.price = price; H.n_resyncs = n_resyncs;
