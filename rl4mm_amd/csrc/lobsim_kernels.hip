@@ -1366,17 +1366,26 @@ DI void load_env(Lds& L, Scal& S, const DevPtrs& P, int env, const EnvHdr& H) {
     int ln = lane();
     const Ladder& G = P.ladder[env];
     S.n_lv.v = (uint32_t)H.n_lv[0] | ((uint32_t)H.n_lv[1] << 16);
+    // every global load of the common case (<= 64 levels per side) is issued before the first LDS store: one HBM
+    // round trip for the whole env state instead of one per loop
+    const int nb = S.n_lv[0], ns = S.n_lv[1];
+    const bool hb = ln < nb, hs = ln < ns;
+    int64_t pb = 0, psl = 0; uint64_t mb = 0, ms = 0; int32_t vb = 0, vs = 0;
+    if (hb) { pb = G.price[0][ln]; mb = G.meta[0][ln]; vb = G.vol[0][ln]; }
+    if (hs) { psl = G.price[1][ln]; ms = G.meta[1][ln]; vs = G.vol[1][ln]; }
+    const AgentOrd* A = P.agent + (size_t)env * NA;
+    const uint16_t* AP = P.apos + (size_t)env * NA;
+    const AgentOrd a0 = A[ln], a1 = A[ln + 64];
+    const uint16_t q0 = AP[ln], q1 = AP[ln + 64];
+    if (hb) { L.price[0][ln] = pb; L.meta[0][ln] = mb; L.vol[0][ln] = vb; }
+    if (hs) { L.price[1][ln] = psl; L.meta[1][ln] = ms; L.vol[1][ln] = vs; }
+    L.agent[ln] = a0; L.agent[ln + 64] = a1;
+    L.apos[ln] = q0; L.apos[ln + 64] = q1;
 #pragma unroll
     for (int s = 0; s < 2; s++)
-        for (int i = ln; i < S.n_lv[s]; i += 64) {
+        for (int i = ln + 64; i < S.n_lv[s]; i += 64) {
             L.price[s][i] = G.price[s][i]; L.meta[s][i] = G.meta[s][i]; L.vol[s][i] = G.vol[s][i];
         }
-    const AgentOrd* A = P.agent + (size_t)env * NA;
-    L.agent[ln] = A[ln];
-    L.agent[ln + 64] = A[ln + 64];
-    const uint16_t* AP = P.apos + (size_t)env * NA;
-    L.apos[ln] = AP[ln];
-    L.apos[ln + 64] = AP[ln + 64];
     if (ln < NA / 64) L.freed[ln] = 0;
     S.status = H.status; S.n_ops = 0;
     if (ln < NSLAB / 64) L.slab_free[ln] = H.slab_free[ln];
