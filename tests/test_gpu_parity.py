@@ -225,6 +225,84 @@ def test_batch_against_oracle(variant):
     gpu.close()
 
 
+def _dense_stream(kind, n_seconds=14):
+    """Constructed 10-level stream that leans on the lane-parallel replay paths: `pairs` = 48 messages per 100 ms, limit
+    orders cycling over all 20 levels (several per level inside one 64-message batch -> FIFO ranks) each followed by the
+    deletion of the order 40 submissions older at that level; `bursts` = per 100 ms eight limit orders on the three best
+    levels of one side, then a run of twelve executions from the other side (multi-order, multi-level sweeps through the
+    agent's quotes, runs cut by batch boundaries)."""
+    from rl4mm_amd.stream import PackedStream, SIDE_SHIFT, TYPE_SHIFT
+
+    t0, mid, tick, lv = 35_990, 1_000_000, 100, 10
+    rows, oid, hist, rr = [], 1, {}, 0
+    for s in range(n_seconds * 10):
+        base = t0 * 1_000_000 + s * 100_000
+        per = []
+        if kind == "pairs":
+            while len(per) < 48:
+                lvl, side = rr % lv, (rr // lv) % 2
+                rr += 1
+                price = mid - tick * (lvl + 1) if side == 0 else mid + tick * (lvl + 1)
+                q = hist.setdefault((side, lvl), [])
+                per.append((1, side, price, 10 + (oid % 7), oid)); q.append(oid); oid += 1
+                if len(q) > 40:
+                    per.append((3, side, price, 1, q.pop(0)))
+        else:
+            aggr = s % 2  # aggressor side; resting side = aggr ^ 1
+            rest = aggr ^ 1
+            for k in range(8):
+                price = mid - tick * (1 + k % 3) if rest == 0 else mid + tick * (1 + k % 3)
+                per.append((1, rest, price, 50, oid)); oid += 1
+            for k in range(12):
+                per.append((4, aggr, mid, 15 + 10 * (k % 4), 0))
+            per.append((1, aggr, mid - tick * 2 if aggr == 0 else mid + tick * 2, 20, oid)); oid += 1
+        for k, (ty, side, price, vol, o) in enumerate(per):
+            rows.append((base + 1 + (k * 99_000) // len(per), o, price, vol | (ty << TYPE_SHIFT) | (side << SIDE_SHIFT)))
+    msgs = np.array(rows, dtype=np.int64).reshape(-1, 4)
+    secs = np.arange(t0, t0 + n_seconds + 1)
+    snaps = np.zeros((len(secs), 2 + 4 * lv), dtype=np.int64)
+    snaps[:, 0], snaps[:, 1] = secs * 1_000_000, np.arange(len(secs))
+    for i in range(lv):
+        snaps[:, 2 + 4 * i], snaps[:, 3 + 4 * i] = mid + tick * (i + 1), 300
+        snaps[:, 4 + 4 * i], snaps[:, 5 + 4 * i] = mid - tick * (i + 1), 300
+    return PackedStream("SYN", "2018-02-21", lv, msgs, snaps)
+
+
+@pytest.mark.parametrize("kind", ["pairs", "bursts"])
+def test_dense_constructed_streams_against_oracle(kind):
+    """The replay fast paths (plain limit orders booked lane-parallel with FIFO ranks, execution runs replayed as one
+    sweep with the fill pairs recovered from the run's cut points) against the oracle's message-by-message replay:
+    fills, inventory, cash and done per env per step; per-order book contents at the end."""
+    n, steps = 64, 60
+    F = _capi.make_feature
+    feats = [F(_capi.F_SPREAD, 0, 100_000, 0, 1e9), F(_capi.F_INVENTORY, 0, 100_000, -1e9, 1e9), F(_capi.F_TRADE_DIRECTION_IMBALANCE, 20, 100_000, -1, 1),
+             F(_capi.F_TRADE_VOLUME_IMBALANCE, 20, 100_000, -1, 1)]  # fmt: skip
+    cfg = _capi.make_cfg(n, 10, feats, step_us=100_000, episode_us=10_000_000, warmup_us=2_000_000, enter_spread=(kind == "bursts"))
+    ps = _dense_stream(kind)
+    gpu, cpu = _lib.new_sim(cfg), ol.oracle_sim(cfg)
+    rng = np.random.default_rng(77)
+    starts = (35_993 + rng.integers(0, 4, size=n)) * 1_000_000
+    for sim in (gpu, cpu):
+        sim.add_stream(ps)
+        sim.set_portfolio(0, 10**10)
+    assert np.array_equal(gpu.reset(starts, 0), cpu.reset(starts, 0))
+    for t in range(steps):
+        act = rng.uniform(0.5, 12.0, size=(n, cfg.action_dim))
+        og, rg, dg = gpu.step(act)
+        oc, rc, dc = cpu.step(act)
+        assert np.array_equal(dg, dc) and np.array_equal(og, oc, equal_nan=True), f"step {t}"
+        for a, b in zip(gpu.portfolios(), cpu.portfolios()):
+            assert np.array_equal(a, b), f"step {t}"
+        for e in (0, 31, 63):
+            sg, sc = gpu.env_state(e), cpu.env_state(e)
+            for k in ("status", "agent_fill_count", "agent_buy_volume", "agent_sell_volume", "ext_buy_count", "ext_sell_count", "ext_buy_volume", "ext_sell_volume"):
+                assert sg[k] == sc[k], (t, e, k, sg[k], sc[k])
+    assert sum(gpu.env_state(e)["status"] == 0 for e in range(n)) > n // 2
+    for e in (0, 13, 63):
+        assert np.array_equal(gpu.queues(e), cpu.queues(e)), f"env {e}: per-order book contents differ"
+    gpu.close()
+
+
 def test_msft_50_level_replay_against_oracle():
     """The reference's own 50-level test slice: warm-up replay (no agent) then stepping, book compared per order."""
     F = _capi.make_feature
