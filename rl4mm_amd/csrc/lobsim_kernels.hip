@@ -12,6 +12,10 @@
 // orders and the agent op list are staged in LDS for the launch; each price level's FIFO queue is a fixed slab
 // of 16-byte slots in HBM read 1 KiB per wave-instruction.  Lookup by id, "is the head a snapshot order",
 // queue compaction and sweeping a level with a market order are ballot / prefix-sum operations over that slab.
+// The message window of a step is replayed in order, with two wave-level shortcuts that leave the book identical:
+// plain limit orders up to the next "complex" message are appended lane-parallel (append_segment), and a run of
+// execution messages on one side is one sweep (execute with cut points).  Rarely touched per-env scalars live in LDS,
+// not in SGPRs: the CU's single scalar unit is what the 16 resident waves contend for.
 // All arithmetic that the reference does on Python ints is int32/int64 here; everything it does on Python floats
 // is f64 in the same operation order (compile with -ffp-contract=off).
 #include <hip/hip_runtime.h>
