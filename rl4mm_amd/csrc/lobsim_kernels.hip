@@ -41,7 +41,8 @@ namespace lobk {
 #endif
 
 #ifndef LOBSIM_TOMB
-#define LOBSIM_TOMB 24  // tombstones a level may hold before its slab is squeezed (measured: 8 .. 128, best 16-32)
+#define LOBSIM_TOMB 128  // tombstones a level may hold before its slab is squeezed.  Measured 8 .. 384: with queue scans
+                         // on every cancellation the optimum was 16-32; now that the position cache answers most of them, 128
 #endif
 struct Op8 {  // one agent order waiting to be processed (built from the pre-step state, then replayed)
     int32_t vol;
@@ -101,6 +102,7 @@ struct Scal {
     int32_t n_ops;
     int64_t q_buy, q_sell;  // best prices the current op list was built against (_get_best_prices)
     Slot* slots;            // this env's slabs
+    uint64_t* idc;          // this env's position cache of external orders (see IDC_N)
 #ifdef LOBSIM_PROFILE_MSG
     uint64_t pm_cycles[8], pm_count[8];  // per message class (diagnostic build only)
 #endif
@@ -276,6 +278,14 @@ DI Slot load_slot(const Slot* sl, int i, int head, int tail) {
     return dead_slot();
 }
 
+// position cache of external orders: where order `id` was last put.  Written at every append and every squeeze, never
+// cleared; a reader bounds-checks the entry and verifies it against the slot inside the live range of the level that
+// owns the slab, so a stale or aliased entry is only a miss.
+DI uint32_t idc_tag(int64_t id) { return (uint32_t)((uint64_t)id >> 15); }
+DI void idc_put(const Scal& S, int64_t id, int slab, int pos) {
+    S.idc[(uint64_t)id & (IDC_N - 1)] = ((uint64_t)idc_tag(id) << 32) | ((uint64_t)slab << 16) | (uint64_t)pos;
+}
+
 // squeeze tombstones out of a slab (FIFO order kept); chunk by chunk, in place: a chunk's survivors always land
 // at or below the chunk's own first slot, so nothing unread is overwritten.  Returns the new meta word.
 DI uint64_t compact_level(Lds& L, Scal& S, int side, int idx, uint64_t m) {
@@ -293,6 +303,7 @@ DI uint64_t compact_level(Lds& L, Scal& S, int side, int idx, uint64_t m) {
             int np = out + popc64(b & below);
             sl[np] = s;
             if (s.kind == K_AGENT) L.apos[s.id] = (uint16_t)np;
+            if (s.kind == K_EXT) idc_put(S, s.id, slab, np);
         }
         out += popc64(b);
         wsync();
@@ -310,6 +321,7 @@ DI void level_append(Lds& L, Scal& S, int side, int idx, int64_t id, int32_t vol
         Slot s; s.id = id; s.vol = vol; s.kind = kind;
         S.slots[(size_t)m_slab(m) * SLOTS + tail] = s;
         if (kind == K_AGENT) L.apos[id] = (uint16_t)tail;
+        if (kind == K_EXT) idc_put(S, id, m_slab(m), tail);
         L.meta[side][idx] = mk_meta(m_slab(m), live == 0 ? tail : m_head(m), tail + 1, live + 1);
         atomicAdd(&L.vol[side][idx], vol);  // ds_add, no read-modify-write round trip
     }
@@ -924,7 +936,7 @@ DI MsgBatch fetch_messages(const StreamDev& st, int64_t cursor) {
     return b;
 }
 
-// Lane-parallel pass over the messages j0.. of a batch: every plain limit order (rests at an existing level with room,
+// Lane-parallel pass over the messages j0.. of a batch (appends, then cancellations): every plain limit order (rests at an existing level with room,
 // does not cross) up to the first message that is neither that nor a cancellation/deletion is appended at once - lane
 // = message, per-lane binary search of the ladder, FIFO rank among the lanes that hit the same level, slot store and
 // LDS atomics on the level's meta word / volume.  Moving these appends ahead of the cancellations that sit between
@@ -937,14 +949,17 @@ DI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt, 
     const bool in = ln >= j0 && ln < cnt;
     const int type = (int)((b.meta >> LOBSIM_TYPE_SHIFT) & 0xf), side = (int)((b.meta >> LOBSIM_SIDE_SHIFT) & 1);
     const int64_t vol64 = b.meta & LOBSIM_VOL_MASK;
-    const bool is_lim = in && type == LOBSIM_LIMIT, is_rem = in && (type == LOBSIM_CANCELLATION || type == LOBSIM_DELETION);
-    const int li = is_lim ? lane_find_level(L, side, S.n_lv[side], b.price) : -1;
+    const bool is_lim = in && type == LOBSIM_LIMIT, is_rem = in && (type == LOBSIM_CANCELLATION || type == LOBSIM_DELETION) && vol64 > 0;
+    const int li = (is_lim || is_rem) ? lane_find_level(L, side, S.n_lv[side], b.price) : -1;
     const uint64_t m = li >= 0 ? L.meta[side][li] : 0;
+    // cancellations: ask the position cache now, so the answer is in flight while the appends are booked
+    uint64_t ce = 0;
+    if (is_rem && li >= 0) ce = S.idc[(uint64_t)b.eid & (IDC_N - 1)];
     bool cross = false;
     if (is_lim && S.n_lv[side ^ 1] > 0) { const int64_t bp = L.price[side ^ 1][0]; cross = side == LOBSIM_BUY ? b.price >= bp : b.price <= bp; }
     const bool plain = is_lim && vol64 > 0 && vol64 < (1ll << 31) && li >= 0 && !cross && m_live(m) > 0 &&
                        m_tail(m) <= SLOTS - WAVE && m_tail(m) - m_head(m) - m_live(m) < LOBSIM_TOMB;
-    const uint64_t stop = ballot(in && !(plain || (is_rem && vol64 > 0)));
+    const uint64_t stop = ballot(in && !(plain || is_rem));
     seg_end = stop ? ffs64(stop) : cnt;
     const bool app = plain && ln < seg_end;
     const uint64_t below = (1ull << ln) - 1;
@@ -958,12 +973,53 @@ DI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt, 
     }
     if (app) {
         Slot w; w.id = b.eid; w.vol = (int32_t)vol64; w.kind = K_EXT;
-        S.slots[(size_t)m_slab(m) * SLOTS + m_tail(m) + rank] = w;
+        const int pos = m_tail(m) + rank;
+        S.slots[(size_t)m_slab(m) * SLOTS + pos] = w;
+        idc_put(S, b.eid, m_slab(m), pos);
         atomicAdd(reinterpret_cast<unsigned long long*>(&L.meta[side][li]), (1ull << 32) + (1ull << 48));  // tail += 1, live += 1
         atomicAdd(&L.vol[side][li], (int32_t)vol64);
     }
     wsync();
-    return ballot(app);
+    // ---- cancellations / deletions whose order the position cache still knows: straight to the slot, no queue scan.
+    // A lane takes this path only when its entry points into the live range [head, tail) of the slab of the level its
+    // price names and that slot holds exactly this external order; the first lane wins when two messages of the
+    // segment name one order (the other, later one is replayed by the general routine afterwards, in order).
+    bool rem = is_rem && ln < seg_end && li >= 0 && (uint32_t)(ce >> 32) == idc_tag(b.eid);
+    const int cslab = (int)((ce >> 16) & 0xffff), cpos = (int)(ce & 0xffff);
+    const uint64_t m2 = rem ? L.meta[side][li] : 0;  // after the appends of this segment
+    rem = rem && cslab == m_slab(m2) && cpos >= m_head(m2) && cpos < m_tail(m2);
+    Slot cs = dead_slot();
+    if (rem) cs = S.slots[(size_t)cslab * SLOTS + cpos];
+    rem = rem && cs.kind == K_EXT && cs.id == b.eid;
+    const int rkey = (cslab << 16) | cpos;
+    for (uint64_t todo = ballot(rem); todo;) {  // duplicates: same slot named twice -> keep the first lane only
+        const int f = ffs64(todo);
+        const int k = rl32(rkey, f);
+        const uint64_t grp = ballot(rem && rkey == k);
+        if (rem && rkey == k && ln != f) rem = false;
+        todo &= ~grp;
+    }
+    bool gone = false;
+    if (rem) {
+        const int32_t v = vol64 > 0x7fffffffll ? 0x7fffffff : (int32_t)vol64;
+        const int32_t rv = v > cs.vol ? cs.vol : v, nv = cs.vol - rv;  // CancellationVolumeExceededError -> whole remainder
+        gone = nv == 0;
+        Slot w = cs; w.vol = nv; if (gone) w.kind = K_DEAD;
+        S.slots[(size_t)cslab * SLOTS + cpos] = w;
+        atomicAdd(&L.vol[side][li], -rv);
+        if (gone) atomicAdd(reinterpret_cast<unsigned long long*>(&L.meta[side][li]), (unsigned long long)(-(1ll << 48)));  // live -= 1
+    }
+    wsync();
+    // levels emptied by these removals leave the ladder (rare; sequential, looked up again by price)
+    for (uint64_t em = ballot(rem && gone && m_live(L.meta[side][li]) == 0); em;) {
+        const int j = ffs64(em);
+        em &= em - 1;
+        const int sd = rl32(side, j);
+        const int ix = find_level(L, S, sd, rl64(b.price, j));
+        if (ix >= 0 && m_live((uint64_t)uni64((int64_t)L.meta[sd][ix])) == 0) ladder_remove(L, S, sd, ix);
+    }
+    wsync();
+    return ballot(app || rem);
 }
 
 // the window (now, until] of historical messages, in stream order (OrderbookSimulator.py:70-85).  `b` is the batch
@@ -1399,6 +1455,7 @@ DI void load_env(Lds& L, Scal& S, const DevPtrs& P, int env, const EnvHdr& H) {
         L.ag_cnt = 0; L.ag_vol[0] = L.ag_vol[1] = 0; L.ext_cnt[0] = L.ext_cnt[1] = 0; L.ext_vol[0] = L.ext_vol[1] = 0;
     }
     S.slots = P.slots + (size_t)env * NSLAB * SLOTS;
+    S.idc = P.idc + (size_t)env * IDC_N;
     wsync();
 }
 
@@ -1749,6 +1806,7 @@ __global__ __launch_bounds__(64, 4) void lob_reset_kernel(DevCfg C, DevPtrs P, R
     const int F = C.c.n_features, D = C.obs_dim, Lv = C.c.n_levels;
     Scal S;
     S.slots = P.slots + (size_t)env * NSLAB * SLOTS;
+    S.idc = P.idc + (size_t)env * IDC_N;
     S.status = 0; S.n_ops = 0;
     if (ln == 0) { L.inv = H.inventory; L.cash = H.cash; }  // the portfolio is NOT reset (Q7)
     ladder_clear(L, S);
@@ -1813,6 +1871,7 @@ __global__ __launch_bounds__(64) void lob_set_book_kernel(DevCfg C, DevPtrs P, i
     EnvHdr& H = P.hdr[env];
     Scal S;
     S.slots = P.slots + (size_t)env * NSLAB * SLOTS;
+    S.idc = P.idc + (size_t)env * IDC_N;
     S.status = 0; S.n_ops = 0;
     if (lane() == 0) { L.inv = H.inventory; L.cash = H.cash; }
     ladder_clear(L, S);

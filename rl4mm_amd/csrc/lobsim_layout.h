@@ -26,6 +26,8 @@ constexpr int LV = 128;          // price levels per side (2 per lane)
 constexpr int SLOTS = 512;       // order slots per price level (8 chunks of one wave-load each; 8 KiB slab)
 constexpr int NSLAB = 2 * LV;    // slabs per env
 constexpr int NA = 128;          // live agent orders per env (2 per lane)
+constexpr int IDC_N = 32768;     // entries of the per-env external-order position cache (256 KiB; a cache: every hit is
+                                 // verified against the slot it points to, misses take the queue scan)
 constexpr int QMAX = 32;         // quote levels per side (2 * QMAX <= 64 lanes)
 constexpr int OPS_MAX = 2 * QMAX + NA + 8;  // agent op list: limits + cancels + market order (resync re-adds reuse it)
 
@@ -114,6 +116,7 @@ struct DevPtrs {
     Slot* slots;       // [env][NSLAB][SLOTS]
     AgentOrd* agent;   // [env][NA]
     uint16_t* apos;    // [env][NA] slot index of each live agent order inside its level's slab
+    uint64_t* idc;     // [env][IDC_N] position cache of external orders: tag(id) << 32 | slab << 16 | slot, direct-mapped by id
     FeatState* feat;   // [env][LOBSIM_MAX_FEATURES]
     int64_t* rings;    // [env][ring_words]
     const StreamDev* streams;
