@@ -36,8 +36,10 @@ namespace lobk {
 #endif
 #ifdef LOBSIM_PROFILE
 #define EVENT(field) (S.field++)
+#define SUBSTAMP(k) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F); S.sub_t[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define EVENT(field) do { } while (0)
+#define SUBSTAMP(k) do { } while (0)
 #endif
 
 #ifndef LOBSIM_TOMB
@@ -108,6 +110,7 @@ struct Scal {
 #endif
 #ifdef LOBSIM_PROFILE
     uint32_t ev_chunks, ev_compact, ev_ladder, ev_exec_levels, ev_rare;  // event counts (diagnostic build only)
+    uint64_t sub_t[10];                                                   // sub-phase stamps (diagnostic build only)
 #endif
 };
 
@@ -588,6 +591,7 @@ DI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action) {
     const int Q = C.Q, ln = lane();
     const int64_t tick = c.tick_size;
     S.n_ops = 0;
+    SUBSTAMP(0);
     // ---- BetaOrderDistributor.convert_action (OrderDistributors.py:23-25,39-56); lane = side * Q + k
     const double EPS = 0.000001;
     int my_side = ln / Q, my_k = ln - my_side * Q;
@@ -603,11 +607,13 @@ DI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action) {
     }
     if (ln < 2 * QMAX) L.cur[ln / QMAX][ln % QMAX] = 0;
     wsync();
+    SUBSTAMP(1);
     int32_t desired = 0;
     if (quoting) {
         double s = np_pairwise_sum(L.pdf[my_side], Q);
         desired = (int32_t)rint(L.pdf[my_side][my_k] / s * 100.0);  // np.round(dist * active_volume).astype(int)
     }
+    SUBSTAMP(2);
     const int64_t inv = cur_inv(L);
     int64_t abs_inv = inv < 0 ? -inv : inv;
     bool clearing = c.market_order_clearing && (double)abs_inv > act_at(action, c.action_dim - 1);
@@ -621,6 +627,7 @@ DI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action) {
         best_sell = (int64_t)(ceil(mid / (double)tick) * (double)tick);
     }
     S.q_buy = best_buy; S.q_sell = best_sell;
+    SUBSTAMP(3);
     // ---- current agent volume per quoted level (_get_current_internal_order_volumes, :291-296); each agent entry
     // finds its quote level (or "wide")
     int ek[2];
@@ -642,6 +649,7 @@ DI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action) {
         }
     }
     wsync();
+    SUBSTAMP(4);
     int32_t diff = quoting ? desired - L.cur[my_side][my_k] : 0;
     wsync();
     if (quoting) L.cur[my_side][my_k] = diff;  // publish: agent entries read their level's diff
@@ -661,9 +669,43 @@ DI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action) {
         code[r] = cand[r] ? (sd << 8) | ek[r] : -1 - r;  // (side, level) key; distinct dummies when not a candidate
     }
     {
+        // newer[r] = volume of the candidates at my level that are newer than me.  Every candidate posts (seq, vol) to
+        // its level's list in LDS (the op list's storage, not yet written; counters in the pdf storage, already
+        // consumed), then reads its own level's list: a handful of entries per lane instead of one wave-wide
+        // broadcast turn per candidate.  A level with more candidates than a list holds takes the broadcast loop.
         const uint32_t q0 = ao[0].seq_side & 0x7fffffffu, q1 = ao[1].seq_side & 0x7fffffffu;
+        int32_t* cntr = reinterpret_cast<int32_t*>(&L.pdf[0][0]);
+        unsigned long long* lists = reinterpret_cast<unsigned long long*>(&L.ops[0]);
+        const int cap = OPS_MAX / (2 * Q);
+        if (ln < 2 * Q) cntr[ln] = 0;
+        wsync();
+        int lvl[2], at[2];
 #pragma unroll
-        for (int r = 0; r < 2; r++) {  // broadcast every candidate once: volume of same-level orders newer than mine
+        for (int r = 0; r < 2; r++) {
+            lvl[r] = (code[r] >> 8) * Q + (code[r] & 0xff);
+            at[r] = 0;
+            if (cand[r]) {
+                at[r] = atomicAdd(&cntr[lvl[r]], 1);
+                if (at[r] < cap) lists[lvl[r] * cap + at[r]] = ((unsigned long long)(r ? q1 : q0) << 32) | (uint32_t)ao[r].vol;
+            }
+        }
+        wsync();
+        const bool overflow = ballot((cand[0] && at[0] >= cap) || (cand[1] && at[1] >= cap)) != 0;
+        if (!overflow) {
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                if (!cand[r]) continue;
+                const int n = cntr[lvl[r]];
+                const uint32_t mine = r ? q1 : q0;
+                for (int i = 0; i < n; i++) {
+                    const unsigned long long e = lists[lvl[r] * cap + i];
+                    newer[r] += (uint32_t)(e >> 32) > mine ? (int32_t)(uint32_t)e : 0;
+                }
+            }
+        }
+        wsync();
+#pragma unroll
+        for (int r = 0; r < 2 && overflow; r++) {  // broadcast every candidate once: volume of same-level orders newer than mine
             uint64_t bb = ballot(cand[r]);
             while (bb) {
                 const int t = ffs64(bb);
@@ -676,6 +718,7 @@ DI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action) {
             }
         }
     }
+    SUBSTAMP(5);
     int32_t cvol[2];
 #pragma unroll
     for (int r = 0; r < 2; r++) {
@@ -705,6 +748,7 @@ DI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action) {
     }
     if (S.n_ops > OPS_MAX) S.status |= LOBSIM_ST_AGENT_OVERFLOW;
     wsync();
+    SUBSTAMP(6);
 }
 
 // per-lane binary search of a price in the sorted ladder of one side; -1 if there is no such level
@@ -1588,6 +1632,7 @@ __global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg 
     Scal S;
 #ifdef LOBSIM_PROFILE
     S.ev_chunks = S.ev_compact = S.ev_ladder = S.ev_exec_levels = S.ev_rare = 0;
+    for (int k = 0; k < 10; k++) S.sub_t[k] = 0;
 #endif
 #ifdef LOBSIM_PROFILE_MSG
     for (int k = 0; k < 8; k++) { S.pm_cycles[k] = 0; S.pm_count[k] = 0; }
@@ -1661,6 +1706,7 @@ __global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg 
         P.prof[(size_t)env * 8 + 7] += 1;
         uint64_t* ev = P.prof + (size_t)gridDim.x * 8 + (size_t)env * 16;  // event counts share the message-class block
         ev[0] += S.ev_chunks; ev[1] += S.ev_compact; ev[2] += S.ev_ladder; ev[3] += S.ev_exec_levels; ev[4] += S.ev_rare;
+        for (int k = 0; k < 9; k++) ev[6 + k] += S.sub_t[k + 1] > S.sub_t[k] ? S.sub_t[k + 1] - S.sub_t[k] : 0;  // sub-phase k
 #ifdef LOBSIM_PROFILE_MSG
         uint64_t* pm = P.prof + (size_t)gridDim.x * 8 + (size_t)env * 16;
         for (int k = 0; k < 8; k++) { pm[k] = S.pm_cycles[k]; pm[8 + k] += S.pm_count[k]; }  // (overwrites the event counts)
