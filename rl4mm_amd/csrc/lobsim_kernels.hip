@@ -109,7 +109,7 @@ struct Scal {
     uint64_t pm_cycles[8], pm_count[8];  // per message class (diagnostic build only)
 #endif
 #ifdef LOBSIM_PROFILE
-    uint32_t ev_chunks, ev_compact, ev_ladder, ev_exec_levels, ev_rare;  // event counts (diagnostic build only)
+    uint32_t ev_chunks, ev_compact, ev_ladder, ev_exec_levels, ev_rare, ev_serial_ops;  // event counts (diagnostic build only)
     uint64_t sub_t[10];                                                   // sub-phase stamps (diagnostic build only)
 #endif
 };
@@ -1078,9 +1078,14 @@ DI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, i
         // waves first, so the wave with the longest window runs closer to its single-wave speed while its SIMD-mates
         // (shorter windows, done earlier anyway) take the contention: longest-job-first.  (Thresholds in messages
         // per window; only the order among the four waves of a SIMD matters.)
-        if (cnt >= 36) __builtin_amdgcn_s_setprio(3);
-        else if (cnt >= 24) __builtin_amdgcn_s_setprio(2);
-        else if (cnt >= 12) __builtin_amdgcn_s_setprio(1);
+#ifndef LOBSIM_PRIO_A
+#define LOBSIM_PRIO_A 12
+#define LOBSIM_PRIO_B 24
+#define LOBSIM_PRIO_C 36
+#endif
+        if (cnt >= LOBSIM_PRIO_C) __builtin_amdgcn_s_setprio(3);
+        else if (cnt >= LOBSIM_PRIO_B) __builtin_amdgcn_s_setprio(2);
+        else if (cnt >= LOBSIM_PRIO_A) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
         uint64_t applied = 0;  // lanes whose limit order the lane-parallel pass has already booked
         int classified = 0;    // lanes below this have been through append_segment
@@ -1554,7 +1559,7 @@ DI void run_agent_ops(Lds& L, Scal& S, const DevCfg& C) {
     if (S.n_ops > 0) has_market = (uni(L.ops[S.n_ops - 1].code) & 0xf) == LOBSIM_MARKET;  // the clearing order is last
     if (S.n_ops <= 64 && !has_market && S.q_buy < S.q_sell) todo = apply_agent_ops_parallel(L, S, C);
     if (S.n_ops <= 64) {
-        while (todo && !S.status) { int k = ffs64(todo); todo &= todo - 1; process_op(L, S, C, L.ops[k]); }
+        while (todo && !S.status) { int k = ffs64(todo); todo &= todo - 1; EVENT(ev_serial_ops); process_op(L, S, C, L.ops[k]); }
     } else {
         for (int k = 0; k < S.n_ops && !S.status; k++) process_op(L, S, C, L.ops[k]);
     }
@@ -1631,7 +1636,7 @@ __global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg 
     STAMP(0);
     Scal S;
 #ifdef LOBSIM_PROFILE
-    S.ev_chunks = S.ev_compact = S.ev_ladder = S.ev_exec_levels = S.ev_rare = 0;
+    S.ev_chunks = S.ev_compact = S.ev_ladder = S.ev_exec_levels = S.ev_rare = S.ev_serial_ops = 0;
     for (int k = 0; k < 10; k++) S.sub_t[k] = 0;
 #endif
 #ifdef LOBSIM_PROFILE_MSG
@@ -1665,9 +1670,12 @@ __global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg 
         if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true, first);
 #endif
         STAMP(4);
+        SUBSTAMP(7);
         if (ln < F) fs = P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln];  // loaded late: not live across the order loops
+        SUBSTAMP(8);
         if (!S.status) {
             StepView v = make_view(L, S, price, now);
+            SUBSTAMP(9);
             bool ok = true;
             if (ln < F) ok = feature_update<EXTRAS>(C.c.features[ln], fs, P.rings + (size_t)env * C.ring_words + C.ring_off[ln], v, norm_history(C, P, env, ln));
             if (ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
@@ -1705,7 +1713,7 @@ __global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg 
         P.prof[(size_t)env * 8 + 6] += S.n_ops;
         P.prof[(size_t)env * 8 + 7] += 1;
         uint64_t* ev = P.prof + (size_t)gridDim.x * 8 + (size_t)env * 16;  // event counts share the message-class block
-        ev[0] += S.ev_chunks; ev[1] += S.ev_compact; ev[2] += S.ev_ladder; ev[3] += S.ev_exec_levels; ev[4] += S.ev_rare;
+        ev[0] += S.ev_chunks; ev[1] += S.ev_compact; ev[2] += S.ev_ladder; ev[3] += S.ev_exec_levels; ev[4] += S.ev_rare; ev[5] += S.ev_serial_ops;
         for (int k = 0; k < 9; k++) ev[6 + k] += S.sub_t[k + 1] > S.sub_t[k] ? S.sub_t[k + 1] - S.sub_t[k] : 0;  // sub-phase k
 #ifdef LOBSIM_PROFILE_MSG
         uint64_t* pm = P.prof + (size_t)gridDim.x * 8 + (size_t)env * 16;
