@@ -1482,10 +1482,16 @@ DI void load_env(Lds& L, Scal& S, const DevPtrs& P, int env, const EnvHdr& H) {
     int64_t pb = 0, psl = 0; uint64_t mb = 0, ms = 0; int32_t vb = 0, vs = 0;
     if (hb) { pb = G.price[0][ln]; mb = G.meta[0][ln]; vb = G.vol[0][ln]; }
     if (hs) { psl = G.price[1][ln]; ms = G.meta[1][ln]; vs = G.vol[1][ln]; }
+    // agent entries: only the live ones travel (the free mask in the header says which; entries are handed out lowest
+    // index first, so the upper half is usually all free and skipped by the whole wave)
     const AgentOrd* A = P.agent + (size_t)env * NA;
     const uint16_t* AP = P.apos + (size_t)env * NA;
-    const AgentOrd a0 = A[ln], a1 = A[ln + 64];
-    const uint16_t q0 = AP[ln], q1 = AP[ln + 64];
+    const uint64_t af0 = H.agent_free[0], af1 = H.agent_free[1];
+    AgentOrd a0, a1;
+    a0.price = 0; a0.vol = 0; a0.seq_side = 0; a1 = a0;
+    uint16_t q0 = 0, q1 = 0;
+    if (!((af0 >> ln) & 1)) { a0 = A[ln]; q0 = AP[ln]; }
+    if (af1 != ~0ull && !((af1 >> ln) & 1)) { a1 = A[ln + 64]; q1 = AP[ln + 64]; }
     if (hb) { L.price[0][ln] = pb; L.meta[0][ln] = mb; L.vol[0][ln] = vb; }
     if (hs) { L.price[1][ln] = psl; L.meta[1][ln] = ms; L.vol[1][ln] = vs; }
     L.agent[ln] = a0; L.agent[ln + 64] = a1;
@@ -1518,11 +1524,10 @@ DI void store_env(const Lds& L, const Scal& S, const DevPtrs& P, int env, EnvHdr
             G.price[s][i] = L.price[s][i]; G.meta[s][i] = L.meta[s][i]; G.vol[s][i] = L.vol[s][i];
         }
     AgentOrd* A = P.agent + (size_t)env * NA;
-    A[ln] = L.agent[ln];
-    A[ln + 64] = L.agent[ln + 64];
     uint16_t* AP = P.apos + (size_t)env * NA;
-    AP[ln] = L.apos[ln];
-    AP[ln + 64] = L.apos[ln + 64];
+    const uint64_t af0 = lds_u64(L.agent_free[0]) | lds_u64(L.agent_pending[0]), af1 = lds_u64(L.agent_free[1]) | lds_u64(L.agent_pending[1]);
+    if (!((af0 >> ln) & 1)) { A[ln] = L.agent[ln]; AP[ln] = L.apos[ln]; }  // live entries only (see load_env)
+    if (af1 != ~0ull && !((af1 >> ln) & 1)) { A[ln + 64] = L.agent[ln + 64]; AP[ln + 64] = L.apos[ln + 64]; }
     if (ln == 0) {
         H.n_lv[0] = S.n_lv[0]; H.n_lv[1] = S.n_lv[1];
         H.status = S.status; H.inventory = L.inv; H.cash = L.cash; H.agent_seq = L.agent_seq;
