@@ -102,6 +102,7 @@ struct Scal {
     LevelCounts n_lv;
     int32_t status;
     int32_t n_ops;
+    uint32_t ladder_ver;    // bumped whenever a level is opened or removed (indices into the ladder shift)
     int64_t q_buy, q_sell;  // best prices the current op list was built against (_get_best_prices)
     Slot* slots;            // this env's slabs
     uint64_t* idc;          // this env's position cache of external orders (see IDC_N)
@@ -246,6 +247,7 @@ DI bool ladder_insert(Lds& L, Scal& S, int side, int pos, int64_t price) {
     }
     if (ln == 0) { L.price[side][pos] = price; L.meta[side][pos] = mk_meta(slab, 0, 0, 0); L.vol[side][pos] = 0; }
     S.n_lv.bump(side, 1);
+    S.ladder_ver++;
     wsync();
     return true;
 }
@@ -268,6 +270,7 @@ DI void ladder_remove(Lds& L, Scal& S, int side, int pos) {
         if (take[r]) { L.price[side][i] = p[r]; L.meta[side][i] = m[r]; L.vol[side][i] = v[r]; }
     }
     S.n_lv.bump(side, -1);
+    S.ladder_ver++;
     wsync();
 }
 
@@ -857,6 +860,7 @@ DI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
 // ---------------------------------------------------------------------------------------------------------------
 DI void ladder_clear(Lds& L, Scal& S) {
     S.n_lv.v = 0;
+    S.ladder_ver = 0;
     if (lane() < NSLAB / 64) L.slab_free[lane()] = ~0ull;
     if (lane() < NA / 64) { L.agent_free[lane()] = ~0ull; L.agent_pending[lane()] = 0; }
     L.agent[lane()].vol = 0;
@@ -988,13 +992,19 @@ DI MsgBatch fetch_messages(const StreamDev& st, int64_t cursor) {
 // cancellation never changes where an append lands (tail positions only grow); compaction and level creation are not
 // taken here.  Returns the lanes appended; `seg_end` = first lane that needs the general routine first (or cnt).
 // Half of all messages take this path with no scalar-unit work per message.
-DI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt, int& seg_end) {
+DI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt, int& seg_end, int& li_memo, uint32_t& memo_levels) {
     const int ln = lane();
     const bool in = ln >= j0 && ln < cnt;
     const int type = (int)((b.meta >> LOBSIM_TYPE_SHIFT) & 0xf), side = (int)((b.meta >> LOBSIM_SIDE_SHIFT) & 1);
     const int64_t vol64 = b.meta & LOBSIM_VOL_MASK;
     const bool is_lim = in && type == LOBSIM_LIMIT, is_rem = in && (type == LOBSIM_CANCELLATION || type == LOBSIM_DELETION) && vol64 > 0;
-    const int li = (is_lim || is_rem) ? lane_find_level(L, side, S.n_lv[side], b.price) : -1;
+    // the level every lane's price names: searched once per batch and kept across the segments of the batch for as
+    // long as no level was opened or removed (S.ladder_ver counts those)
+    if (memo_levels != S.ladder_ver) {
+        li_memo = (ln < cnt && (type == LOBSIM_LIMIT || type == LOBSIM_CANCELLATION || type == LOBSIM_DELETION)) ? lane_find_level(L, side, S.n_lv[side], b.price) : -1;
+        memo_levels = S.ladder_ver;
+    }
+    const int li = (is_lim || is_rem) ? li_memo : -1;
     const uint64_t m = li >= 0 ? L.meta[side][li] : 0;
     // cancellations: ask the position cache now, so the answer is in flight while the appends are booked
     uint64_t ce = 0;
@@ -1087,12 +1097,14 @@ DI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, i
         else if (cnt >= LOBSIM_PRIO_B) __builtin_amdgcn_s_setprio(2);
         else if (cnt >= LOBSIM_PRIO_A) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
+        int li_memo = -1;                             // per lane: level index of this lane's price ...
+        uint32_t memo_ver = S.ladder_ver + 0x80000000u;  // ... as of this ladder version (none yet)
         uint64_t applied = 0;  // lanes whose limit order the lane-parallel pass has already booked
         int classified = 0;    // lanes below this have been through append_segment
         for (int j = 0; j < cnt && !S.status; j++) {
             if (j >= classified) {
                 int seg_end;
-                applied |= append_segment(L, S, b, j, cnt, seg_end);
+                applied |= append_segment(L, S, b, j, cnt, seg_end, li_memo, memo_ver);
                 classified = seg_end + 1;  // the message at seg_end goes through the general routine as it is
             }
             if ((applied >> j) & 1) continue;
@@ -1502,7 +1514,7 @@ DI void load_env(Lds& L, Scal& S, const DevPtrs& P, int env, const EnvHdr& H) {
             L.price[s][i] = G.price[s][i]; L.meta[s][i] = G.meta[s][i]; L.vol[s][i] = G.vol[s][i];
         }
     if (ln < NA / 64) L.freed[ln] = 0;
-    S.status = H.status; S.n_ops = 0;
+    S.status = H.status; S.n_ops = 0; S.ladder_ver = 0;
     if (ln < NSLAB / 64) L.slab_free[ln] = H.slab_free[ln];
     if (ln < NA / 64) { L.agent_free[ln] = H.agent_free[ln]; L.agent_pending[ln] = 0; }
     if (ln == 0) {
