@@ -42,6 +42,11 @@ namespace lobk {
 #define SUBSTAMP(k) do { } while (0)
 #endif
 
+#ifndef LOBSIM_PRIO_A
+#define LOBSIM_PRIO_A 12  // messages per window from which a wave raises its priority (see replay_messages)
+#define LOBSIM_PRIO_B 24
+#define LOBSIM_PRIO_C 36
+#endif
 #ifndef LOBSIM_TOMB
 #define LOBSIM_TOMB 128  // tombstones a level may hold before its slab is squeezed.  Measured 8 .. 384: with queue scans
                          // on every cancellation the optimum was 16-32; now that the position cache answers most of them, 128
@@ -1659,8 +1664,6 @@ __global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg 
 #ifdef LOBSIM_PROFILE_MSG
     for (int k = 0; k < 8; k++) { S.pm_cycles[k] = 0; S.pm_count[k] = 0; }
 #endif
-    load_env(L, S, P, env, H);
-    STAMP(1);
     const double* ap = A.actions + (size_t)env * AD;
     Act5 act;
     act.v0 = ap[0]; act.v1 = ap[1];
@@ -1669,6 +1672,14 @@ __global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg 
     int stream_id = H.stream_id;
     MsgBatch first = {INT64_MAX, 0, 0, 0};
     if (stream_id >= 0) first = fetch_messages(P.streams[stream_id], cursor);  // in flight while the agent's orders are built
+    load_env(L, S, P, env, H);
+    STAMP(1);
+    {   // longest-job-first from the start of the step (replay_messages sets the same level again)
+        const int c0 = popc64(ballot(first.t <= now + C.c.step_us));
+        if (c0 >= LOBSIM_PRIO_C) __builtin_amdgcn_s_setprio(3);
+        else if (c0 >= LOBSIM_PRIO_B) __builtin_amdgcn_s_setprio(2);
+        else if (c0 >= LOBSIM_PRIO_A) __builtin_amdgcn_s_setprio(1);
+    }
     Ranges R = {H.min_buy, H.max_sell, H.init_buy_range, H.init_sell_range};
     int n_resyncs = H.n_resyncs;
     double price = H.price, reward = 0.0;
