@@ -606,8 +606,8 @@ DI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action) {
     bool quoting = ln < 2 * Q;
     if (quoting) {
         double a, b;
-        if (c.use_concentration) { a = act_at(action, my_side) + EPS; b = c.concentration - a + EPS; }
-        else { a = act_at(action, 2 * my_side) + EPS; b = act_at(action, 2 * my_side + 1) + EPS; }
+        if (c.use_concentration) { a = (my_side ? action.v1 : action.v0) + EPS; b = c.concentration - a + EPS; }
+        else { a = (my_side ? action.v2 : action.v0) + EPS; b = (my_side ? action.v3 : action.v1) + EPS; }
         // beta.pdf up to the 1/B(a,b) that cancels in the normalisation below; x^(a-1) (1-x)^(b-1) as one exp over
         // host-tabulated logs (two pow() calls were a quarter of this kernel's fixed VALU work).  Only the integer
         // volumes after rounding are observable: tests pin them against a 320k-value scipy table.
@@ -649,7 +649,9 @@ DI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action) {
             ek[r] = -1;  // negative, not a tick multiple or beyond the quoted range: "wide"
             if (d >= 0 && d < (int64_t)(c.min_quote_level + Q) * tick) {  // small: 32-bit divide
                 uint32_t du = (uint32_t)d, tu = (uint32_t)tick;
-                uint32_t qd = du / tu;
+                // d / tick: multiply-high by ceil(2^32 / tick) is exact while d * tick < 2^32 (the host checks the quoted
+                // range against that, tick_magic = 0 otherwise); a run-time 32-bit division is ~30 instructions per entry
+                uint32_t qd = C.tick_magic ? __umulhi(du, C.tick_magic) : du / tu;
                 int kk = (int)qd - c.min_quote_level;
                 if (qd * tu == du && kk >= 0) ek[r] = kk;
             }

@@ -104,6 +104,7 @@ struct DevCfg {
     int32_t obs_dim;
     int32_t ring_off[LOBSIM_MAX_FEATURES];  // offset of feature f's ring (in 8-byte words) inside an env's ring block
     int32_t ring_words;         // ring words per env
+    uint32_t tick_magic;        // ceil(2^32 / tick_size) when (min_quote_level + Q) * tick_size^2 < 2^32, else 0
     int32_t norm_off[LOBSIM_MAX_FEATURES];  // offset (8-byte words) of feature f's normalisation history inside an env's block
     int32_t norm_words;                     // history words per env (0: no feature is normalised)
     // ln(x_k), ln(1 - x_k) at the Q quote-level midpoints x_k = (k + 0.5) / Q: Beta pdf = exp((a-1) ln x + (b-1) ln(1-x))
