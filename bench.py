@@ -55,11 +55,11 @@ def build_stream(sim_seconds):
 
 def pmc_traffic(n_envs):
     """HBM bytes per launch of the step kernel from the committed rocprofv3 --pmc passes of this same command
-    (tools/pmc_passes.sh -> profiles/r1/g_pmc_step_kernel.csv; counters cannot be collected from inside the timed
+    (tools/pmc_passes.sh -> profiles/r1/h_pmc_step_kernel.csv; counters cannot be collected from inside the timed
     run).  FETCH_SIZE / WRITE_SIZE are in KB per dispatch; on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes
     for wide reads, so it is doubled (MI355X_MICROARCH.md, HBM section): an upper bound for this kernel's mix of
     8- and 16-byte-per-lane loads.  None when the file is absent or was taken at another batch size."""
-    f = ROOT / "profiles" / "r1" / "g_pmc_step_kernel.csv"
+    f = ROOT / "profiles" / "r1" / "h_pmc_step_kernel.csv"
     try:
         rows = {r.split(",")[1]: float(r.split(",")[2]) for r in f.read_text().splitlines()[1:] if r.count(",") >= 3}
         if int(rows["SQ_WAVES"]) != n_envs:
