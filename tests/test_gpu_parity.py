@@ -303,6 +303,46 @@ def test_dense_constructed_streams_against_oracle(kind):
     gpu.close()
 
 
+def test_soak_many_short_episodes_against_oracle():
+    """512 envs x 1500 steps of 6-second episodes (every env is reset ~25 times, from different seconds), random actions,
+    `enter_spread` so that the agent's quotes are hit: the replay fast paths (lane-parallel appends, cancellations through
+    the never-cleared position cache, merged execution runs, slab squeezes) over many resets.  Inventory, cash, price and
+    done per env per step; fill counters and per-order book contents of sampled envs at the end."""
+    n, steps = 512, 1500
+    cfg = _capi.make_cfg(n, 10, _short_features(), step_us=100_000, episode_us=6_000_000, outer_levels=20, enter_spread=True)
+    stream = ol.golden_stream("synth_small")
+    gpu, cpu = _lib.new_sim(cfg), ol.oracle_sim(cfg)
+    rng = np.random.Generator(np.random.PCG64(2024))
+    starts = (35_720 + rng.integers(0, 300, size=n)) * 1_000_000
+    for sim in (gpu, cpu):
+        sim.add_stream(stream)
+        sim.set_portfolio(0, 10**10)
+    assert np.allclose(gpu.reset(starts, 0), cpu.reset(starts, 0), rtol=RTOL, atol=ATOL)
+    n_resets = 0
+    for t in range(steps):
+        act = rng.uniform(0, 10.0, size=(n, cfg.action_dim))
+        og, rg, dg = gpu.step(act)
+        oc, rc, dc = cpu.step(act)
+        assert np.array_equal(dg, dc), f"step {t}: done differs"
+        for a, b, what in zip(gpu.portfolios(), cpu.portfolios(), ("inventory", "cash", "price")):
+            assert np.array_equal(a, b), f"step {t}: {what} differs in envs {np.nonzero(a != b)[0][:8]}"
+        if t % 50 == 0:
+            assert np.allclose(og, oc, rtol=RTOL, atol=ATOL), f"step {t}: obs differ by {np.abs(og - oc).max()}"
+        if dg.any():
+            ids = np.nonzero(dg)[0].astype(np.int32)
+            n_resets += len(ids)
+            starts[ids] = (35_720 + rng.integers(0, 380, size=len(ids))) * 1_000_000
+            gpu.reset(starts[ids], 0, ids)
+            cpu.reset(starts[ids], 0, ids)
+    assert n_resets > 20 * n
+    for e in (0, 100, 255, 511):
+        assert np.array_equal(gpu.queues(e), cpu.queues(e)), f"env {e}: per-order book contents differ"
+        sg, sc = gpu.env_state(e), cpu.env_state(e)
+        for k in ("status", "n_agent_orders", "n_resyncs", "agent_fill_count", "ext_buy_count", "ext_sell_count", "ext_buy_volume", "ext_sell_volume"):
+            assert sg[k] == sc[k], (e, k, sg[k], sc[k])
+    gpu.close()
+
+
 def test_msft_50_level_replay_against_oracle():
     """The reference's own 50-level test slice: warm-up replay (no agent) then stepping, book compared per order."""
     F = _capi.make_feature
