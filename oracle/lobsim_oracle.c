@@ -943,7 +943,7 @@ static void env_forward(oracle_t* h, Env* e, Order* internal, int n_internal) {
 
 /* get_sharpe (RewardFunctions.py:10-22) with numpy's summation order.  Returns 0 and sets *bad when min(aum) <= 0. */
 static double get_sharpe(const double* aum, int n, int* bad) {
-    double s[LOBSIM_SHARPE_MAX_WINDOW], x[LOBSIM_SHARPE_MAX_WINDOW];
+    double s[LOBSIM_SHARPE_MAX_WINDOW] = {0}, x[LOBSIM_SHARPE_MAX_WINDOW] = {0};
     for (int i = 0; i < n; i++) if (aum[i] <= 0) { *bad = 1; return 0.0; }
     int m = n - 1;
     for (int i = 0; i < m; i++) s[i] = exp(log(aum[i + 1]) - log(aum[i])) - 1;
