@@ -1,18 +1,27 @@
 #!/usr/bin/env python3
 """bench.py - env-steps/s of the batched LOB simulation step on MI355X (BASELINE.json metric).
 
-A "step" is one launch of the hot path (lob_step_kernel) over one batch: every env of the rank converts its action
-to orders, replays its 100 ms message window, updates features and reward.  Workload at N=1 = BASELINE.json
-configs[1]: 4096 vectorised envs on one MI355X, synthetic 10-level SPY-shaped stream with 1 s snapshots, random
-Beta-policy actions (uniform in Box[0,10]^4, PCG64(42)), default `full_state` features, PnL reward.  With --gpus N
-every rank owns 4096 envs of its own (weak scaling; envs are independent, the stream is replicated), the only
-collective is the episode-return gather after the timed loop.
+A "step" is one pass of the hot path over one batch: every env of the rank converts its action to orders, replays
+its 100 ms message window, updates features and reward (one `lobsim_step_device` call = one env.step() per env).
+Workload at N=1 = BASELINE.json configs[1]: 4096 vectorised envs on one MI355X, synthetic 10-level SPY-shaped stream
+with 1 s snapshots, random Beta-policy actions (uniform in Box[0,10]^4, PCG64(42)), default `full_state` features,
+PnL reward.  The other configs run as `--workload` shards (they are parity-test cases first, tests/test_gpu_parity.py):
+  teradactyl  configs[2] shape: 4096 envs, on-device Teradactyl policy, PnL (SPY-shaped synthetic; real SPY absent)
+  ad          configs[3] shard: 4096 envs, random actions, asymmetrically dampened per-step reward
+  deep50      configs[4] shard: 8192 envs, 50-level books, 4 tickers (50/150/300/600 msg/s), 100 ms snapshots
+
+`--gpus N` (the reference's num_workers knob, rl4mm/helpers/main_helper.py:262-263): when not already running under
+torch.distributed.run, this process starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a
+child BEFORE touching the GPU and relays its output; every rank owns `--envs` envs of its own (weak scaling; envs
+are independent, the stream is replicated), the only collective is the episode-return gather after the timed loop.
 
 Inputs (actions, stream, env state) are resident in HBM when the timed region starts.  Prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -26,6 +35,16 @@ HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md
 ENVS_PER_GPU = 4096
 STEP_US = 100_000
 EPISODE_US = 1_800_000_000  # 30 min, the reference default
+PROFILE_ROUND = "r2"
+
+WORKLOADS = {
+    "random": "4096 vectorised envs per GPU, synthetic 10-level SPY-shaped LOBSTER stream @1s snapshots, random Beta-policy actions (BASELINE.json configs[1])",
+    "teradactyl": "4096 envs per GPU, synthetic 10-level SPY-shaped stream, on-device Teradactyl rule-based agent, PnL reward (BASELINE.json configs[2] shape; real SPY 2018-02-21 data absent)",
+    "ad": "4096 envs per GPU, synthetic 10-level stream, random actions, AD (asymmetrically dampened) per-step reward (BASELINE.json configs[3] shard)",
+    "deep50": "8192 envs per GPU, 50-level books, 4 tickers at 50/150/300/600 msg/s, 100 ms snapshots (BASELINE.json configs[4] shard)",
+}
+DEEP50_RATES = (50.0, 150.0, 300.0, 600.0)
+TERADACTYL_PARAMS = [1000, 10.0, 0.5, 10.0, 1.0, 5, 0, 1000]  # max_inventory, kappa, omega, max_kappa, exponent, inventory feature index, no MOC, denom
 
 
 def default_features(capi):
@@ -46,20 +65,40 @@ def default_features(capi):
     ]
 
 
-def build_stream(sim_seconds):
+def build_streams(workload, sim_seconds):
+    """Synthetic LOBSTER streams of the workload: 09:54:50 (a 300 s feature warm-up before 10:00:00) up to the last
+    start (10:00:59) + sim_seconds."""
     from rl4mm_amd.synth import synthetic_stream
 
-    # 09:54:50 -> enough for a 300 s feature warm-up before 10:00:00 plus the stepped window
-    return synthetic_stream(20180221, 10, 200.0, 9.5 * 3600 + 1490, 9.5 * 3600 + 1800 + 60 + max(sim_seconds, 105) + 5)
+    t0, t1 = 9.5 * 3600 + 1490, 9.5 * 3600 + 1800 + 60 + sim_seconds + 5
+    if workload == "deep50":
+        return [synthetic_stream(20180221 + i, 50, lam, t0, t1, mid_price=2_700_000 - 350_000 * i, ticker=f"SY{i}", book_snapshot_freq="100ms")
+                for i, lam in enumerate(DEEP50_RATES)]  # fmt: skip
+    return [synthetic_stream(20180221, 10, 200.0, t0, t1)]
 
 
-def pmc_traffic(n_envs):
+def workload_cfg(capi, workload, n_envs, device_id=0):
+    kw = dict(step_us=STEP_US, episode_us=EPISODE_US, device_id=device_id)
+    if workload == "ad":  # get_reward_function("AD"), rl4mm/gym/utils.py:29-39
+        kw.update(per_step_reward=(capi.R_INVENTORY_ADJUSTED, 1, 0.1), terminal_reward=(capi.R_INVENTORY_ADJUSTED, 1, 0.1))
+    return capi.make_cfg(n_envs, 50 if workload == "deep50" else 10, default_features(capi), **kw)
+
+
+def workload_starts(workload, n_envs, n_streams, seed):
+    """Episode starts 10:00:00 .. 10:00:59 and the stream of every env (round-robin over the tickers)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    starts = (36_000 + rng.integers(0, 60, size=n_envs)) * 1_000_000
+    sids = (np.arange(n_envs) % n_streams).astype(np.int32)
+    return starts, sids
+
+
+def pmc_traffic(workload, n_envs):
     """HBM bytes per launch of the step kernel from the committed rocprofv3 --pmc passes of this same command
-    (tools/pmc_passes.sh -> profiles/r1/h_pmc_step_kernel.csv; counters cannot be collected from inside the timed
+    (tools/pmc_passes.sh -> profiles/<round>/pmc_step_kernel.csv; counters cannot be collected from inside the timed
     run).  FETCH_SIZE / WRITE_SIZE are in KB per dispatch; on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes
     for wide reads, so it is doubled (MI355X_MICROARCH.md, HBM section): an upper bound for this kernel's mix of
-    8- and 16-byte-per-lane loads.  None when the file is absent or was taken at another batch size."""
-    f = ROOT / "profiles" / "r1" / "h_pmc_step_kernel.csv"
+    8- and 16-byte-per-lane loads.  None when the file is absent or was taken at another batch size / workload."""
+    f = ROOT / "profiles" / PROFILE_ROUND / ("pmc_step_kernel.csv" if workload == "random" else f"pmc_step_kernel_{workload}.csv")
     try:
         rows = {r.split(",")[1]: float(r.split(",")[2]) for r in f.read_text().splitlines()[1:] if r.count(",") >= 3}
         if int(rows["SQ_WAVES"]) != n_envs:
@@ -69,84 +108,194 @@ def pmc_traffic(n_envs):
         return None, None
 
 
-def cpu_baseline(capi, stream, n_envs, n_steps):
-    """The CPU oracle (a port: the reference itself is Python and cannot travel) on the host cores, same stream,
-    same features, same action distribution."""
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline leg (child process: no torch, its own OpenMP runtime with the threads pinned)
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline_child(workload, budget_s):
+    """The CPU oracle (a port: the reference itself is Python and cannot travel) on the host cores: same stream
+    generator, same features, same action distribution.  The oracle is driven through oracle_rollout - T steps per
+    env inside ONE OpenMP parallel region, 64 envs per thread - first on all cores, then on one thread."""
+    import ctypes as C
+
     sys.path.insert(0, str(ROOT / "tests"))
     import oracle_lib as ol
 
+    from rl4mm_amd import _capi
+
     cores = len(os.sched_getaffinity(0))
-    cfg = capi.make_cfg(n_envs, 10, default_features(capi), step_us=STEP_US, episode_us=EPISODE_US)
-    cpu = ol.oracle_sim(cfg)
-    cpu.add_stream(stream)
-    cpu.set_portfolio(0, 10**12)
-    rng = np.random.Generator(np.random.PCG64(1234))
-    starts = (36_000 + rng.integers(0, 60, size=n_envs)) * 1_000_000
-    cpu.reset(starts, 0)
-    acts = np.random.Generator(np.random.PCG64(42)).uniform(0, 10, size=(n_steps, n_envs, 4))
-    t0 = time.perf_counter()
-    done_steps = 0
-    for t in range(n_steps):  # bounded sample: stop after ~12 s of CPU work
-        cpu.step(acts[t])
-        done_steps += 1
-        if time.perf_counter() - t0 > 12.0:
-            break
-    dt = time.perf_counter() - t0
+    T, chunks_max, per_thread = 500, 24, 64
+    streams = build_streams(workload, T * chunks_max * STEP_US // 1_000_000 + 1)
+    lib = ol.oracle_binding().lib
+    lib.oracle_set_threads.restype = None
+    lib.oracle_set_threads.argtypes = [C.c_int]
+
+    def run(threads, n_envs, budget):
+        lib.oracle_set_threads(threads)
+        cfg = workload_cfg(_capi, workload, n_envs)
+        cpu = ol.oracle_sim(cfg)
+        for s in streams:
+            cpu.add_stream(s)
+        cpu.set_portfolio(0, 10**12)
+        starts, sids = workload_starts(workload, n_envs, len(streams), 1234)
+        t0 = time.perf_counter()
+        cpu.reset(starts, sids)
+        reset_s = time.perf_counter() - t0
+        rng = np.random.Generator(np.random.PCG64(42))
+        steps, dt = 0, 0.0
+        for _ in range(chunks_max):  # bounded sample: whole chunks until the budget is spent
+            if workload == "teradactyl":
+                policy, params, acts = _capi.POLICY_TERADACTYL, TERADACTYL_PARAMS, None
+            else:
+                policy, params, acts = _capi.POLICY_GIVEN, [], rng.uniform(0, 10, size=(T, n_envs, 4))
+            t0 = time.perf_counter()
+            out = ol.oracle_rollout(cpu, policy, params, T, acts, want_actions=False)
+            dt += time.perf_counter() - t0
+            steps += int(out["steps"].sum())
+            if dt > budget:
+                break
+        cpu.close()
+        return steps / dt, steps, dt, reset_s
+
+    all_v, all_steps, all_dt, all_reset = run(cores, per_thread * cores, budget_s)
+    one_v, one_steps, one_dt, _ = run(1, per_thread, budget_s / 3)
     return {
-        "value": n_envs * done_steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-        "sample": f"{n_envs} envs x {done_steps} steps of the same workload (oracle/lobsim_oracle.c, OpenMP over envs), {dt:.1f} s",
+        "value": all_v, "unit": "env-steps/s", "cores": cores, "threads": cores, "per_core": one_v, "kind": "port",
+        "sample": f"all cores: {per_thread * cores} envs, {all_steps} env-steps in {all_dt:.1f} s (+{all_reset:.1f} s reset incl. 3000 warm-up steps per env); "
+                  f"1 thread: {per_thread} envs, {one_steps} env-steps in {one_dt:.1f} s; oracle/lobsim_oracle.c through oracle_rollout "
+                  f"({T} steps per env per OpenMP region, static schedule, OMP_PROC_BIND=close), workload '{workload}'",
     }  # fmt: skip
 
 
+def cpu_baseline(workload, budget_s=10.0):
+    env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores", OMP_NUM_THREADS=str(len(os.sched_getaffinity(0))))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--cpu-baseline-only", "--workload", workload, "--cpu-budget", str(budget_s)],
+                       env=env, capture_output=True, text=True, timeout=600)  # fmt: skip
+    if p.returncode != 0:
+        return {"error": (p.stderr or p.stdout)[-400:]}
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# multi-GPU launcher
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`bench.py --gpus N` outside torchrun: start N ranks (one per GPU) as a child job and relay its output.  Nothing in
+    this process has touched the GPU (torch is not even imported), and the child is a new process, not an exec."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(ROOT / "bench.py"), *argv]  # fmt: skip
+    return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+
+
+def stub_rank(args, rank, world):
+    """CPU stand-in of one rank (tests/test_host_logic.py): same launcher, same barrier / max-over-ranks timing, same
+    episode-return gather - over gloo, with a step that only fills the return vector."""
+    import torch
+    import torch.distributed as dist
+
+    from rl4mm_amd.dist import gather_episode_returns, shard_range
+
+    dist.init_process_group("gloo")
+    lo, hi = shard_range(world * args.envs, rank, world)
+    returns = torch.zeros(hi - lo, dtype=torch.float64)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        returns += torch.arange(lo, hi, dtype=torch.float64)
+    dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    per_rank = [torch.zeros_like(el) for _ in range(world)]
+    dist.all_gather(per_rank, el)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    allr = gather_episode_returns(returns)
+    if rank == 0:
+        ok = bool(torch.equal(allr, args.steps * torch.arange(world * args.envs, dtype=torch.float64)))
+        print(json.dumps({"metric": "stub", "n_gpus": world, "steps": args.steps, "gathered_returns": int(allr.numel()), "gather_in_env_order": ok,
+                          "ms_per_step_per_rank": [float(x.item()) / args.steps * 1e3 for x in per_rank]}))  # fmt: skip
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--envs", type=int, default=ENVS_PER_GPU, help="envs per GPU")
+    ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default 4096; 8192 for deep50)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="random")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of all-core CPU work in the cpu_baseline sample")
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # CPU test of the launcher (gloo, no lobsim)
     args = ap.parse_args()
+    if args.envs is None:
+        args.envs = 8192 if args.workload == "deep50" else ENVS_PER_GPU
+
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline_child(args.workload, args.cpu_budget)))
+        return 0
+    under_torchrun = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if args.gpus > 1 and not under_torchrun:
+        return launch_ranks(args.gpus, sys.argv[1:])
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.stub:
+        stub_rank(args, rank, world)
+        return 0
 
     import torch
 
     from rl4mm_amd import _capi, _lib
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if "RANK" in os.environ and "MASTER_ADDR" in os.environ:  # launched by torch.distributed.run (also with one rank)
+    if under_torchrun:  # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    K, W, N = args.steps, args.warmup, args.envs
+    K, W, N, wl = args.steps, args.warmup, args.envs, args.workload
 
-    sim_seconds = (K + W) * STEP_US // 1_000_000 + 1
-    stream = build_stream(sim_seconds)
-    cfg = _capi.make_cfg(N, 10, default_features(_capi), step_us=STEP_US, episode_us=EPISODE_US, device_id=local_rank)
+    sim_seconds = (2 * K + W) * STEP_US // 1_000_000 + 1  # the timed steps, then the open-loop rollout leg's K more
+    streams = build_streams(wl, sim_seconds)
+    cfg = workload_cfg(_capi, wl, N, device_id=local_rank)
     sim = _lib.new_sim(cfg)
     # kernels run on a torch-owned (non-default) stream so the torch.cuda.Event pairs below time exactly them
     torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     sim.set_stream(torch.cuda.current_stream().cuda_stream)
-    sim.add_stream(stream)
+    for s in streams:
+        sim.add_stream(s)
     sim.set_portfolio(0, 10**12)  # initial_cash 1e12 (main_helper.py:78)
-    rng = np.random.Generator(np.random.PCG64(1234 + rank))
-    starts = (36_000 + rng.integers(0, 60, size=N)) * 1_000_000  # episode starts 10:00:00 .. 10:00:59
+    starts, sids = workload_starts(wl, N, len(streams), 1234 + rank)
     t0 = time.perf_counter()
-    sim.reset(starts, 0)  # snapshot + 3000 warm-up steps per env (5 min Volatility window)
+    sim.reset(starts, sids)  # snapshot + 3000 warm-up steps per env (5 min Volatility window)
     reset_s = time.perf_counter() - t0
 
-    acts = torch.from_numpy(np.random.Generator(np.random.PCG64(42 + rank)).uniform(0, 10, size=(K + W, N, 4))).to(dev)
     obs = torch.zeros((N, sim.obs_dim), dtype=torch.float64, device=dev)
     obs32 = torch.zeros((N, sim.obs_dim), dtype=torch.float32, device=dev)
     reward = torch.zeros(N, dtype=torch.float64, device=dev)
     done = torch.zeros(N, dtype=torch.uint8, device=dev)
     returns = torch.zeros(N, dtype=torch.float64, device=dev)
+    if wl == "teradactyl":
+        acts = None
 
-    def step(t):  # one launch of lob_step_kernel over the rank's envs; the episode return is accumulated in its epilogue
-        sim.step_device(acts[t].data_ptr(), 0, obs.data_ptr(), obs32.data_ptr(), reward.data_ptr(), done.data_ptr(), returns.data_ptr())
+        def step(t):  # one env.step() per env per launch, the rule-based agent's action computed in the kernel prologue
+            sim.rollout_device(_capi.POLICY_TERADACTYL, TERADACTYL_PARAMS, 1, 0, 0, obs.data_ptr(), obs32.data_ptr(), reward.data_ptr(), done.data_ptr(), returns.data_ptr(), 0)
+    else:
+        acts = torch.from_numpy(np.random.Generator(np.random.PCG64(42 + rank)).uniform(0, 10, size=(K + W, N, 4))).to(dev)
+
+        def step(t):  # one launch of lob_step_kernel over the rank's envs; the episode return is accumulated in its epilogue
+            sim.step_device(acts[t].data_ptr(), 0, obs.data_ptr(), obs32.data_ptr(), reward.data_ptr(), done.data_ptr(), returns.data_ptr())
 
     for t in range(W):
         step(t)
@@ -168,6 +317,7 @@ def main():
             ev[t][1].record()
     ev_all[1].record()
     torch.cuda.synchronize()
+    local_elapsed = time.perf_counter() - t0
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -175,25 +325,35 @@ def main():
     kernel_ms_sampled = float(np.mean([a.elapsed_time(b) for a, b in ev.values()]))  # event pair around single launches
     kernel_ms = ev_all[0].elapsed_time(ev_all[1]) / K  # average launch duration over the timed region (back-to-back launches)
 
-    # extra (not `value`): the same K steps as ONE launch with the pre-drawn actions (lobsim_rollout_device) - the
-    # mode the reference's rule-based baseline sweeps can use; no per-step launch tail, state stays on chip
-    roll_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-    steps_taken = torch.zeros(N, dtype=torch.int32, device=dev)
-    roll_ev[0].record()
-    sim.rollout_device(_capi.POLICY_GIVEN, [], K, acts[W:].data_ptr(), 0, obs.data_ptr(), obs32.data_ptr(), reward.data_ptr(), done.data_ptr(), 0, steps_taken.data_ptr())
-    roll_ev[1].record()
-    torch.cuda.synchronize()
-    rollout_ms = roll_ev[0].elapsed_time(roll_ev[1])
-    rollout_steps = int(steps_taken.sum().item())
+    # extra (not `value`): K more steps as ONE launch (lobsim_rollout_device) - the mode the reference's rule-based
+    # baseline sweeps can use; no per-step launch tail, state stays on chip
+    rollout = None
+    if wl in ("random", "teradactyl"):
+        roll_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        steps_taken = torch.zeros(N, dtype=torch.int32, device=dev)
+        acts2 = None if acts is None else torch.from_numpy(np.random.Generator(np.random.PCG64(4242 + rank)).uniform(0, 10, size=(K, N, 4))).to(dev)
+        roll_ev[0].record()
+        if wl == "teradactyl":
+            sim.rollout_device(_capi.POLICY_TERADACTYL, TERADACTYL_PARAMS, K, 0, 0, obs.data_ptr(), obs32.data_ptr(), reward.data_ptr(), done.data_ptr(), 0, steps_taken.data_ptr())
+        else:
+            sim.rollout_device(_capi.POLICY_GIVEN, [], K, acts2.data_ptr(), 0, obs.data_ptr(), obs32.data_ptr(), reward.data_ptr(), done.data_ptr(), 0, steps_taken.data_ptr())
+        roll_ev[1].record()
+        torch.cuda.synchronize()
+        rollout = (roll_ev[0].elapsed_time(roll_ev[1]), int(steps_taken.sum().item()))
 
     # the only collective: gather per-env episode returns (RCCL over xGMI; 32 KiB per GPU)
+    per_rank_ms = [local_elapsed / K * 1e3]
     if dist:
+        from rl4mm_amd.dist import gather_episode_returns
+
         el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
-        gathered = [torch.zeros_like(returns) for _ in range(world)]
-        dist.all_gather(gathered, returns)
-        all_returns = torch.cat(gathered)
+        mine = torch.tensor([local_elapsed / K * 1e3], dtype=torch.float64, device=dev)
+        allms = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allms, mine)
+        per_rank_ms = [float(x.item()) for x in allms]
+        all_returns = gather_episode_returns(returns)
     else:
         all_returns = returns
     n_bad = int((torch.isnan(all_returns)).sum().item())
@@ -202,40 +362,47 @@ def main():
         # algorithmic bytes per env-step: 32 B per replayed message + 105 B of step I/O
         t_lo = starts + W * STEP_US
         t_hi = t_lo + K * STEP_US
-        n_msgs = int(np.sum(np.searchsorted(stream.msgs[:, 0], t_hi, side="right") - np.searchsorted(stream.msgs[:, 0], t_lo, side="right")))
+        n_msgs = 0
+        for i, s in enumerate(streams):
+            m = sids == i
+            n_msgs += int(np.sum(np.searchsorted(s.msgs[:, 0], t_hi[m], side="right") - np.searchsorted(s.msgs[:, 0], t_lo[m], side="right")))
         m_bar = n_msgs / (N * K)
         b_step = 32.0 * m_bar + 105.0
         achieved = N * b_step / (kernel_ms * 1e-3)
-        inv, cash, _ = sim.portfolios()
-        st_bad = sum(sim.env_state(int(e))["status"] != 0 for e in range(0, N, max(1, N // 64)))
-        traffic, traffic_src = pmc_traffic(N)
+        sample = range(0, N, max(1, N // 64))
+        st_bad = sum(sim.env_state(int(e))["status"] != 0 for e in sample)
+        traffic, traffic_src = pmc_traffic(wl, N)
+        kernel = "lob_rollout_kernel (T=1)" if wl == "teradactyl" else "lob_step_kernel"
         out = {
             "metric": "env-steps/sec (batched LOB sims)", "value": world * N * K / elapsed, "unit": "env-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int64+f64", "data": "synthetic",
             "config": {
-                "workload": "4096 vectorised envs per GPU, synthetic 10-level SPY-shaped LOBSTER stream @1s snapshots, random Beta-policy actions (BASELINE.json configs[1])",
-                "envs_per_gpu": N, "global_envs": world * N, "features": "full_state (10 default features, 5 min warm-up)",
-                "step_size_s": 0.1, "reward": "PnL", "messages_per_env_step": round(m_bar, 2), "parallelism": f"env-sharded x{world}",
+                "workload": WORKLOADS[wl], "envs_per_gpu": N, "global_envs": world * N, "features": "full_state (10 default features, 5 min warm-up)",
+                "step_size_s": 0.1, "reward": "AD" if wl == "ad" else "PnL", "messages_per_env_step": round(m_bar, 2), "parallelism": f"env-sharded x{world}",
                 "reset_seconds": round(reset_s, 3), "envs_in_error_state_sampled": int(st_bad), "nan_returns": n_bad,
+                "ranks": world, "ms_per_step_per_rank": [round(x, 5) for x in per_rank_ms], "gathered_returns": int(all_returns.numel()),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
-                "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src, "kernel": "lob_step_kernel", "kernel_ms": kernel_ms, "kernel_ms_sampled_pairs": kernel_ms_sampled, "algorithmic_bytes_per_env_step": round(b_step, 1),
+                "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src, "kernel": kernel, "kernel_ms": kernel_ms,
+                "kernel_ms_sampled_pairs": kernel_ms_sampled, "algorithmic_bytes_per_env_step": round(b_step, 1),
             },
         }  # fmt: skip
-        out["open_loop_rollout"] = {
-            "value": rollout_steps / (rollout_ms * 1e-3), "unit": "env-steps/s (rank 0)", "steps_per_launch": K, "launch_ms": rollout_ms,
-            "note": "lob_rollout_kernel: K steps per env in one launch with pre-drawn actions; reported beside, never as, `value`",
-        }
+        if rollout:
+            out["open_loop_rollout"] = {
+                "value": rollout[1] / (rollout[0] * 1e-3), "unit": "env-steps/s (rank 0)", "steps_per_launch": K, "launch_ms": rollout[0],
+                "note": "lob_rollout_kernel: K steps per env in one launch; reported beside, never as, `value`",
+            }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(_capi, stream, max(256, 4 * len(os.sched_getaffinity(0))), 3000)
+            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_budget)
         print(json.dumps(out))
     if dist:
         dist.barrier()
         dist.destroy_process_group()
     sim.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -21,6 +21,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include "../include/lobsim.h"
 
@@ -1096,7 +1099,8 @@ int oracle_reset(oracle_t* h, const int32_t* env_ids, int32_t n, const int32_t* 
         if (id < 0 || id >= h->cfg.n_envs || stream_ids[i] < 0 || stream_ids[i] >= h->n_streams) return LOBSIM_ERR_ARG;
         if (episode_start_us[i] % 1000000 != 0) return LOBSIM_ERR_ARG; /* "Episodes must be started on the second" */
     }
-#pragma omp parallel for schedule(dynamic, 1)
+    /* static schedule here and in oracle_rollout: a thread keeps its envs (heap locality on multi-socket hosts) */
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < n; i++) {
         int id = env_ids ? env_ids[i] : i;
         env_reset(h, &h->env[id], stream_ids[i], episode_start_us[i]);
@@ -1166,7 +1170,7 @@ static void teradactyl_action(const double* p, double inventory, double* a) {
 int oracle_rollout(oracle_t* h, int32_t policy, const double* params8, int32_t T, const double* actions, const uint8_t* active,
                    double* obs, double* reward, uint8_t* done, double* return_acc, int32_t* steps_taken, double* actions_out) {
     int D = oracle_obs_dim(h), A = h->cfg.action_dim, N = h->cfg.n_envs;
-#pragma omp parallel for schedule(dynamic, 4)
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < N; i++) {
         if (active && !active[i]) continue;
         Env* e = &h->env[i];
@@ -1308,6 +1312,15 @@ int oracle_debug_process_orders(oracle_t* h, int32_t env, const int64_t* orders,
         fills_out[7] = e->cash - cash0;
     }
     return LOBSIM_OK;
+}
+
+/* Number of OpenMP threads of the parallel regions above (bench.py's cpu_baseline: 1-thread and all-core runs). */
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n > 0 ? n : 1);
+#else
+    (void)n;
+#endif
 }
 
 /* test-only helpers --------------------------------------------------------------------------------------- */

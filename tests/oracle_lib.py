@@ -112,20 +112,20 @@ def snapshot_row_from_levels(levels, n_levels: int) -> np.ndarray:
     return row
 
 
-def oracle_rollout(sim, policy, params, T, actions=None):
+def oracle_rollout(sim, policy, params, T, actions=None, want_actions=True):
     """Host mirror of Sim.rollout_device: -> dict(obs, reward, done, ret, steps, actions)."""
     n, A, D = sim.n_envs, sim.action_dim, sim.obs_dim
     p8 = np.zeros(8, dtype=np.float64)
     p8[: len(params)] = params
     obs = np.zeros((n, D)); reward = np.zeros(n); done = np.zeros(n, dtype=np.uint8); ret = np.zeros(n)
-    steps = np.zeros(n, dtype=np.int32); acts_out = np.zeros((max(T, 1), n, A))
+    steps = np.zeros(n, dtype=np.int32); acts_out = np.zeros((max(T, 1), n, A)) if want_actions else None
     PD, PU8, PI32 = C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
     a = None if actions is None else np.ascontiguousarray(actions, dtype=np.float64)
     rc = sim.b.lib.oracle_rollout(sim.h, policy, p8.ctypes.data_as(PD), T, None if a is None else a.ctypes.data_as(PD), None,
                                   obs.ctypes.data_as(PD), reward.ctypes.data_as(PD), done.ctypes.data_as(PU8), ret.ctypes.data_as(PD),
-                                  steps.ctypes.data_as(PI32), acts_out.ctypes.data_as(PD))
+                                  steps.ctypes.data_as(PI32), None if acts_out is None else acts_out.ctypes.data_as(PD))
     assert rc == 0
-    return dict(obs=obs, reward=reward, done=done, ret=ret, steps=steps, actions=acts_out[:T])
+    return dict(obs=obs, reward=reward, done=done, ret=ret, steps=steps, actions=None if acts_out is None else acts_out[:T])
 
 
 TERADACTYL_GOLDEN = {  # the agents oracle/gen_golden.py drove the reference with (policy parameters of lobsim_rollout_device)

@@ -31,6 +31,42 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_capi.OrderView) == 24
 
 
+def test_header_struct_sizes_compile_time(tmp_path):
+    """A C translation unit against include/lobsim.h: the sizes/offsets the ctypes mirror assumes are _Static_asserted by
+    the C compiler itself (a maintainer binding the header from another language gets the same layout)."""
+    import ctypes as C
+    import subprocess
+
+    offs = "\n".join(
+        f'_Static_assert(offsetof({cname}, {f}) == {getattr(cls, f).offset}, "{cname}.{f}");'
+        for cname, cls in (("lobsim_feature", _capi.FeatureDesc), ("lobsim_reward", _capi.RewardDesc), ("lobsim_cfg", _capi.Cfg),
+                           ("lobsim_env_state", _capi.EnvState), ("lobsim_order_view", _capi.OrderView))
+        for f, _ in cls._fields_
+    )  # fmt: skip
+    src = tmp_path / "sizes.c"
+    src.write_text(
+        '#include <stddef.h>\n#include "lobsim.h"\n'
+        f'_Static_assert(sizeof(lobsim_feature) == {C.sizeof(_capi.FeatureDesc)}, "lobsim_feature");\n'
+        f'_Static_assert(sizeof(lobsim_reward) == {C.sizeof(_capi.RewardDesc)}, "lobsim_reward");\n'
+        f'_Static_assert(sizeof(lobsim_cfg) == {C.sizeof(_capi.Cfg)}, "lobsim_cfg");\n'
+        f'_Static_assert(sizeof(lobsim_env_state) == {C.sizeof(_capi.EnvState)}, "lobsim_env_state");\n'
+        f'_Static_assert(sizeof(lobsim_order_view) == {C.sizeof(_capi.OrderView)}, "lobsim_order_view");\n'
+        f'_Static_assert(sizeof(lobsim_feature) == 56, "documented size");\n{offs}\nint main(void) {{ return 0; }}\n'
+    )
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", str(ROOT / "include"), "-c", str(src), "-o", str(tmp_path / "sizes.o")])
+
+
+def test_integration_md_struct_excerpt_matches_binding():
+    """INTEGRATION.md section 4 shows a ctypes lobsim_feature: its field list must be the real one."""
+    text = (ROOT / "INTEGRATION.md").read_text()
+    block = text[text.index("class lobsim_feature(C.Structure)") :]
+    block = block[: block.index("h = C.c_void_p()")]
+    fields = re.findall(r'\("([a-z_]+)",\s*C\.(c_[a-z0-9]+)\)', block)
+    import ctypes as C
+
+    assert [(n, getattr(C, t)) for n, t in fields] == list(_capi.FeatureDesc._fields_)
+
+
 def test_create_fails_loudly_without_gpu():
     import torch
 

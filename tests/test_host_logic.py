@@ -122,3 +122,23 @@ def test_episode_return_gather_world_size_2_gloo():
         assert p.exitcode == 0
     for r in range(2):
         assert np.array_equal(res[r], np.arange(n_total) * 0.5)
+
+
+def test_bench_gpus_flag_launches_ranks_gloo_stub():
+    """`python bench.py --gpus 2` (no torchrun around it) must itself start 2 ranks: the launcher path of bench.py with
+    the CPU stand-in step (gloo) - rank 0 prints one JSON line with n_gpus = 2 and the gathered return vector of both
+    ranks in env order."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--stub", "--steps", "3", "--envs", "37"], env=env,
+                       capture_output=True, text=True, timeout=300)  # fmt: skip
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["gathered_returns"] == 74 and out["gather_in_env_order"] and len(out["ms_per_step_per_rank"]) == 2
