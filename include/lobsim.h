@@ -125,7 +125,8 @@ typedef struct lobsim_cfg {
     int32_t inc_prev_action_in_obs;
     int32_t n_features;
     int32_t device_id; /* HIP device ordinal (ignored by the oracle) */
-    int32_t reserved0;
+    int32_t ladder_levels; /* price levels per side an env can hold: 0 = auto (64 for n_levels <= 16, else 128), 64 or 128.
+                              Exceeding it sets LOBSIM_ST_LEVEL_OVERFLOW on that env (ignored by the oracle) */
     int64_t step_us;    /* step_size */
     int64_t episode_us; /* episode_length */
     int64_t warmup_us;  /* max feature window (whole seconds) */

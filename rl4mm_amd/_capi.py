@@ -58,7 +58,7 @@ class Cfg(C.Structure):
         ("inc_prev_action_in_obs", C.c_int32),
         ("n_features", C.c_int32),
         ("device_id", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("ladder_levels", C.c_int32),
         ("step_us", C.c_int64),
         ("episode_us", C.c_int64),
         ("warmup_us", C.c_int64),
@@ -188,6 +188,7 @@ def make_cfg(
     per_step_reward=(R_PNL, 0, 0.0),
     terminal_reward=(R_PNL, 0, 0.0),
     device_id: int = 0,
+    ladder_levels: int = 0,
 ) -> Cfg:
     cfg = Cfg()
     cfg.n_envs, cfg.n_levels, cfg.tick_size, cfg.outer_levels = n_envs, n_levels, tick_size, outer_levels
@@ -214,6 +215,7 @@ def make_cfg(
     cfg.per_step_reward = _rw(per_step_reward)
     cfg.terminal_reward = _rw(terminal_reward)
     cfg.device_id = device_id
+    cfg.ladder_levels = ladder_levels
     return cfg
 
 

@@ -26,6 +26,7 @@
 namespace lobk {
 
 #define DI __device__ __forceinline__
+#define SDI static __device__ __forceinline__
 
 // Diagnostic build only (-DLOBSIM_PROFILE, tools/phase_profile.py): s_memtime stamps between the phases of a step,
 // written to a buffer nothing else reads.  The product library is built without it and contains no stamp.
@@ -56,6 +57,44 @@ struct Op8 {  // one agent order waiting to be processed (built from the pre-ste
     int32_t code;  // type (bits 0-3) | side << 4 | from_agent << 5 | idx << 8; idx = quote level (limit) or agent index
 };
 
+struct StepArgs {
+    const double* actions;  // [n_envs][A]
+    const uint8_t* active;  // [n_envs] or null
+    double* obs;            // [n_envs][obs_dim] or null
+    float* obs_f32;         // or null
+    double* reward;
+    uint8_t* done;
+    double* return_acc;     // or null: per-env sum of rewards (episode return), accumulated here
+};
+
+struct ResetArgs {
+    const int32_t* env_ids;  // [n]
+    const int32_t* stream_ids;
+    const int64_t* start_us;
+    double* obs;  // [n][obs_dim] or null
+};
+
+struct RolloutArgs {
+    int32_t policy, T;
+    const double* actions;  // LOBSIM_POLICY_GIVEN: [T][n_envs][A]
+    double params[8];
+    const uint8_t* active;
+    double* obs;
+    float* obs_f32;
+    double* reward;
+    uint8_t* done;
+    double* return_acc;
+    int32_t* steps_taken;
+};
+
+// Everything below is a member of Eng<LVT>: LVT = price levels per side the LDS-resident ladder holds (64 or 128; the HBM
+// image always has room for lobk::LV = 128).  The 64-level build is the one the 10-level configurations run: 7.5 KB of
+// ladder + agent state per env leaves LDS room for the message batch and the feature state to be prefetched by LDS-DMA.
+template <int LVT>
+struct Eng {
+static constexpr int LV = LVT;
+static constexpr int HALVES = LVT / 64;  // ladder entries per lane
+
 // 9.4 KB per env -> 16 envs (waves) per CU: all 4096 envs of a launch are resident at once
 struct Lds {
     int64_t price[2][LV];
@@ -79,13 +118,13 @@ struct Lds {
     uint32_t agent_seq;
 };
 
-DI uint64_t mk_meta(int slab, int head, int tail, int live) {
+SDI uint64_t mk_meta(int slab, int head, int tail, int live) {
     return (uint64_t)(uint32_t)slab | ((uint64_t)(uint32_t)head << 16) | ((uint64_t)(uint32_t)tail << 32) | ((uint64_t)(uint32_t)live << 48);
 }
-DI int m_slab(uint64_t m) { return (int)(m & 0xffff); }
-DI int m_head(uint64_t m) { return (int)((m >> 16) & 0xffff); }
-DI int m_tail(uint64_t m) { return (int)((m >> 32) & 0xffff); }
-DI int m_live(uint64_t m) { return (int)(m >> 48); }
+SDI int m_slab(uint64_t m) { return (int)(m & 0xffff); }
+SDI int m_head(uint64_t m) { return (int)((m >> 16) & 0xffff); }
+SDI int m_tail(uint64_t m) { return (int)((m >> 32) & 0xffff); }
+SDI int m_live(uint64_t m) { return (int)(m >> 48); }
 
 // wave-uniform scalars of the env being advanced (kept in registers)
 template <typename T>
@@ -120,32 +159,32 @@ struct Scal {
 #endif
 };
 
-DI int lane() { return (int)threadIdx.x; }
+SDI int lane() { return (int)threadIdx.x; }
 // lane mask of a predicate; the builtin takes the compare's own mask (HIP's __ballot(int) round-trips through a VGPR)
-DI uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+SDI uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 // signed 64-bit order tests for WAVE-UNIFORM values: the scalar unit has no 64-bit ordered compare, the compiler would
 // move both operands to vector registers.  Valid while |a - b| < 2^63 (prices, times, ids here are far inside that).
-DI bool lt64(int64_t a, int64_t b) { return (int32_t)(((uint64_t)a - (uint64_t)b) >> 32) < 0; }
-DI bool le64(int64_t a, int64_t b) { return !lt64(b, a); }
+SDI bool lt64(int64_t a, int64_t b) { return (int32_t)(((uint64_t)a - (uint64_t)b) >> 32) < 0; }
+SDI bool le64(int64_t a, int64_t b) { return !lt64(b, a); }
 // Lanes of ONE wave exchange data through LDS and through the env's own slabs.  A wavefront's LDS instructions and
 // its vector-memory instructions each execute in program order, so a later instruction of the same wave observes an
 // earlier one's write without any s_waitcnt; what must be prevented is the COMPILER moving or caching accesses
 // across the hand-off.  A wavefront-scope fence is exactly that: no instruction emitted, no vmcnt(0) drain (a
 // __syncthreads() here cost a full global-store round trip per order: 0.94 ms -> see profiles/).
-DI void wsync() {
+SDI void wsync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 
-DI int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-DI int32_t rl32(int32_t v, int src) { return __builtin_amdgcn_readlane(v, src); }
-DI int64_t rl64(int64_t v, int src) {
+SDI int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+SDI int32_t rl32(int32_t v, int src) { return __builtin_amdgcn_readlane(v, src); }
+SDI int64_t rl64(int64_t v, int src) {
     int32_t lo = __builtin_amdgcn_readlane((int32_t)(v & 0xffffffffll), src);
     int32_t hi = __builtin_amdgcn_readlane((int32_t)(v >> 32), src);
     return ((int64_t)hi << 32) | (uint32_t)lo;
 }
-DI double rld(double v, int src) { return __longlong_as_double(rl64(__double_as_longlong(v), src)); }
-DI int64_t uni64(int64_t v) {
+SDI double rld(double v, int src) { return __longlong_as_double(rl64(__double_as_longlong(v), src)); }
+SDI int64_t uni64(int64_t v) {
     int32_t lo = uni((int32_t)(v & 0xffffffffll)), hi = uni((int32_t)(v >> 32));
     return ((int64_t)hi << 32) | (uint32_t)lo;
 }
@@ -153,8 +192,8 @@ DI int64_t uni64(int64_t v) {
 // Inclusive prefix sum over the 64 lanes with DPP row shifts + row broadcasts (gfx9 cross-lane ALU path, a few
 // cycles per step) instead of six ds_bpermute round trips.  Lanes a shift has no source for add 0.
 template <int CTRL, int ROW_MASK>
-DI int32_t dpp_add(int32_t v) { return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false); }
-DI int32_t wave_incl_scan(int32_t v) {
+SDI int32_t dpp_add(int32_t v) { return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false); }
+SDI int32_t wave_incl_scan(int32_t v) {
     v = dpp_add<0x111, 0xf>(v);  // row_shr:1
     v = dpp_add<0x112, 0xf>(v);  // row_shr:2
     v = dpp_add<0x114, 0xf>(v);  // row_shr:4
@@ -163,15 +202,15 @@ DI int32_t wave_incl_scan(int32_t v) {
     v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
     return v;
 }
-DI int32_t wave_sum(int32_t v) { return rl32(wave_incl_scan(v), 63); }
-DI int popc64(uint64_t m) { return __popcll(m); }
-DI int ffs64(uint64_t m) { return __ffsll((unsigned long long)m) - 1; }     // lowest set bit, -1 if none
-DI int fls64(uint64_t m) { return m ? 63 - __clzll((long long)m) : -1; }   // highest set bit
+SDI int32_t wave_sum(int32_t v) { return rl32(wave_incl_scan(v), 63); }
+SDI int popc64(uint64_t m) { return __popcll(m); }
+SDI int ffs64(uint64_t m) { return __ffsll((unsigned long long)m) - 1; }     // lowest set bit, -1 if none
+SDI int fls64(uint64_t m) { return m ? 63 - __clzll((long long)m) : -1; }   // highest set bit
 
 // bit masks kept in LDS (see Lds): uniform reads, lane 0 writes
-DI uint64_t lds_u64(const unsigned long long& w) { return (uint64_t)uni64((int64_t)w); }
+SDI uint64_t lds_u64(const unsigned long long& w) { return (uint64_t)uni64((int64_t)w); }
 template <int N>
-DI int mask_take_first(unsigned long long (&w)[N]) {
+SDI int mask_take_first(unsigned long long (&w)[N]) {
     int r = -1;
 #pragma unroll
     for (int i = 0; i < N; i++) {
@@ -182,13 +221,13 @@ DI int mask_take_first(unsigned long long (&w)[N]) {
     wsync();
     return r;
 }
-DI void mask_set(unsigned long long* w, int bit) {
+SDI void mask_set(unsigned long long* w, int bit) {
     if (lane() == 0) w[bit >> 6] |= 1ull << (bit & 63);
 }
 // portfolio and per-step fill counters (in LDS, see Lds)
-DI int64_t cur_inv(const Lds& L) { return uni64(L.inv); }
-DI int64_t cur_cash(const Lds& L) { return uni64(L.cash); }
-DI void trade(Lds& L, int64_t dinv, int64_t dcash) {
+SDI int64_t cur_inv(const Lds& L) { return uni64(L.inv); }
+SDI int64_t cur_cash(const Lds& L) { return uni64(L.cash); }
+SDI void trade(Lds& L, int64_t dinv, int64_t dcash) {
     if (lane() == 0) { L.inv += dinv; L.cash += dcash; }
 }
 
@@ -196,25 +235,28 @@ DI void trade(Lds& L, int64_t dinv, int64_t dcash) {
 // ---------------------------------------------------------------------------------------------------------------
 // price ladder (LDS): sorted best first; SortedDict of rl4mm/orderbook/models.py:64-69
 // ---------------------------------------------------------------------------------------------------------------
-DI int find_level(const Lds& L, const Scal& S, int side, int64_t price) {
+SDI int find_level(const Lds& L, const Scal& S, int side, int64_t price) {
     int n = S.n_lv[side], ln = lane();
     bool m0 = ln < n && L.price[side][ln] == price;
-    bool m1 = ln + 64 < n && L.price[side][ln + 64] == price;
-    uint64_t b0 = ballot(m0), b1 = ballot(m1);
+    uint64_t b0 = ballot(m0);
     if (b0) return ffs64(b0);
-    if (b1) return 64 + ffs64(b1);
+    if constexpr (HALVES > 1) {
+        bool m1 = ln + 64 < n && L.price[side][ln + 64] == price;
+        uint64_t b1 = ballot(m1);
+        if (b1) return 64 + ffs64(b1);
+    }
     return -1;
 }
 
 // find_level + the level's packed meta word in one LDS round trip: each lane reads the price and the meta word of its
 // level together, the hit lane's meta is broadcast with readlane (no second, dependent ds_read)
-DI int find_level_meta(const Lds& L, const Scal& S, int side, int64_t price, uint64_t& meta) {
+SDI int find_level_meta(const Lds& L, const Scal& S, int side, int64_t price, uint64_t& meta) {
     int n = S.n_lv[side], ln = lane();
     int64_t p0 = L.price[side][ln];
     uint64_t q0 = L.meta[side][ln];
     uint64_t b0 = ballot(ln < n && p0 == price);
     if (b0) { int i = ffs64(b0); meta = (uint64_t)rl64((int64_t)q0, i); return i; }
-    if (n > 64) {
+    if constexpr (HALVES > 1) if (n > 64) {
         int64_t p1 = L.price[side][ln + 64];
         uint64_t q1 = L.meta[side][ln + 64];
         uint64_t b1 = ballot(ln + 64 < n && p1 == price);
@@ -224,29 +266,33 @@ DI int find_level_meta(const Lds& L, const Scal& S, int side, int64_t price, uin
     return -1;
 }
 
-DI int insert_pos(const Lds& L, const Scal& S, int side, int64_t price) {
+SDI int insert_pos(const Lds& L, const Scal& S, int side, int64_t price) {
     int n = S.n_lv[side], ln = lane();
     bool m0 = ln < n && (side == LOBSIM_BUY ? L.price[side][ln] > price : L.price[side][ln] < price);
-    bool m1 = ln + 64 < n && (side == LOBSIM_BUY ? L.price[side][ln + 64] > price : L.price[side][ln + 64] < price);
-    return popc64(ballot(m0)) + popc64(ballot(m1));
+    int r = popc64(ballot(m0));
+    if constexpr (HALVES > 1) {
+        bool m1 = ln + 64 < n && (side == LOBSIM_BUY ? L.price[side][ln + 64] > price : L.price[side][ln + 64] < price);
+        r += popc64(ballot(m1));
+    }
+    return r;
 }
 
 // open an empty level at sorted position pos; returns false on overflow
-DI bool ladder_insert(Lds& L, Scal& S, int side, int pos, int64_t price) {
+SDI bool ladder_insert(Lds& L, Scal& S, int side, int pos, int64_t price) {
     int n = S.n_lv[side], ln = lane();
     EVENT(ev_ladder);
     if (n >= LV) { S.status |= LOBSIM_ST_LEVEL_OVERFLOW; return false; }
     int slab = mask_take_first(L.slab_free);
-    int64_t p[2]; uint64_t m[2]; int32_t v[2]; bool take[2];
+    int64_t p[HALVES]; uint64_t m[HALVES]; int32_t v[HALVES]; bool take[HALVES];
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
+    for (int r = 0; r < HALVES; r++) {
         int i = ln + 64 * r;
-        take[r] = i > pos && i <= n;
+        take[r] = i > pos && i <= n && i < LV;
         if (take[r]) { p[r] = L.price[side][i - 1]; m[r] = L.meta[side][i - 1]; v[r] = L.vol[side][i - 1]; }
     }
     wsync();
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
+    for (int r = 0; r < HALVES; r++) {
         int i = ln + 64 * r;
         if (take[r]) { L.price[side][i] = p[r]; L.meta[side][i] = m[r]; L.vol[side][i] = v[r]; }
     }
@@ -257,20 +303,20 @@ DI bool ladder_insert(Lds& L, Scal& S, int side, int pos, int64_t price) {
     return true;
 }
 
-DI void ladder_remove(Lds& L, Scal& S, int side, int pos) {
+SDI void ladder_remove(Lds& L, Scal& S, int side, int pos) {
     int n = S.n_lv[side], ln = lane();
     EVENT(ev_ladder);
     mask_set(L.slab_free, m_slab((uint64_t)uni64((int64_t)L.meta[side][pos])));
-    int64_t p[2]; uint64_t m[2]; int32_t v[2]; bool take[2];
+    int64_t p[HALVES]; uint64_t m[HALVES]; int32_t v[HALVES]; bool take[HALVES];
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
+    for (int r = 0; r < HALVES; r++) {
         int i = ln + 64 * r;
         take[r] = i >= pos && i < n - 1;
         if (take[r]) { p[r] = L.price[side][i + 1]; m[r] = L.meta[side][i + 1]; v[r] = L.vol[side][i + 1]; }
     }
     wsync();
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
+    for (int r = 0; r < HALVES; r++) {
         int i = ln + 64 * r;
         if (take[r]) { L.price[side][i] = p[r]; L.meta[side][i] = m[r]; L.vol[side][i] = v[r]; }
     }
@@ -282,9 +328,9 @@ DI void ladder_remove(Lds& L, Scal& S, int side, int pos) {
 // ---------------------------------------------------------------------------------------------------------------
 // level queues (HBM slabs): deque of rl4mm/orderbook/models.py:66
 // ---------------------------------------------------------------------------------------------------------------
-DI Slot dead_slot() { Slot s; s.id = 0; s.vol = 0; s.kind = K_DEAD; return s; }
+SDI Slot dead_slot() { Slot s; s.id = 0; s.vol = 0; s.kind = K_DEAD; return s; }
 
-DI Slot load_slot(const Slot* sl, int i, int head, int tail) {
+SDI Slot load_slot(const Slot* sl, int i, int head, int tail) {
     if (i >= head && i < tail) return sl[i];
     return dead_slot();
 }
@@ -292,14 +338,14 @@ DI Slot load_slot(const Slot* sl, int i, int head, int tail) {
 // position cache of external orders: where order `id` was last put.  Written at every append and every squeeze, never
 // cleared; a reader bounds-checks the entry and verifies it against the slot inside the live range of the level that
 // owns the slab, so a stale or aliased entry is only a miss.
-DI uint32_t idc_tag(int64_t id) { return (uint32_t)((uint64_t)id >> 15); }
-DI void idc_put(const Scal& S, int64_t id, int slab, int pos) {
+SDI uint32_t idc_tag(int64_t id) { return (uint32_t)((uint64_t)id >> 15); }
+SDI void idc_put(const Scal& S, int64_t id, int slab, int pos) {
     S.idc[(uint64_t)id & (IDC_N - 1)] = ((uint64_t)idc_tag(id) << 32) | ((uint64_t)slab << 16) | (uint64_t)pos;
 }
 
 // squeeze tombstones out of a slab (FIFO order kept); chunk by chunk, in place: a chunk's survivors always land
 // at or below the chunk's own first slot, so nothing unread is overwritten.  Returns the new meta word.
-DI uint64_t compact_level(Lds& L, Scal& S, int side, int idx, uint64_t m) {
+SDI uint64_t compact_level(Lds& L, Scal& S, int side, int idx, uint64_t m) {
     int ln = lane();
     EVENT(ev_compact);
     int slab = m_slab(m), head = m_head(m), tail = m_tail(m);
@@ -322,7 +368,7 @@ DI uint64_t compact_level(Lds& L, Scal& S, int side, int idx, uint64_t m) {
     return mk_meta(slab, 0, out, m_live(m));
 }
 
-DI void level_append(Lds& L, Scal& S, int side, int idx, int64_t id, int32_t vol, int32_t kind, uint64_t m) {
+SDI void level_append(Lds& L, Scal& S, int side, int idx, int64_t id, int32_t vol, int32_t kind, uint64_t m) {
     if (m_tail(m) == SLOTS || m_tail(m) - m_head(m) - m_live(m) >= LOBSIM_TOMB) {  // full, or a chunk's worth of tombstones
         m = compact_level(L, S, side, idx, m);
         if (m_tail(m) == SLOTS) { S.status |= LOBSIM_ST_QUEUE_OVERFLOW; return; }
@@ -339,7 +385,7 @@ DI void level_append(Lds& L, Scal& S, int side, int idx, int64_t id, int32_t vol
     wsync();
 }
 
-DI int alloc_agent(Lds& L, Scal& S) {
+SDI int alloc_agent(Lds& L, Scal& S) {
     int a = mask_take_first(L.agent_free);
     if (a < 0) S.status |= LOBSIM_ST_AGENT_OVERFLOW;
     return a;
@@ -347,7 +393,7 @@ DI int alloc_agent(Lds& L, Scal& S) {
 
 // Take `rv` shares off slot `pos` (whose current contents are pv / pk / pid) of level idx (meta word m): the tail of
 // _reduce_order_with_queue_position + _clear_empty_orders_and_prices (Exchange.py:219-247).
-DI void reduce_slot(Lds& L, Scal& S, int side, int idx, uint64_t m, int pos, int32_t rv, int32_t pv, int32_t pk, int64_t pid) {
+SDI void reduce_slot(Lds& L, Scal& S, int side, int idx, uint64_t m, int pos, int32_t rv, int32_t pv, int32_t pk, int64_t pid) {
     int ln = lane();
     int head = m_head(m), tail = m_tail(m);
     Slot* sl = S.slots + (size_t)m_slab(m) * SLOTS;
@@ -371,7 +417,7 @@ DI void reduce_slot(Lds& L, Scal& S, int side, int idx, uint64_t m, int pos, int
 // remove_order + _find_queue_position (Exchange.py:122-147,196-217) on the central book.  kind/id name the target:
 // (K_EXT, external id) for historical messages, (K_AGENT, agent index) for the agent's own cancellations.
 // vol < 0 means "Deletion without volume".
-DI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, int64_t id, int32_t vol) {
+SDI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, int64_t id, int32_t vol) {
     uint64_t m;
     int idx = find_level_meta(L, S, side, price, m);
     if (idx < 0) return;  // warn + KeyError -> continue
@@ -410,7 +456,7 @@ DI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, int
 }
 
 // cuts strictly inside the executed interval (from, from + ex) of one resting order (all lanes run the same trip count)
-DI int32_t cuts_inside(const int32_t* cuts, int n_cuts, int32_t from, int32_t ex) {
+SDI int32_t cuts_inside(const int32_t* cuts, int n_cuts, int32_t from, int32_t ex) {
     int32_t k = 0;
     for (int i = 0; i < n_cuts; i++) { const int32_t c = cuts[i]; k += (c > from && c < from + ex) ? 1 : 0; }
     return k;
@@ -423,7 +469,7 @@ DI int32_t cuts_inside(const int32_t* cuts, int n_cuts, int32_t from, int32_t ex
 // one sweep (identical book: each order of the run continues where the previous one stopped); L.cur holds the cumulative
 // volumes at which one order of the run ends and the next begins.  The reference records one fill per (aggressor,
 // resting order) pair, so a resting order whose executed interval contains a cut counts once more per cut.
-DI int32_t execute(Lds& L, Scal& S, int side, bool is_agent, bool is_market, int64_t price, int32_t rem, int n_cuts = 0) {
+SDI int32_t execute(Lds& L, Scal& S, int side, bool is_agent, bool is_market, int64_t price, int32_t rem, int n_cuts = 0) {
     const int opp = side ^ 1;
     int ln = lane();
     const int32_t total = rem;
@@ -507,7 +553,7 @@ DI int32_t execute(Lds& L, Scal& S, int side, bool is_agent, bool is_market, int
 }
 
 // submit_order (Exchange.py:71-83): cross -> execute, remainder rests at the back of its level's queue
-DI void submit_limit(Lds& L, Scal& S, int side, int64_t price, int32_t vol, bool is_agent, int64_t ext_id) {
+SDI void submit_limit(Lds& L, Scal& S, int side, int64_t price, int32_t vol, bool is_agent, int64_t ext_id) {
     const int opp = side ^ 1;
     // one LDS round trip serves both questions: does it cross (best opposite price), and where does it rest
     const int64_t bp = uni64(L.price[opp][0]);
@@ -534,7 +580,7 @@ DI void submit_limit(Lds& L, Scal& S, int side, int64_t price, int32_t vol, bool
 }
 
 // process_order (Exchange.py:58-69) for one historical message
-DI void process_message(Lds& L, Scal& S, int type, int side, int64_t price, int64_t vol64, int64_t ext_id) {
+SDI void process_message(Lds& L, Scal& S, int type, int side, int64_t price, int64_t vol64, int64_t ext_id) {
     if (vol64 == 0) { S.status |= LOBSIM_ST_ASSERT; return; }  // assert order.volume > 0 (the packed field is unsigned)
     int32_t vol = (vol64 >> 31) ? 0x7fffffff : (int32_t)vol64;
     switch (type) {
@@ -548,7 +594,7 @@ DI void process_message(Lds& L, Scal& S, int type, int side, int64_t price, int6
 
 // one entry of the agent op list.  Prices are implied: a limit quotes level idx of the best prices the list was
 // built against; a cancellation (and a resync re-add, from_agent) takes the price of the agent entry it names.
-DI void process_op(Lds& L, Scal& S, const DevCfg& C, Op8 op) {
+SDI void process_op(Lds& L, Scal& S, const DevCfg& C, Op8 op) {
     op.code = uni(op.code); op.vol = uni(op.vol);  // same value in every lane: keep the dispatch on the scalar unit
     int type = op.code & 0xf, side = (op.code >> 4) & 1, from_agent = (op.code >> 5) & 1, idx = op.code >> 8;
     if (!(op.vol > 0)) { S.status |= LOBSIM_ST_ASSERT; return; }
@@ -565,7 +611,7 @@ DI void process_op(Lds& L, Scal& S, const DevCfg& C, Op8 op) {
 // ---------------------------------------------------------------------------------------------------------------
 // action -> agent order list (HistoricalOrderbookEnvironment.py:206-331)
 // ---------------------------------------------------------------------------------------------------------------
-DI double np_pairwise_sum(const double* a, int n) {  // numpy add.reduce order for n <= 128
+SDI double np_pairwise_sum(const double* a, int n) {  // numpy add.reduce order for n <= 128
     if (n < 8) { double r = 0.; for (int i = 0; i < n; i++) r += a[i]; return r; }
     double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
     int i;
@@ -585,16 +631,16 @@ struct Act5 {  // the action vector as five scalars (an array indexed at run tim
         return i == 4 ? e : r;
     }
 };
-DI double act_at(const Act5& a, int i) { return a.at(i); }
+SDI double act_at(const Act5& a, int i) { return a.at(i); }
 
-DI void push_op(Lds& L, Scal& S, int type, int side, int idx, int32_t vol) {
+SDI void push_op(Lds& L, Scal& S, int type, int side, int idx, int32_t vol) {
     if (lane() == 0 && S.n_ops < OPS_MAX) { Op8 o; o.vol = vol; o.code = type | (side << 4) | (idx << 8); L.ops[S.n_ops] = o; }
     S.n_ops++;
 }
 
 // Builds L.ops from the action and the PRE-step book; nothing is mutated (the reference computes the whole
 // order list first and only then hands it to the simulator).
-DI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action) {
+SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action) {
     const lobsim_cfg& c = C.c;
     const int Q = C.Q, ln = lane();
     const int64_t tick = c.tick_size;
@@ -762,7 +808,7 @@ DI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action) {
 }
 
 // per-lane binary search of a price in the sorted ladder of one side; -1 if there is no such level
-DI int lane_find_level(const Lds& L, int side, int n, int64_t price) {
+SDI int lane_find_level(const Lds& L, int side, int n, int64_t price) {
     int lo = 0, hi = n;
     while (lo < hi) {
         int mid = (lo + hi) >> 1;
@@ -780,7 +826,7 @@ DI int lane_find_level(const Lds& L, int side, int n, int64_t price) {
 // (no queue scan), and level totals shared by several cancellations are updated with LDS atomics.  Anything unusual
 // (level missing, slab full or due for compaction, stale position) is left to the sequential path: the returned
 // mask has one bit per op still to be replayed in list order.  Requires S.n_ops <= 64.
-DI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
+SDI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
     const int ln = lane(), n = S.n_ops;
     const uint64_t below = (1ull << ln) - 1;
     const bool have = ln < n;
@@ -865,7 +911,7 @@ DI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
 // ---------------------------------------------------------------------------------------------------------------
 // simulator: snapshot -> book, outer-level resync, message replay
 // ---------------------------------------------------------------------------------------------------------------
-DI void ladder_clear(Lds& L, Scal& S) {
+SDI void ladder_clear(Lds& L, Scal& S) {
     S.n_lv.v = 0;
     S.ladder_ver = 0;
     if (lane() < NSLAB / 64) L.slab_free[lane()] = ~0ull;
@@ -880,7 +926,7 @@ DI void ladder_clear(Lds& L, Scal& S) {
 }
 
 // book[direction][price] = deque([LimitOrder(internal_id=-1)]) (Exchange.py:172-178, OrderbookSimulator.py:130)
-DI void set_level_to_snapshot(Lds& L, Scal& S, int side, int64_t price, int32_t vol) {
+SDI void set_level_to_snapshot(Lds& L, Scal& S, int side, int64_t price, int32_t vol) {
     int idx = find_level(L, S, side, price);
     if (idx < 0) {
         idx = insert_pos(L, S, side, price);
@@ -896,27 +942,31 @@ DI void set_level_to_snapshot(Lds& L, Scal& S, int side, int64_t price, int32_t 
 }
 
 // orderbook_price_range (Exchange.py:158-169): lowest buy price > 0 and highest sell price < 9999999999
-DI bool price_range(const Lds& L, const Scal& S, int64_t& worst_buy, int64_t& worst_sell) {
+SDI bool price_range(const Lds& L, const Scal& S, int64_t& worst_buy, int64_t& worst_sell) {
     int ln = lane();
     int nb = S.n_lv[0], ns = S.n_lv[1];
-    uint64_t b0 = ballot(ln < nb && L.price[0][ln] > 0), b1 = ballot(ln + 64 < nb && L.price[0][ln + 64] > 0);
-    uint64_t s0 = ballot(ln < ns && L.price[1][ln] < DUMMY_PRICE), s1 = ballot(ln + 64 < ns && L.price[1][ln + 64] < DUMMY_PRICE);
-    int ib = b1 ? 64 + fls64(b1) : fls64(b0), is = s1 ? 64 + fls64(s1) : fls64(s0);
+    uint64_t b0 = ballot(ln < nb && L.price[0][ln] > 0), s0 = ballot(ln < ns && L.price[1][ln] < DUMMY_PRICE);
+    int ib = fls64(b0), is = fls64(s0);
+    if constexpr (HALVES > 1) {
+        uint64_t b1 = ballot(ln + 64 < nb && L.price[0][ln + 64] > 0), s1 = ballot(ln + 64 < ns && L.price[1][ln + 64] < DUMMY_PRICE);
+        if (b1) ib = 64 + fls64(b1);
+        if (s1) is = 64 + fls64(s1);
+    }
     if (ib < 0 || is < 0) return false;  // StopIteration
     worst_buy = uni64(L.price[0][ib]);
     worst_sell = uni64(L.price[1][is]);
     return true;
 }
 
-DI double best_buy_d(const Lds& L, const Scal& S) { return S.n_lv[0] ? (double)uni64(L.price[0][0]) : 0.0; }
-DI double best_sell_d(const Lds& L, const Scal& S) { return S.n_lv[1] ? (double)uni64(L.price[1][0]) : (double)INFINITY; }
+SDI double best_buy_d(const Lds& L, const Scal& S) { return S.n_lv[0] ? (double)uni64(L.price[0][0]) : 0.0; }
+SDI double best_sell_d(const Lds& L, const Scal& S) { return S.n_lv[1] ? (double)uni64(L.price[1][0]) : (double)INFINITY; }
 
 struct alignas(16) I64x2 { int64_t x, y; };
 
 struct Ranges { double min_buy, max_sell, init_buy, init_sell; };
 
 // update_outer_levels (OrderbookSimulator.py:105-135)
-DI void resync_outer_levels(Lds& L, Scal& S, const DevCfg& C, const StreamDev& st, int64_t now_us, Ranges& R) {
+SDI void resync_outer_levels(Lds& L, Scal& S, const DevCfg& C, const StreamDev& st, int64_t now_us, Ranges& R) {
     const int Lv = C.c.n_levels, ln = lane();
     int64_t sec = now_us / 1000000 - st.first_sec;
     // (a load through a pointer that was itself loaded from memory is a flat-address-space load, which the compiler
@@ -980,7 +1030,7 @@ struct MsgBatch { int64_t t, eid, price, meta; };
 typedef long long ll2_t __attribute__((ext_vector_type(2)));
 typedef const ll2_t __attribute__((address_space(1)))* GlobalI64x2;  // global (not flat) loads of the packed stream
 
-DI MsgBatch fetch_messages(const StreamDev& st, int64_t cursor) {
+SDI MsgBatch fetch_messages(const StreamDev& st, int64_t cursor) {
     MsgBatch b = {INT64_MAX, 0, 0, 0};
     const int64_t i = cursor + lane();
     if (i < st.n_msgs) {
@@ -999,7 +1049,7 @@ DI MsgBatch fetch_messages(const StreamDev& st, int64_t cursor) {
 // cancellation never changes where an append lands (tail positions only grow); compaction and level creation are not
 // taken here.  Returns the lanes appended; `seg_end` = first lane that needs the general routine first (or cnt).
 // Half of all messages take this path with no scalar-unit work per message.
-DI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt, int& seg_end, int& li_memo, uint32_t& memo_levels) {
+SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt, int& seg_end, int& li_memo, uint32_t& memo_levels) {
     const int ln = lane();
     const bool in = ln >= j0 && ln < cnt;
     const int type = (int)((b.meta >> LOBSIM_TYPE_SHIFT) & 0xf), side = (int)((b.meta >> LOBSIM_SIDE_SHIFT) & 1);
@@ -1086,7 +1136,7 @@ DI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt, 
 // the window (now, until] of historical messages, in stream order (OrderbookSimulator.py:70-85).  `b` is the batch
 // at `cursor`, requested by the caller as early as it knew the cursor (the step kernel asks for it before it builds
 // the agent's orders, so the stream's HBM latency hides behind that work).
-DI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, int64_t until_us, MsgBatch b) {
+SDI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, int64_t until_us, MsgBatch b) {
     const int ln = lane();
     while (!S.status) {
         uint64_t bm = ballot(b.t <= until_us);
@@ -1168,7 +1218,7 @@ DI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, i
 }
 
 // microprice (models.py:80-97)
-DI bool microprice(const Lds& L, const Scal& S, double& out) {
+SDI bool microprice(const Lds& L, const Scal& S, double& out) {
     if (!S.n_lv[0] || !S.n_lv[1]) return false;
     int64_t bv = uni(L.vol[0][0]), av = uni(L.vol[1][0]);
     if (bv + av == 0) return false;
@@ -1190,10 +1240,10 @@ struct StepView {  // what Feature._update reads from State
     bool book_ok;
 };
 
-DI double clampd(double x, double lo, double hi) { double m = x < hi ? x : hi; return m > lo ? m : lo; }
+SDI double clampd(double x, double lo, double hi) { double m = x < hi ? x : hi; return m > lo ? m : lo; }
 
 // Feature._update; returns false where the reference would raise
-DI bool feature_raw(const lobsim_feature& d, FeatState& f, int64_t* ring, const StepView& v) {
+SDI bool feature_raw(const lobsim_feature& d, FeatState& f, int64_t* ring, const StepView& v) {
     const int lb = d.lookback;
     double* pr = reinterpret_cast<double*>(ring);
     // The ring words the steady-state branches below read, requested for all feature lanes at once: the switch runs
@@ -1330,7 +1380,7 @@ DI bool feature_raw(const lobsim_feature& d, FeatState& f, int64_t* ring, const 
 }
 
 // lane f's normalisation history, or null when feature f is not normalised
-DI double* norm_history(const DevCfg& C, const DevPtrs& P, int env, int f) {
+SDI double* norm_history(const DevCfg& C, const DevPtrs& P, int env, int f) {
     if (!P.norm || f >= C.c.n_features || C.c.features[f].norm_len <= 0) return nullptr;
     return P.norm + (size_t)env * C.norm_words + C.norm_off[f];
 }
@@ -1341,7 +1391,7 @@ DI double* norm_history(const DevCfg& C, const DevPtrs& P, int env, int f) {
 // that are added left to right.  The history is a ring (deque(maxlen)): element i is a[(start + i) mod cap].  One lane
 // per feature walks it serially, as everywhere in the feature phase; the explicit stacks make this the part of the
 // EXTRAS kernel variants that uses private memory.
-DI double np_leaf_ring(const double* a, int cap, int first, int n, bool centered, double mean) {
+SDI double np_leaf_ring(const double* a, int cap, int first, int n, bool centered, double mean) {
     auto at = [&](int i) { int k = first + i; k = k >= cap ? k - cap : k; const double x = a[k]; return centered ? (x - mean) * (x - mean) : x; };
     if (n < 8) { double r = 0.; for (int i = 0; i < n; i++) r += at(i); return r; }
     double r0 = at(0), r1 = at(1), r2 = at(2), r3 = at(3), r4 = at(4), r5 = at(5), r6 = at(6), r7 = at(7);
@@ -1351,7 +1401,7 @@ DI double np_leaf_ring(const double* a, int cap, int first, int n, bool centered
     for (; i < n; i++) res += at(i);
     return res;
 }
-DI double np_sum_ring(const double* a, int cap, int start, int n, bool centered, double mean) {
+SDI double np_sum_ring(const double* a, int cap, int start, int n, bool centered, double mean) {
     double total = 0.;
     for (int coff = 0; coff < n; coff += 8192) {
         // depth-first over the pairwise tree of this chunk; `red` = additions owed once the subtree's sum is known
@@ -1380,7 +1430,7 @@ DI double np_sum_ring(const double* a, int cap, int start, int n, bool centered,
 }
 // Feature.normalise: history.append(value) [preceded by value + 1e-06 when the history is empty], then
 // scipy.stats.zscore(history)[-1] = (value - mean) / std, numpy mean and std(ddof=0).  hist[0] = count | start << 32.
-DI double feature_normalise(double* hist, int cap, double value) {
+SDI double feature_normalise(double* hist, int cap, double value) {
     int64_t* hw = reinterpret_cast<int64_t*>(hist);
     int n = (int)(hw[0] & 0xffffffff), start = (int)(hw[0] >> 32);
     double* a = hist + 1;
@@ -1395,7 +1445,7 @@ DI double feature_normalise(double* hist, int cap, double value) {
     return (value - mean) / sqrt(var);
 }
 
-DI bool feature_reset(const lobsim_feature& d, FeatState& f, int64_t* ring, const StepView& v, int64_t first_usage, double* hist) {  // _reset, :92-96
+SDI bool feature_reset(const lobsim_feature& d, FeatState& f, int64_t* ring, const StepView& v, int64_t first_usage, double* hist) {  // _reset, :92-96
     if (hist) reinterpret_cast<int64_t*>(hist)[0] = 0;  // history.clear()
     f.count = 0; f.pos = 0; f.total = 0; f.diff = 0; f.acc = 0.0; f.p_first = 0.0; f.p_last = 0.0;
     f.first_usage_us = first_usage;
@@ -1406,7 +1456,7 @@ DI bool feature_reset(const lobsim_feature& d, FeatState& f, int64_t* ring, cons
 }
 
 template <bool EXTRAS>
-DI bool feature_update(const lobsim_feature& d, FeatState& f, int64_t* ring, const StepView& v, double* hist) {  // update, :80-86
+SDI bool feature_update(const lobsim_feature& d, FeatState& f, int64_t* ring, const StepView& v, double* hist) {  // update, :80-86
     if (v.now_us < f.first_usage_us) return true;
     if (d.update_us <= 0xffffffffll ? (v.now_mod_min % (uint32_t)d.update_us != 0) : ((int64_t)v.now_mod_min % d.update_us != 0)) return true;  // _now_is_multiple_of_update_freq
     if (!feature_raw(d, f, ring, v)) return false;
@@ -1416,7 +1466,7 @@ DI bool feature_update(const lobsim_feature& d, FeatState& f, int64_t* ring, con
     return true;
 }
 
-DI double reward_of(const lobsim_reward& r, int64_t inv0, int64_t cash0, double p0, int64_t inv1, int64_t cash1, double p1) {
+SDI double reward_of(const lobsim_reward& r, int64_t inv0, int64_t cash0, double p0, int64_t inv1, int64_t cash1, double p1) {
     double cur = (double)cash0 + (double)inv0 * p0;  // PnL.calculate, RewardFunctions.py:98-101
     double nxt = (double)cash1 + (double)inv1 * p1;
     double pnl = nxt - cur;
@@ -1433,7 +1483,7 @@ DI double reward_of(const lobsim_reward& r, int64_t inv0, int64_t cash0, double 
 // (by now consumed) op list in LDS; mean and std follow numpy's pairwise summation order.  A non-positive AUM is the
 // reference's `raise Exception` -> LOBSIM_ST_ASSERT.  log/exp here are ocml's, the reference's are numpy's SIMD ones:
 // parity for this reward is to a tolerance, every other reward and feature is bit-exact.
-DI double rolling_sharpe(Lds& L, Scal& S, const lobsim_reward& r, double* st, int64_t cash, int64_t inv, double price) {
+SDI double rolling_sharpe(Lds& L, Scal& S, const lobsim_reward& r, double* st, int64_t cash, int64_t inv, double price) {
     const int ln = lane();
     const int W = r.max_window;
     const int64_t word = uni64(((const int64_t*)st)[0]);
@@ -1479,7 +1529,7 @@ DI double rolling_sharpe(Lds& L, Scal& S, const lobsim_reward& r, double* st, in
 // EXTRAS selects the kernel variant that carries the RollingSharpe and the normalisation code: configurations without them (the default
 // rewards are PnL / inventory-adjusted PnL) run a variant whose register allocation does not pay for it.
 template <bool EXTRAS>
-DI double step_reward(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, int env, bool terminal, int64_t inv0, int64_t cash0, double p0, double price) {
+SDI double step_reward(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, int env, bool terminal, int64_t inv0, int64_t cash0, double p0, double price) {
     const lobsim_reward& r = terminal ? C.c.terminal_reward : C.c.per_step_reward;
     if constexpr (EXTRAS)
         if (r.kind == LOBSIM_R_ROLLING_SHARPE)
@@ -1490,7 +1540,7 @@ DI double step_reward(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, int en
 // ---------------------------------------------------------------------------------------------------------------
 // env state <-> LDS
 // ---------------------------------------------------------------------------------------------------------------
-DI void load_env(Lds& L, Scal& S, const DevPtrs& P, int env, const EnvHdr& H) {
+SDI void load_env(Lds& L, Scal& S, const DevPtrs& P, int env, const EnvHdr& H) {
     int ln = lane();
     const Ladder& G = P.ladder[env];
     S.n_lv.v = (uint32_t)H.n_lv[0] | ((uint32_t)H.n_lv[1] << 16);
@@ -1533,7 +1583,7 @@ DI void load_env(Lds& L, Scal& S, const DevPtrs& P, int env, const EnvHdr& H) {
     wsync();
 }
 
-DI void store_env(const Lds& L, const Scal& S, const DevPtrs& P, int env, EnvHdr& H) {
+SDI void store_env(const Lds& L, const Scal& S, const DevPtrs& P, int env, EnvHdr& H) {
     int ln = lane();
     wsync();
     Ladder& G = P.ladder[env];
@@ -1557,14 +1607,14 @@ DI void store_env(const Lds& L, const Scal& S, const DevPtrs& P, int env, EnvHdr
     if (ln < NA / 64) H.agent_free[ln] = L.agent_free[ln] | L.agent_pending[ln];
 }
 
-DI void clear_step_fills(Lds& L) {
+SDI void clear_step_fills(Lds& L) {
     wsync();
     if (lane() == 0) { L.ag_cnt = 0; L.ag_vol[0] = L.ag_vol[1] = 0; L.ext_cnt[0] = L.ext_cnt[1] = 0; L.ext_vol[0] = L.ext_vol[1] = 0; }
     if (lane() < NA / 64) { L.agent_free[lane()] |= L.agent_pending[lane()]; L.agent_pending[lane()] = 0; }
     wsync();
 }
 
-DI StepView make_view(const Lds& L, const Scal& S, double price, int64_t now_us) {
+SDI StepView make_view(const Lds& L, const Scal& S, double price, int64_t now_us) {
     StepView v;
     v.price = price; v.now_us = now_us; v.inventory = cur_inv(L);
     v.now_mod_min = (uint32_t)(now_us % 60000000ll);
@@ -1577,7 +1627,7 @@ DI StepView make_view(const Lds& L, const Scal& S, double price, int64_t now_us)
 }
 
 // the agent's orders of this step, before any historical message (OrderbookSimulator.py:76-81)
-DI void run_agent_ops(Lds& L, Scal& S, const DevCfg& C) {
+SDI void run_agent_ops(Lds& L, Scal& S, const DevCfg& C) {
     uint64_t todo = S.n_ops >= 64 ? ~0ull : (1ull << S.n_ops) - 1;
     bool has_market = false;
     if (S.n_ops > 0) has_market = (uni(L.ops[S.n_ops - 1].code) & 0xf) == LOBSIM_MARKET;  // the clearing order is last
@@ -1591,7 +1641,7 @@ DI void run_agent_ops(Lds& L, Scal& S, const DevCfg& C) {
 
 // OrderbookSimulator.forward_step (:70-88) + update_internal_state (HistoricalOrderbookEnvironment.py:199-204):
 // agent ops first, then the message window, clock, resync check, new price.
-DI void advance_one_step(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, int stream_id, int64_t& cursor, int64_t& now_us,
+SDI void advance_one_step(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, int stream_id, int64_t& cursor, int64_t& now_us,
                          Ranges& R, int& n_resyncs, double& price, bool with_ops, const MsgBatch& first) {
     if (with_ops) run_agent_ops(L, S, C);
     int64_t until = now_us + C.c.step_us;
@@ -1608,7 +1658,7 @@ DI void advance_one_step(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, int
 
 // get_initial_orderbook_from_orders / _get_initial_orders_from_snapshot (Exchange.py:172-178,
 // OrderbookSimulator.py:156-175): buy levels 0..L-1 then sell levels; equal prices overwrite
-DI void load_snapshot_book(Lds& L, Scal& S, const int64_t* row, int Lv, bool skip_zero_price) {
+SDI void load_snapshot_book(Lds& L, Scal& S, const int64_t* row, int Lv, bool skip_zero_price) {
     int ln = lane();
     for (int side = 0; side < 2 && !S.status; side++)
         for (int base = 0; base < Lv && !S.status; base += 64) {
@@ -1627,28 +1677,10 @@ DI void load_snapshot_book(Lds& L, Scal& S, const int64_t* row, int Lv, bool ski
 // ---------------------------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------------------------
-struct StepArgs {
-    const double* actions;  // [n_envs][A]
-    const uint8_t* active;  // [n_envs] or null
-    double* obs;            // [n_envs][obs_dim] or null
-    float* obs_f32;         // or null
-    double* reward;
-    uint8_t* done;
-    double* return_acc;     // or null: per-env sum of rewards (episode return), accumulated here
-};
 
-struct ResetArgs {
-    const int32_t* env_ids;  // [n]
-    const int32_t* stream_ids;
-    const int64_t* start_us;
-    double* obs;  // [n][obs_dim] or null
-};
 
-#ifndef LOBSIM_STEP_WAVES
-#define LOBSIM_STEP_WAVES 4  // waves per SIMD the step kernel is register-budgeted for (4 = 16 envs per CU)
-#endif
 template <bool EXTRAS>
-__global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg C, DevPtrs P, StepArgs A) {
+SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
     __shared__ Lds L;
     const int env = blockIdx.x, ln = lane();
     if (A.active && !A.active[env]) return;
@@ -1753,21 +1785,9 @@ __global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg 
 #endif
 }
 
-struct RolloutArgs {
-    int32_t policy, T;
-    const double* actions;  // LOBSIM_POLICY_GIVEN: [T][n_envs][A]
-    double params[8];
-    const uint8_t* active;
-    double* obs;
-    float* obs_f32;
-    double* reward;
-    uint8_t* done;
-    double* return_acc;
-    int32_t* steps_taken;
-};
 
 // Teradactyl.get_action (rl4mm/agents/baseline_agents.py:58-87), same f64 operation order
-DI Act5 teradactyl_action(const double* p, double inventory) {
+SDI Act5 teradactyl_action(const double* p, double inventory) {
     const double max_inv = p[0], def_kappa = p[1], w = p[2], max_kappa = p[3], e = p[4], denom = p[7], eps = 0.00001;
     double x = inventory / denom;
     double u = x < 1 - eps ? x : 1 - eps;  // clamp_to_unit: max(min(x, 1 - eps), -1 + eps)
@@ -1793,11 +1813,8 @@ DI Act5 teradactyl_action(const double* p, double inventory) {
 // generate_trajectory (rl4mm/gym/utils.py:100-117) for open-loop / rule-based agents: up to T env.step()s per env in
 // one launch.  Every wave runs its env's steps back to back, so a launch no longer lasts as long as the busiest env of
 // EACH step, and the ladder / agent orders / feature scalars stay in LDS / registers between steps.
-#ifndef LOBSIM_ROLLOUT_WAVES
-#define LOBSIM_ROLLOUT_WAVES 4
-#endif
 template <bool EXTRAS>
-__global__ __launch_bounds__(64, LOBSIM_ROLLOUT_WAVES) void lob_rollout_kernel(DevCfg C, DevPtrs P, RolloutArgs A) {
+SDI void rollout_body(const DevCfg& C, const DevPtrs& P, const RolloutArgs& A) {
     __shared__ Lds L;
     const int env = blockIdx.x, ln = lane();
     if (A.active && !A.active[env]) return;
@@ -1882,7 +1899,7 @@ __global__ __launch_bounds__(64, LOBSIM_ROLLOUT_WAVES) void lob_rollout_kernel(D
 // env.reset(): snapshot book at (episode_start - warmup), features reset, warm-up replay without agent orders
 // (HistoricalOrderbookEnvironment.py:147-161)
 template <bool EXTRAS>
-__global__ __launch_bounds__(64, 4) void lob_reset_kernel(DevCfg C, DevPtrs P, ResetArgs A) {
+SDI void reset_body(const DevCfg& C, const DevPtrs& P, const ResetArgs& A) {
     __shared__ Lds L;
     const int k = blockIdx.x, ln = lane();
     const int env = A.env_ids[k];
@@ -1950,7 +1967,7 @@ __global__ __launch_bounds__(64, 4) void lob_reset_kernel(DevCfg C, DevPtrs P, R
 }
 
 // engine-level entry points (unit parity of Exchange.process_order)
-__global__ __launch_bounds__(64) void lob_set_book_kernel(DevCfg C, DevPtrs P, int env, const int64_t* row, int64_t now_us) {
+SDI void set_book_body(const DevCfg& C, const DevPtrs& P, int env, const int64_t* row, int64_t now_us) {
     __shared__ Lds L;
     EnvHdr& H = P.hdr[env];
     Scal S;
@@ -1971,7 +1988,7 @@ __global__ __launch_bounds__(64) void lob_set_book_kernel(DevCfg C, DevPtrs P, i
 
 // orders [n][6] = {type, side, price, volume (-1 none), id, is_external}; agent cancels address their target by
 // FIFO rank among the agent's orders at that price
-__global__ __launch_bounds__(64) void lob_process_orders_kernel(DevCfg C, DevPtrs P, int env, const int64_t* orders, int n, int64_t* fills_out) {
+SDI void process_orders_body(const DevCfg& C, const DevPtrs& P, int env, const int64_t* orders, int n, int64_t* fills_out) {
     __shared__ Lds L;
     EnvHdr& H = P.hdr[env];
     const int ln = lane();
@@ -2023,6 +2040,26 @@ __global__ __launch_bounds__(64) void lob_process_orders_kernel(DevCfg C, DevPtr
     store_env(L, S, P, env, H);
 }
 
+};  // struct Eng
+
+// kernels: one wave per env; LVT selects the LDS ladder capacity (lobsim_host.inc picks it per handle)
+#ifndef LOBSIM_STEP_WAVES
+#define LOBSIM_STEP_WAVES 4  // waves per SIMD the step kernel is register-budgeted for (4 = 16 envs per CU)
+#endif
+#ifndef LOBSIM_ROLLOUT_WAVES
+#define LOBSIM_ROLLOUT_WAVES 4
+#endif
+template <bool EXTRAS, int LVT>
+__global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg C, DevPtrs P, StepArgs A) { Eng<LVT>::template step_body<EXTRAS>(C, P, A); }
+template <bool EXTRAS, int LVT>
+__global__ __launch_bounds__(64, LOBSIM_ROLLOUT_WAVES) void lob_rollout_kernel(DevCfg C, DevPtrs P, RolloutArgs A) { Eng<LVT>::template rollout_body<EXTRAS>(C, P, A); }
+template <bool EXTRAS, int LVT>
+__global__ __launch_bounds__(64, 4) void lob_reset_kernel(DevCfg C, DevPtrs P, ResetArgs A) { Eng<LVT>::template reset_body<EXTRAS>(C, P, A); }
+template <int LVT>
+__global__ __launch_bounds__(64) void lob_set_book_kernel(DevCfg C, DevPtrs P, int env, const int64_t* row, int64_t now_us) { Eng<LVT>::set_book_body(C, P, env, row, now_us); }
+template <int LVT>
+__global__ __launch_bounds__(64) void lob_process_orders_kernel(DevCfg C, DevPtrs P, int env, const int64_t* orders, int n, int64_t* fills_out) { Eng<LVT>::process_orders_body(C, P, env, orders, n, fills_out); }
+
 // (inventory, cash, price) of every env, coalesced
 __global__ void lob_gather_portfolios_kernel(DevPtrs P, int n, int64_t* inv, int64_t* cash, double* price) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2062,15 +2099,3 @@ __global__ void lob_set_portfolio_kernel(DevPtrs P, const int32_t* ids, int n, c
 }  // namespace lobk
 
 #include "lobsim_host.inc"
-
-#ifdef LOBSIM_ISA_PROBE
-// compile-only probes: static instruction count of one call of each engine primitive (tools: hipcc -S -DLOBSIM_ISA_PROBE)
-namespace lobk {
-#define PROBE_PROLOGUE __shared__ Lds L; EnvHdr& H = P.hdr[blockIdx.x]; Scal S; load_env(L, S, P, blockIdx.x, H);
-__global__ __launch_bounds__(64, 4) void probe_base(DevCfg C, DevPtrs P, int side, int64_t price, int vol, int64_t id) { PROBE_PROLOGUE; store_env(L, S, P, blockIdx.x, H); }
-__global__ __launch_bounds__(64, 4) void probe_limit(DevCfg C, DevPtrs P, int side, int64_t price, int vol, int64_t id) { PROBE_PROLOGUE; submit_limit(L, S, side, price, vol, false, id); store_env(L, S, P, blockIdx.x, H); }
-__global__ __launch_bounds__(64, 4) void probe_remove(DevCfg C, DevPtrs P, int side, int64_t price, int vol, int64_t id) { PROBE_PROLOGUE; remove_order(L, S, side, price, K_EXT, id, vol); store_env(L, S, P, blockIdx.x, H); }
-__global__ __launch_bounds__(64, 4) void probe_market(DevCfg C, DevPtrs P, int side, int64_t price, int vol, int64_t id) { PROBE_PROLOGUE; execute(L, S, side, false, true, 0, vol); store_env(L, S, P, blockIdx.x, H); }
-__global__ __launch_bounds__(64, 4) void probe_find(DevCfg C, DevPtrs P, int side, int64_t price, int vol, int64_t id) { PROBE_PROLOGUE; S.status = find_level(L, S, side, price); store_env(L, S, P, blockIdx.x, H); }
-}
-#endif
