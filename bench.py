@@ -82,6 +82,11 @@ def build_stream(sim_seconds):
     return build_streams("random", sim_seconds)[0]
 
 
+def build_stream(sim_seconds):
+    """The configs[1] stream alone (tools/)."""
+    return build_streams("random", sim_seconds)[0]
+
+
 def workload_cfg(capi, workload, n_envs, device_id=0):
     kw = dict(step_us=STEP_US, episode_us=EPISODE_US, device_id=device_id)
     if workload == "ad":  # get_reward_function("AD"), rl4mm/gym/utils.py:29-39

@@ -48,6 +48,15 @@ namespace lobk {
 #define LOBSIM_PRIO_B 24
 #define LOBSIM_PRIO_C 36
 #endif
+#ifndef LOBSIM_MERGED_SCAN
+#define LOBSIM_MERGED_SCAN 1  // remove_order notes the queue's head while it searches (no second pass for an unknown id)
+#endif
+#ifndef LOBSIM_TRUST_APOS
+#define LOBSIM_TRUST_APOS 1   // the agent's cancellations take the slot recorded in apos without reading it back first
+#endif
+#ifndef LOBSIM_FEAT_PF
+#define LOBSIM_FEAT_PF 1      // step kernel: feature scalars and the ring words they name are asked for at the top of the step
+#endif
 #ifndef LOBSIM_TOMB
 #define LOBSIM_TOMB 128  // tombstones a level may hold before its slab is squeezed.  Measured 8 .. 384: with queue scans
                          // on every cancellation the optimum was 16-32; now that the position cache answers most of them, 128
@@ -106,6 +115,9 @@ struct Lds {
     double pdf[2][QMAX];
     uint16_t apos[NA];             // slot index of each live agent order inside its level's slab
     unsigned long long freed[NA / 64];  // agent entries freed by the lane-parallel cancel pass (OR-ed by lanes)
+    // step kernel: the two ring words each feature lane will read, asked for right after the env state and parked here until
+    // the feature phase (one HBM round trip less at the end of the step)
+    int64_t rstash[LOBSIM_MAX_FEATURES][2];
     // Wave-uniform state that is touched rarely (a level opens or empties, the agent trades, an execution is counted).
     // It lives here and not in scalar registers: the replay loop would otherwise carry ~35 SGPRs through every one of
     // its merge points (copies and spills on the scalar unit, which is what bounds this kernel at 16 waves per CU).
@@ -426,6 +438,11 @@ SDI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, in
     const Slot* sl = S.slots + (size_t)m_slab(m) * SLOTS;
     int pos = -1;
     int32_t pv = 0;
+#if LOBSIM_MERGED_SCAN
+    // the same pass notes the head - the first slot that is not a tombstone - for the unknown-id rule below
+    int first_live = -1;
+    int32_t hk = K_DEAD, hv = 0;
+#endif
     for (int c = head >> 6; c * 64 < tail; c += 2) {  // 1 KiB chunks, two loads in flight; a ballot per chunk finds the order
         EVENT(ev_chunks);
         const Slot s0 = load_slot(sl, c * 64 + ln, head, tail);
@@ -433,12 +450,20 @@ SDI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, in
         const uint64_t b0 = ballot(s0.kind == kind && s0.id == id), b1 = ballot(s1.kind == kind && s1.id == id);
         if (b0) { int l = fls64(b0); pos = c * 64 + l; pv = rl32(s0.vol, l); }
         if (b1) { int l = fls64(b1); pos = c * 64 + 64 + l; pv = rl32(s1.vol, l); }
+#if LOBSIM_MERGED_SCAN
+        if (first_live < 0) {
+            const uint64_t l0 = ballot(s0.kind != K_DEAD), l1 = ballot(s1.kind != K_DEAD);
+            if (l0) { int l = ffs64(l0); first_live = c * 64 + l; hk = rl32(s0.kind, l); hv = rl32(s0.vol, l); }
+            else if (l1) { int l = ffs64(l1); first_live = c * 64 + 64 + l; hk = rl32(s1.kind, l); hv = rl32(s1.vol, l); }
+        }
+#endif
     }
     int32_t pk = kind;
     int64_t pid = id;
     if (pos < 0) {
         // unknown id: if the head - the first slot that is not a tombstone - is a snapshot order (internal_id == -1)
-        // it absorbs the removal (:133-137).  Rare path: look the head up with a second pass.
+        // it absorbs the removal (:133-137)
+#if !LOBSIM_MERGED_SCAN
         int first_live = -1;
         int32_t hk = K_DEAD, hv = 0;
         for (int c = head >> 6; c * 64 < tail && first_live < 0; c++) {
@@ -447,6 +472,7 @@ SDI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, in
             uint64_t lv = ballot(s.kind != K_DEAD);
             if (lv) { int l = ffs64(lv); first_live = c * 64 + l; hk = rl32(s.kind, l); hv = rl32(s.vol, l); }
         }
+#endif
         if (hk != K_SNAP) return;
         if (vol < 0) { S.status |= LOBSIM_ST_ASSERT; return; }
         pos = first_live; pv = hv; pk = K_SNAP; pid = -1;
@@ -875,9 +901,16 @@ SDI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
     bool can_ok = is_cancel && li >= 0;
     const int pos = can_ok ? L.apos[idx] : 0;
     can_ok = can_ok && pos >= m_head(m) && pos < m_tail(m);
+    // The slot's contents are known without reading it: an agent order's slot is {index, volume, K_AGENT}, its volume is
+    // mirrored in L.agent and its position in L.apos by every routine that touches it (append, fill, reduction, squeeze).
     Slot cs = dead_slot();
+#if LOBSIM_TRUST_APOS
+    if (can_ok) { cs.id = idx; cs.vol = L.agent[idx].vol; cs.kind = K_AGENT; }
+    can_ok = can_ok && cs.vol > 0;
+#else
     if (can_ok) cs = sl[pos];
     can_ok = can_ok && cs.kind == K_AGENT && cs.id == idx;
+#endif
     bool gone = false;
     if (can_ok) {
         const int32_t cv = op.vol > cs.vol ? cs.vol : op.vol, nv = cs.vol - cv;
@@ -1243,17 +1276,22 @@ struct StepView {  // what Feature._update reads from State
 SDI double clampd(double x, double lo, double hi) { double m = x < hi ? x : hi; return m > lo ? m : lo; }
 
 // Feature._update; returns false where the reference would raise
-SDI bool feature_raw(const lobsim_feature& d, FeatState& f, int64_t* ring, const StepView& v) {
+// The two ring words the steady-state branches of feature_raw read (word 0, always allocated, where a branch reads none).
+SDI void ring_idx(int kind, int lb, int count, int pos, int& i0, int& i1) {
+    i0 = 0; i1 = 0;
+    if (kind == LOBSIM_F_PRICE_MOVE) { const int cap = lb + 1; i0 = count + 1 < cap ? 0 : (pos + 1 == cap ? 0 : pos + 1); }
+    else if (kind == LOBSIM_F_VOLATILITY && count > lb) { const int cap = lb + 1; i0 = pos; i1 = pos + 1 == cap ? 0 : pos + 1; }
+    else if ((kind == LOBSIM_F_TRADE_DIRECTION_IMBALANCE || kind == LOBSIM_F_TRADE_VOLUME_IMBALANCE) && count >= lb && lb > 0) { i0 = pos; i1 = lb + pos; }
+}
+// `have_pre`: pre0 / pre1 are ring[i0], ring[i1] as prefetched by the caller for exactly this feature state.
+SDI bool feature_raw(const lobsim_feature& d, FeatState& f, int64_t* ring, const StepView& v, bool have_pre = false, int64_t pre0 = 0, int64_t pre1 = 0) {
     const int lb = d.lookback;
     double* pr = reinterpret_cast<double*>(ring);
     // The ring words the steady-state branches below read, requested for all feature lanes at once: the switch runs
     // one feature kind after the other (each lane group waiting for its own loads), this way the HBM latency is paid
-    // once.  i0 / i1 default to word 0 (always allocated); the branches that do not use them ignore the values.
-    int i0 = 0, i1 = 0;
-    if (d.kind == LOBSIM_F_PRICE_MOVE) { const int cap = lb + 1; i0 = f.count + 1 < cap ? 0 : (f.pos + 1 == cap ? 0 : f.pos + 1); }
-    else if (d.kind == LOBSIM_F_VOLATILITY && f.count > lb) { const int cap = lb + 1; i0 = f.pos; i1 = f.pos + 1 == cap ? 0 : f.pos + 1; }
-    else if ((d.kind == LOBSIM_F_TRADE_DIRECTION_IMBALANCE || d.kind == LOBSIM_F_TRADE_VOLUME_IMBALANCE) && f.count >= lb && lb > 0) { i0 = f.pos; i1 = lb + f.pos; }
-    const int64_t w0 = ring[i0], w1 = ring[i1];
+    // once (or not at all: the step kernel asks for them at the top of the step).
+    int64_t w0 = pre0, w1 = pre1;
+    if (!have_pre) { int i0, i1; ring_idx(d.kind, lb, f.count, f.pos, i0, i1); w0 = ring[i0]; w1 = ring[i1]; }
     switch (d.kind) {
     case LOBSIM_F_SPREAD: f.current_value = v.spread; return true;
     case LOBSIM_F_BOOK_IMBALANCE:
@@ -1456,10 +1494,10 @@ SDI bool feature_reset(const lobsim_feature& d, FeatState& f, int64_t* ring, con
 }
 
 template <bool EXTRAS>
-SDI bool feature_update(const lobsim_feature& d, FeatState& f, int64_t* ring, const StepView& v, double* hist) {  // update, :80-86
+SDI bool feature_update(const lobsim_feature& d, FeatState& f, int64_t* ring, const StepView& v, double* hist, bool have_pre = false, int64_t pre0 = 0, int64_t pre1 = 0) {  // update, :80-86
     if (v.now_us < f.first_usage_us) return true;
     if (d.update_us <= 0xffffffffll ? (v.now_mod_min % (uint32_t)d.update_us != 0) : ((int64_t)v.now_mod_min % d.update_us != 0)) return true;  // _now_is_multiple_of_update_freq
-    if (!feature_raw(d, f, ring, v)) return false;
+    if (!feature_raw(d, f, ring, v, have_pre, pre0, pre1)) return false;
     f.current_value = clampd(f.current_value, d.min_value, d.max_value);
     if constexpr (EXTRAS)
         if (hist) f.current_value = feature_normalise(hist, (int)d.norm_len, f.current_value);  // :86
@@ -1706,7 +1744,25 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
     int stream_id = H.stream_id;
     MsgBatch first = {INT64_MAX, 0, 0, 0};
     if (stream_id >= 0) first = fetch_messages(P.streams[stream_id], cursor);  // in flight while the agent's orders are built
+#if LOBSIM_FEAT_PF
+    // (only what the ring addresses need travels early; asked for together with the env state)
+    int fkind = 0, flb = 0, fcount = 0, fpos = 0, froff = 0;
+    if (ln < F) {
+        fkind = C.c.features[ln].kind; flb = C.c.features[ln].lookback; froff = C.ring_off[ln];
+        const FeatState& g = P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln];
+        fcount = g.count; fpos = g.pos;
+    }
+#endif
     load_env(L, S, P, env, H);
+#if LOBSIM_FEAT_PF
+    int64_t rw0 = 0, rw1 = 0;
+    if (ln < F) {  // (landed with the env state: vector-memory loads return in order)
+        int i0, i1;
+        ring_idx(fkind, flb, fcount, fpos, i0, i1);
+        const int64_t* ring = P.rings + (size_t)env * C.ring_words + froff;
+        rw0 = ring[i0]; rw1 = ring[i1];  // in flight while the agent's orders are built
+    }
+#endif
     STAMP(1);
     {   // longest-job-first from the start of the step (replay_messages sets the same level again)
         const int c0 = popc64(ballot(first.t <= now + C.c.step_us));
@@ -1723,6 +1779,9 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
         const int64_t inv0 = cur_inv(L), cash0 = cur_cash(L);
         const double p0 = price;
         build_agent_ops(L, S, C, act);  // convert_action_to_orders on the pre-step state
+#if LOBSIM_FEAT_PF
+        if (ln < F) { L.rstash[ln][0] = rw0; L.rstash[ln][1] = rw1; }
+#endif
         STAMP(2);
 #ifdef LOBSIM_PROFILE
         if (!S.status) run_agent_ops(L, S, C);
@@ -1739,7 +1798,11 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
             StepView v = make_view(L, S, price, now);
             SUBSTAMP(9);
             bool ok = true;
+#if LOBSIM_FEAT_PF
+            if (ln < F) ok = feature_update<EXTRAS>(C.c.features[ln], fs, P.rings + (size_t)env * C.ring_words + C.ring_off[ln], v, norm_history(C, P, env, ln), true, L.rstash[ln][0], L.rstash[ln][1]);
+#else
             if (ln < F) ok = feature_update<EXTRAS>(C.c.features[ln], fs, P.rings + (size_t)env * C.ring_words + C.ring_off[ln], v, norm_history(C, P, env, ln));
+#endif
             if (ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
         }
         if (!S.status) {
