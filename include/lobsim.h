@@ -86,7 +86,8 @@ typedef struct lobsim_feature {
     int64_t update_us; /* update_frequency in microseconds */
     double min_value, max_value;
     double dparam;  /* EpisodeProportion: update_frequency / episode_length (Features.py:505) */
-    int64_t iparam; /* TimeOfDay: bucket size in us (Features.py:528); AmihudLambda: slowing_factor */
+    int64_t iparam; /* TimeOfDay: bucket size in us (Features.py:528); AmihudLambda: slowing_factor;
+                       TradeDirectionImbalance / TradeVolumeImbalance: track_internal (0 / 1, Features.py:379-381,438-440) */
     /* normalisation_on (Features.py:60-74): > 0 = capacity of the value history (deque(maxlen=max_norm_len)); every
      * update then returns scipy.stats.zscore(history)[-1], an O(len) pass in numpy's summation order.  0 = off (the
      * reference's default).  Memory: 8 * norm_len bytes per env and feature - pass the number of updates an episode

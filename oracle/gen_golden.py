@@ -300,6 +300,8 @@ def feature_desc(f):
         d["iparam"] = int(f.bucket_size / timedelta(microseconds=1))
     if isinstance(f, AmihudLambda):
         d["iparam"] = int(f.slowing_factor)
+    if isinstance(f, (TradeDirectionImbalance, TradeVolumeImbalance)):
+        d["iparam"] = int(bool(f.track_internal))
     return d
 
 
@@ -492,6 +494,43 @@ def gen_resync_msft(db):
     print("resync_msft min_buy", sim.min_buy_price, "max_sell", sim.max_sell_price)
 
 
+def gen_feature_known_answers(db):
+    """G6: rl4mm/features/tests/testFeatures.py:152-196 (test_order_direction_and_volume_imbalance) re-run here with the
+    reference's classes, recording per 0.1 s step the fills and both feature values (19 steps after the episode start);
+    the values the reference's test asserts are kept next to them."""
+    from rl4mm.features.Features import State
+    ticker, L = "MSFT", 50
+    gen = HistoricalOrderGenerator(ticker, db, preload_orders=False)
+    sim = OrderbookSimulator(ticker, Exchange(ticker), [gen], L, db, preload_orders=False, outer_levels=48)
+    start_of_trading_day = datetime(2012, 6, 21, 9, 30)
+    start = db.get_next_snapshot(start_of_trading_day, ticker).name
+    start += timedelta(microseconds=10**6 - start.microsecond)
+    sim.reset_episode(start)
+    tdi = TradeDirectionImbalance(lookback_periods=10, update_frequency=timedelta(seconds=0.1))
+    tvi = TradeVolumeImbalance(lookback_periods=10, update_frequency=timedelta(seconds=0.1), track_internal=True)
+    from rl4mm.orderbook.models import FilledOrders
+    mock = State(filled_orders=FilledOrders(internal=list(), external=list()), orderbook=sim.exchange.central_orderbook, price=100, portfolio=Portfolio(inventory=0, cash=0), now_is=start)
+    tdi.reset(mock); tvi.reset(mock)
+    now, vals = start, []
+    import contextlib, io
+    for _ in range(19):
+        now += timedelta(seconds=0.1)
+        with warnings.catch_warnings(), contextlib.redirect_stdout(io.StringIO()):
+            warnings.simplefilter("ignore")
+            filled = sim.forward_step(now)
+        st = deepcopy(mock)
+        st.filled_orders = filled
+        st.now_is = now
+        tdi.update(st); tvi.update(st)
+        vals.append((tdi.current_value, tvi.current_value))
+    day0 = datetime(2012, 6, 21)
+    np.savez_compressed(
+        GOLD / "feature_known_answers.npz", start_us=np.array(int((start - day0) / timedelta(microseconds=1))), values=np.array(vals),
+        expected_dir=np.array([1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 6 / 36, 13 / 43]), expected_vol=np.array([1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, -988 / 14642, -188 / 15442]),
+    )  # fmt: skip
+    print("feature_known_answers", start, vals[9:])
+
+
 def main():
     GOLD.mkdir(parents=True, exist_ok=True)
     # G0: the reference's own data file, kept as a test fixture (gzip for the wide orderbook file)
@@ -509,6 +548,8 @@ def main():
     if not ONLY:
         gen_replay_msft(db_all)
         gen_resync_msft(db_all)
+    if not ONLY or "feature_known_answers" in ONLY:
+        gen_feature_known_answers(db_all)
 
     test_feats = lambda: [Inventory(), Spread(), PriceMove(lookback_periods=1), PriceRange(lookback_periods=1)]  # noqa: E731
     run_trajectory("msft_fixed", db_all, "MSFT", date, 50, test_feats(), fixed_agent([1, 2, 1, 2]), 2, [36001, 36001], 1.0, stream_file="msft")
@@ -571,6 +612,15 @@ def main():
         run_trajectory("synth_norm", db_s, "SYN", sdate, 10, normed(), random_agent(33, high=20.0), 2, [35925, 35945], 15.0, step_reward="PnL", terminal_reward="PnL",
                        enter_spread=True, initial=(5, 10**9), stream_file="synth_small")  # fmt: skip
         run_trajectory("synth_q5_fixed", db_s, "SYN", sdate, 10, short(), fixed_agent([2, 5, 5, 2]), 1, [36010], 20.0, minq=2, maxq=7, stream_file="synth_small")
+        # track_internal=True (Features.py:379-381, 438-440; the reference's own feature test builds TradeVolumeImbalance that way,
+        # testFeatures.py:160): quotes inside the spread so that the agent is filled a lot, both imbalance features with and without
+        tracked = lambda: [Spread(), Inventory(),  # noqa: E731
+                           TradeDirectionImbalance(name="tdi_int", update_frequency=timedelta(seconds=0.1), lookback_periods=10, track_internal=True),
+                           TradeVolumeImbalance(name="tvi_int", update_frequency=timedelta(seconds=0.1), lookback_periods=10, track_internal=True),
+                           TradeDirectionImbalance(name="tdi", update_frequency=timedelta(seconds=0.1), lookback_periods=10),
+                           TradeVolumeImbalance(name="tvi", update_frequency=timedelta(seconds=0.2), lookback_periods=10, track_internal=True)]
+        run_trajectory("synth_track_internal", db_s, "SYN", sdate, 10, tracked(), random_agent(44), 2, [35940, 35965], 20.0, step_reward="PnL", terminal_reward="PnL",
+                       enter_spread=True, initial=(0, 10**9), stream_file="synth_small")  # fmt: skip
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

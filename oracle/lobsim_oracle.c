@@ -670,6 +670,11 @@ static int feature_raw_update(const oracle_t* h, Env* e, Feature* f) {
             int64_t w = f->d.kind == LOBSIM_F_TRADE_DIRECTION_IMBALANCE ? 1 : e->fex.f[i].vol;
             if (e->fex.f[i].side == LOBSIM_BUY) nb += w; else ns += w;
         }
+        if (f->d.iparam) /* track_internal (:379-381, :438-440): the agent's own fills count as well */
+            for (int i = 0; i < e->fin.n; i++) {
+                int64_t w = f->d.kind == LOBSIM_F_TRADE_DIRECTION_IMBALANCE ? 1 : e->fin.f[i].vol;
+                if (e->fin.f[i].side == LOBSIM_BUY) nb += w; else ns += w;
+            }
         int lb = f->d.lookback;
         if (f->n_trades < lb) {
             trades_append(f, nb, ns);
@@ -1356,6 +1361,24 @@ int oracle_debug_forward(oracle_t* h, int32_t env, int32_t stream_id, int64_t un
     Env* e = &h->env[env];
     e->stream_id = stream_id;
     forward_step(h, e, until_us, NULL, 0);
+    return e->status;
+}
+
+/* Feature-level known answers (rl4mm/features/tests/testFeatures.py): feature.reset(state) on the current simulator
+ * state, then one forward step without agent orders + feature.update(state) per call; obs [n_features] gets the values. */
+int oracle_debug_features_reset(oracle_t* h, int32_t env) {
+    Env* e = &h->env[env];
+    if (!book_microprice(&e->ex.central, &e->price)) e->price = 0.0;
+    e->fin.n = e->fex.n = 0;
+    for (int f = 0; f < h->cfg.n_features; f++) feature_reset(h, e, &e->feat[f], e->now_us);
+    return e->status;
+}
+int oracle_debug_feature_step(oracle_t* h, int32_t env, double* obs) {
+    Env* e = &h->env[env];
+    env_forward(h, e, NULL, 0);
+    if (e->status) return e->status;
+    for (int f = 0; f < h->cfg.n_features; f++) feature_update(h, e, &e->feat[f]);
+    for (int f = 0; f < h->cfg.n_features; f++) obs[f] = e->feat[f].current_value;
     return e->status;
 }
 

@@ -126,7 +126,8 @@ struct Lds {
     unsigned long long agent_free[NA / 64];
     unsigned long long agent_pending[NA / 64];  // entries freed during this step: not reused before the step ends
     long long inv, cash;
-    int32_t ag_cnt, ag_vol[2], ext_cnt[2], ext_vol[2];  // fills of the current step
+    int32_t ag_cnt[2], ag_vol[2], ext_cnt[2], ext_vol[2];  // fills of the current step; agent fills by the agent's side, external
+                                                          // fills by the resting order's side
     uint32_t agent_seq;
 };
 
@@ -559,12 +560,12 @@ SDI int32_t execute(Lds& L, Scal& S, int side, bool is_agent, bool is_market, in
         // fills: resting side = opp (Q10: external fills are counted by the resting order's direction)
         if (ln == 0) { L.ext_cnt[opp] += n_ext; L.ext_vol[opp] += exec_ext; }
         if (n_agent) {  // an external aggressor hit resting agent orders (executed_internal_orders, :107-109)
-            if (ln == 0) { L.ag_cnt += n_agent; L.ag_vol[opp] += exec_agent; }
+            if (ln == 0) { L.ag_cnt[opp] += n_agent; L.ag_vol[opp] += exec_agent; }
             if (opp == LOBSIM_SELL) trade(L, -(int64_t)exec_agent, (int64_t)exec_agent * bp);
             else trade(L, exec_agent, -(int64_t)exec_agent * bp);
         }
         if (is_agent) {  // the agent's own aggressing fills, one MarketOrder copy per resting fill (:110-115)
-            if (ln == 0) { L.ag_cnt += n_ext; L.ag_vol[side] += exec_ext; }
+            if (ln == 0) { L.ag_cnt[side] += n_ext; L.ag_vol[side] += exec_ext; }
             if (side == LOBSIM_SELL) trade(L, -(int64_t)exec_ext, (int64_t)exec_ext * bp);
             else trade(L, exec_ext, -(int64_t)exec_ext * bp);
         }
@@ -1269,6 +1270,7 @@ struct StepView {  // what Feature._update reads from State
     int64_t inventory, now_us;
     uint32_t now_mod_min;  // (second, microsecond) part of now: now_us mod 60 s
     int64_t ext_cnt[2], ext_vol[2];
+    int64_t int_cnt[2], int_vol[2];  // the agent's own fills by its side (track_internal)
     int64_t bv, av;
     bool book_ok;
 };
@@ -1398,6 +1400,7 @@ SDI bool feature_raw(const lobsim_feature& d, FeatState& f, int64_t* ring, const
     case LOBSIM_F_TRADE_VOLUME_IMBALANCE: {  // Features.py:376-403 / 435-462 as running sums over a ring
         bool dirn = d.kind == LOBSIM_F_TRADE_DIRECTION_IMBALANCE;
         int64_t nb = dirn ? v.ext_cnt[0] : v.ext_vol[0], ns = dirn ? v.ext_cnt[1] : v.ext_vol[1];
+        if (d.iparam) { nb += dirn ? v.int_cnt[0] : v.int_vol[0]; ns += dirn ? v.int_cnt[1] : v.int_vol[1]; }  // track_internal (:379-381, :438-440)
         if (f.count < lb) {
             ring[f.pos] = nb; ring[lb + f.pos] = ns;
             f.total += nb + ns; f.diff += nb - ns;
@@ -1614,7 +1617,7 @@ SDI void load_env(Lds& L, Scal& S, const DevPtrs& P, int env, const EnvHdr& H) {
     if (ln < NA / 64) { L.agent_free[ln] = H.agent_free[ln]; L.agent_pending[ln] = 0; }
     if (ln == 0) {
         L.inv = H.inventory; L.cash = H.cash; L.agent_seq = H.agent_seq;
-        L.ag_cnt = 0; L.ag_vol[0] = L.ag_vol[1] = 0; L.ext_cnt[0] = L.ext_cnt[1] = 0; L.ext_vol[0] = L.ext_vol[1] = 0;
+        L.ag_cnt[0] = L.ag_cnt[1] = 0; L.ag_vol[0] = L.ag_vol[1] = 0; L.ext_cnt[0] = L.ext_cnt[1] = 0; L.ext_vol[0] = L.ext_vol[1] = 0;
     }
     S.slots = P.slots + (size_t)env * NSLAB * SLOTS;
     S.idc = P.idc + (size_t)env * IDC_N;
@@ -1638,7 +1641,7 @@ SDI void store_env(const Lds& L, const Scal& S, const DevPtrs& P, int env, EnvHd
     if (ln == 0) {
         H.n_lv[0] = S.n_lv[0]; H.n_lv[1] = S.n_lv[1];
         H.status = S.status; H.inventory = L.inv; H.cash = L.cash; H.agent_seq = L.agent_seq;
-        H.agent_fill_count = L.ag_cnt; H.agent_vol[0] = L.ag_vol[0]; H.agent_vol[1] = L.ag_vol[1];
+        H.agent_fill_count = L.ag_cnt[0] + L.ag_cnt[1]; H.agent_vol[0] = L.ag_vol[0]; H.agent_vol[1] = L.ag_vol[1];
         H.ext_count[0] = L.ext_cnt[0]; H.ext_count[1] = L.ext_cnt[1]; H.ext_vol[0] = L.ext_vol[0]; H.ext_vol[1] = L.ext_vol[1];
     }
     if (ln < NSLAB / 64) H.slab_free[ln] = L.slab_free[ln];
@@ -1647,7 +1650,7 @@ SDI void store_env(const Lds& L, const Scal& S, const DevPtrs& P, int env, EnvHd
 
 SDI void clear_step_fills(Lds& L) {
     wsync();
-    if (lane() == 0) { L.ag_cnt = 0; L.ag_vol[0] = L.ag_vol[1] = 0; L.ext_cnt[0] = L.ext_cnt[1] = 0; L.ext_vol[0] = L.ext_vol[1] = 0; }
+    if (lane() == 0) { L.ag_cnt[0] = L.ag_cnt[1] = 0; L.ag_vol[0] = L.ag_vol[1] = 0; L.ext_cnt[0] = L.ext_cnt[1] = 0; L.ext_vol[0] = L.ext_vol[1] = 0; }
     if (lane() < NA / 64) { L.agent_free[lane()] |= L.agent_pending[lane()]; L.agent_pending[lane()] = 0; }
     wsync();
 }
@@ -1658,6 +1661,7 @@ SDI StepView make_view(const Lds& L, const Scal& S, double price, int64_t now_us
     v.now_mod_min = (uint32_t)(now_us % 60000000ll);
     v.spread = best_sell_d(L, S) - best_buy_d(L, S);
     v.ext_cnt[0] = uni(L.ext_cnt[0]); v.ext_cnt[1] = uni(L.ext_cnt[1]); v.ext_vol[0] = uni(L.ext_vol[0]); v.ext_vol[1] = uni(L.ext_vol[1]);
+    v.int_cnt[0] = uni(L.ag_cnt[0]); v.int_cnt[1] = uni(L.ag_cnt[1]); v.int_vol[0] = uni(L.ag_vol[0]); v.int_vol[1] = uni(L.ag_vol[1]);
     v.book_ok = S.n_lv[0] && S.n_lv[1];
     v.bv = v.book_ok ? uni(L.vol[0][0]) : 0; v.av = v.book_ok ? uni(L.vol[1][0]) : 0;
     if (v.bv + v.av == 0) v.book_ok = false;
@@ -2096,7 +2100,7 @@ SDI void process_orders_body(const DevCfg& C, const DevPtrs& P, int env, const i
         // make entries freed by this order reusable, like the reference (no step boundary at this level)
     }
     if (ln == 0 && fills_out) {
-        fills_out[0] = L.ag_cnt; fills_out[1] = L.ag_vol[0]; fills_out[2] = L.ag_vol[1];
+        fills_out[0] = L.ag_cnt[0] + L.ag_cnt[1]; fills_out[1] = L.ag_vol[0]; fills_out[2] = L.ag_vol[1];
         fills_out[3] = L.ext_cnt[0]; fills_out[4] = L.ext_cnt[1]; fills_out[5] = L.ext_vol[0]; fills_out[6] = L.ext_vol[1];
         fills_out[7] = L.cash - cash0;
     }

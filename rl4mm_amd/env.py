@@ -154,9 +154,13 @@ class TradeDirectionImbalance(Feature):  # :351
     kind = _capi.F_TRADE_DIRECTION_IMBALANCE
 
     def __init__(self, name="TradeImbalance", update_frequency=timedelta(seconds=0.1), lookback_periods=600, track_internal=False, normalisation_on=False, max_norm_len=100_000):
-        if track_internal:
-            raise NotImplementedError("track_internal=True is not on the device path")
         super().__init__(name, -1.0, 1.0, update_frequency, lookback_periods, normalisation_on, max_norm_len)
+        self.track_internal = track_internal  # Features.py:379-381, 438-440: the agent's own fills count as well
+
+    def desc(self):
+        d = super().desc()
+        d.iparam = int(bool(self.track_internal))
+        return d
 
 
 class TradeVolumeImbalance(TradeDirectionImbalance):  # :410
@@ -464,8 +468,10 @@ class HistoricalOrderbookVectorEnv:
         return ts - timedelta(microseconds=ts.microseconds)
 
     def _get_random_trading_day(self) -> datetime:
+        from .trading_calendar import get_next_trading_dt
+
         trading_dates = pd.bdate_range(self.min_date, self.max_date)
-        d = pd.to_datetime(np.random.choice(trading_dates))  # get_next_trading_dt: weekdays only, NASDAQ holidays are not modelled
+        d = get_next_trading_dt(pd.to_datetime(np.random.choice(trading_dates)).to_pydatetime())  # rl4mm/utils/utils.py:54-57 (NASDAQ sessions)
         return datetime.combine(d.date(), datetime.min.time())
 
     def _get_random_start_time(self) -> datetime:

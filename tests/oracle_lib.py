@@ -34,6 +34,10 @@ def oracle_binding() -> _capi.Binding:
         b.lib.oracle_debug_forward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64]
         b.lib.oracle_debug_reset_episode.restype = C.c_int
         b.lib.oracle_debug_reset_episode.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64]
+        b.lib.oracle_debug_features_reset.restype = C.c_int
+        b.lib.oracle_debug_features_reset.argtypes = [C.c_void_p, C.c_int32]
+        b.lib.oracle_debug_feature_step.restype = C.c_int
+        b.lib.oracle_debug_feature_step.argtypes = [C.c_void_p, C.c_int32, PD]
         PI32, PU8 = C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
         b.lib.oracle_rollout.restype = C.c_int
         b.lib.oracle_rollout.argtypes = [C.c_void_p, C.c_int32, PD, C.c_int32, PD, PU8, PD, PD, PU8, PD, PI32, PD]

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 RTOL, ATOL = 1e-12, 1e-9
 TRAJ = ["msft_fixed", "msft_teradactyl_ad", "msft_random_allfeat", "synth_default_random", "synth_teradactyl_ad_spread", "synth_amihud", "synth_info_moc", "synth_info_spread",
-        "synth_moc_conc", "synth_moc_crash", "synth_q5_fixed", "synth_norm"]  # fmt: skip
+        "synth_moc_conc", "synth_moc_crash", "synth_q5_fixed", "synth_norm", "synth_track_internal"]  # fmt: skip
 
 
 def _small_cfg(n_envs=1, n_levels=8, **kw):
@@ -57,11 +57,12 @@ def test_trajectory_matches_reference(name):
 @pytest.mark.parametrize("name", ["synth_sharpe", "synth_sharpe_small", "synth_sharpe_crash"])
 def test_rolling_sharpe_trajectory(name):
     """RollingSharpe (RewardFunctions.py:38-94) recorded from the reference.  State, fills and book are bit-exact; the
-    reward is compared at rtol 1e-6: the reference's exp/log are numpy's SIMD routines, the kernel's are ocml's."""
+    reward is compared at rtol 1e-7: the reference's exp/log are numpy's SIMD routines, the kernel's are ocml's (the oracle,
+    libm, reaches the same trajectories to 4.4e-8)."""
     g, z = ol.load_traj(name)
     sim = _lib.new_sim(ol.cfg_from_golden(g))
     sid = sim.add_stream(ol.golden_stream(g["stream_file"]))
-    replay_and_check(sim, g, z, sid, obs_rtol=RTOL, obs_atol=ATOL, label=name, reward_rtol=1e-6)
+    replay_and_check(sim, g, z, sid, obs_rtol=RTOL, obs_atol=ATOL, label=name, reward_rtol=1e-7)
     if name == "synth_sharpe_crash":
         assert sim.env_state(0)["status"] & _capi.ST_ASSERT
     sim.close()
@@ -69,7 +70,7 @@ def test_rolling_sharpe_trajectory(name):
 
 def test_rolling_sharpe_batch_matches_oracle():
     """256 envs x 150 steps with RollingSharpe rewards (window 32/8 per step, 120/60-default terminal), random actions,
-    rollout kernel and step kernel against the oracle: rewards within 1e-6 relative, state bit-exact."""
+    rollout kernel and step kernel against the oracle: rewards within 1e-7 relative, state bit-exact."""
     g, _ = ol.load_traj("synth_sharpe")
     g = dict(g, per_step_reward=["RS", 32, 8], terminal_reward="RS")
     n, T = 256, 150
@@ -97,7 +98,7 @@ def test_rolling_sharpe_batch_matches_oracle():
     (r0, i0, c0, p0), (r1, i1, c1, p1) = outs
     assert np.array_equal(i0, i1) and np.array_equal(c0, c1) and np.array_equal(p0, p1)
     assert (r1 != 0).mean() > 0.5
-    assert np.allclose(r0, r1, rtol=1e-6, atol=1e-12), np.abs(r0 - r1).max()
+    assert np.allclose(r0, r1, rtol=1e-7, atol=1e-12), np.abs(r0 - r1).max()
 
 
 def test_normalised_features_batch_matches_oracle():

@@ -142,3 +142,36 @@ def test_bench_gpus_flag_launches_ranks_gloo_stub():
     assert len(lines) == 1, p.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["gathered_returns"] == 74 and out["gather_in_env_order"] and len(out["ms_per_step_per_rank"]) == 2
+
+
+def test_nasdaq_trading_calendar():
+    """rl4mm/utils/utils.py:48-62 without pandas_market_calendars: the exchange's holiday rules restated.  Checked against
+    known closures, against pandas' federal-holiday rules where the two coincide, and through the env's day draw."""
+    from datetime import date
+
+    import pandas as pd
+    from pandas.tseries.holiday import USFederalHolidayCalendar
+
+    from rl4mm_amd import trading_calendar as tc
+
+    closed = [date(2012, 1, 2), date(2012, 1, 16), date(2012, 2, 20), date(2012, 4, 6), date(2012, 5, 28), date(2012, 7, 4), date(2012, 9, 3), date(2012, 10, 29),
+              date(2012, 10, 30), date(2012, 11, 22), date(2012, 12, 25), date(2018, 1, 1), date(2018, 1, 15), date(2018, 2, 19), date(2018, 3, 30), date(2018, 5, 28),
+              date(2018, 7, 4), date(2018, 9, 3), date(2018, 11, 22), date(2018, 12, 5), date(2018, 12, 25), date(2022, 6, 20), date(2021, 12, 24), date(2023, 1, 2),
+              date(2015, 7, 3), date(2019, 4, 19), date(2024, 3, 29)]  # fmt: skip
+    for d in closed:
+        assert not tc.is_trading_day(d), d
+    for d in (date(2012, 6, 21), date(2018, 2, 21), date(2021, 12, 31), date(2010, 12, 31), date(2021, 6, 18), date(2018, 11, 23), date(2012, 10, 31), date(2011, 11, 11)):
+        assert tc.is_trading_day(d), d  # (New Year's Day on a Saturday is not observed; Veterans / Columbus Day are sessions)
+    # rules shared with the federal calendar: same dates apart from Columbus Day, Veterans Day and the Saturday rule of 1 January
+    fed = USFederalHolidayCalendar().holidays(start="2005-01-01", end="2030-12-31")
+    for ts in fed:
+        d = ts.date()
+        if d.month in (10,) or (d.month == 11 and d.day in (10, 11, 12)) or (d.month == 12 and d.day == 31) or (d.month == 6 and d.year < 2022):
+            continue
+        assert not tc.is_trading_day(d), d
+    for y in range(2005, 2031):
+        n = sum(tc.is_trading_day(ts.date()) for ts in pd.bdate_range(f"{y}-01-01", f"{y}-12-31"))
+        assert 249 <= n <= 253, (y, n)
+    assert tc.get_next_trading_dt(datetime(2018, 3, 30)) == datetime(2018, 4, 2, 9, 30)
+    assert tc.get_last_trading_dt(datetime(2018, 4, 1)) == datetime(2018, 3, 29, 16)
+    assert [d.day for d in tc.get_trading_datetimes(datetime(2018, 12, 24), datetime(2018, 12, 27))] == [24, 26, 27]

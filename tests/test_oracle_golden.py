@@ -10,7 +10,7 @@ from rl4mm_amd import _capi
 from traj_util import replay_and_check, run_engine_case
 
 TRAJ = ["msft_fixed", "msft_teradactyl_ad", "msft_random_allfeat", "synth_default_random", "synth_teradactyl_ad_spread", "synth_amihud", "synth_info_moc", "synth_info_spread",
-        "synth_moc_conc", "synth_moc_crash", "synth_q5_fixed", "synth_norm"]  # fmt: skip
+        "synth_moc_conc", "synth_moc_crash", "synth_q5_fixed", "synth_norm", "synth_track_internal"]  # fmt: skip
 
 
 def _small_cfg(n_levels=8, **kw):
@@ -103,7 +103,8 @@ def test_trajectory_bit_exact(name):
     replay_and_check(sim, g, z, sid, check_fills=check_fills, label=name)
 
 
-SHARPE_RTOL = 1e-6  # RollingSharpe: np.exp/np.log (AVX-512 kernels in numpy) vs libm differ in the last ulp of ~1e-9-sized returns
+SHARPE_RTOL = 1e-7  # RollingSharpe: np.exp/np.log (AVX-512 kernels in numpy) vs libm differ in the last ulp of ~1e-9-sized returns
+                    # (the oracle reaches the reference's three recorded trajectories to 4.4e-8)
 
 
 @pytest.mark.parametrize("name", ["synth_sharpe", "synth_sharpe_small", "synth_sharpe_crash"])
@@ -150,6 +151,28 @@ def test_known_answers_from_reference_tests():
     assert len(orders) == 20 and np.all(orders[:, 3] == 10) and np.all(orders[:, 0] == 1)
     orders = ol.oracle_peek_orders(sim, [1, 2, 1, 2])
     assert list(orders[:, 3]) == [19, 17, 15, 13, 11, 9, 7, 5, 3, 1] * 2
+
+
+def test_feature_known_answers_of_reference_test():
+    """G6, rl4mm/features/tests/testFeatures.py:152-196 (test_order_direction_and_volume_imbalance): the reference's simulator
+    replays the MSFT slice from the first whole second in 0.1 s steps without an agent; TradeDirectionImbalance(10) and
+    TradeVolumeImbalance(10, track_internal=True) are 0 for nine updates, then 1.0 x 7, 6/36, 13/43 and 1.0 x 7, -988/14642,
+    -188/15442 (the numbers the reference's test asserts).  The fixture holds what the reference's classes produced here for
+    all 19 steps; the oracle must give exactly those."""
+    z = np.load(ol.GOLD / "feature_known_answers.npz")
+    feats = [_capi.make_feature(_capi.F_TRADE_DIRECTION_IMBALANCE, 10, 100_000, -1, 1), _capi.make_feature(_capi.F_TRADE_VOLUME_IMBALANCE, 10, 100_000, -1, 1, iparam=1)]
+    sim = ol.oracle_sim(_capi.make_cfg(1, 50, feats, step_us=100_000, outer_levels=48))
+    sid = sim.add_stream(ol.golden_stream("msft"))
+    lib = sim.b.lib
+    assert lib.oracle_debug_reset_episode(sim.h, 0, sid, int(z["start_us"])) == 0
+    assert lib.oracle_debug_features_reset(sim.h, 0) == 0
+    vals = np.zeros((19, 2))
+    for k in range(19):
+        assert lib.oracle_debug_feature_step(sim.h, 0, vals[k].ctypes.data_as(C.POINTER(C.c_double))) == 0
+    assert np.array_equal(vals, z["values"])
+    assert np.all(vals[:9] == 0)
+    for k in range(9):  # assertAlmostEqual (7 places) against the constants in the reference's test
+        assert round(vals[9 + k, 0] - z["expected_dir"][k], 7) == 0 and round(vals[9 + k, 1] - z["expected_vol"][k], 7) == 0
 
 
 @pytest.mark.parametrize("name", list(ol.TERADACTYL_GOLDEN))
