@@ -367,21 +367,24 @@ def test_msft_50_level_replay_against_oracle():
 
 
 def test_full_size_properties():
-    """BASELINE config 2 size (4096 envs, synthetic 10-level stream): size-independent properties.
+    """BASELINE configs[1] size (4096 envs, synthetic 10-level stream, default full_state features): size-independent properties.
     (a) envs given identical (start, actions) produce identical results wherever they sit in the batch;
     (b) a second handle fed the same inputs reproduces every output bit for bit;
     (c) inventory is the running sum of the per-step agent fills; (d) a strided sample of envs equals the oracle."""
+    import bench
+
     n, steps = 4096, 30
-    stream = synthetic_stream(77, 10, 200.0, 9.5 * 3600 + 1500, 9.5 * 3600 + 1500 + 200)
-    cfg = _capi.make_cfg(n, 10, _short_features(), step_us=100_000, episode_us=60_000_000)
+    stream = synthetic_stream(77, 10, 200.0, 9.5 * 3600 + 1490, 9.5 * 3600 + 1800 + 70)  # 09:54:50 .. 10:01:10: the 5 min warm-up of the default features
+    feats = bench.default_features(_capi)
+    cfg = _capi.make_cfg(n, 10, feats, step_us=100_000, episode_us=60_000_000)
     rng = np.random.Generator(np.random.PCG64(9))
-    base_starts = (35_720 + rng.integers(0, 60, size=n // 2)) * 1_000_000
+    base_starts = (36_000 + rng.integers(0, 60, size=n // 2)) * 1_000_000
     starts = np.concatenate([base_starts, base_starts])  # env i and env i + n/2 are twins
     acts = rng.uniform(0, 10, size=(steps, n // 2, 4))
     acts = np.concatenate([acts, acts], axis=1)
     sims = [_lib.new_sim(cfg), _lib.new_sim(cfg)]
     sample = np.arange(0, n, 128)
-    cpu = ol.oracle_sim(_capi.make_cfg(len(sample), 10, _short_features(), step_us=100_000, episode_us=60_000_000))
+    cpu = ol.oracle_sim(_capi.make_cfg(len(sample), 10, feats, step_us=100_000, episode_us=60_000_000))
     cpu.add_stream(stream)
     cpu.set_portfolio(0, 10**9)
     cpu.reset(starts[sample], 0)
