@@ -121,6 +121,26 @@ def pmc_traffic(workload, n_envs):
 # ---------------------------------------------------------------------------------------------------------------------
 # CPU baseline leg (child process: no torch, its own OpenMP runtime with the threads pinned)
 # ---------------------------------------------------------------------------------------------------------------------
+def effective_cpus():
+    """CPUs this process can actually keep busy: the affinity mask, capped by the cgroup's CPU quota (a container that sees
+    256 CPUs but is granted 16 CPUs' worth of time runs 256 threads at a sixteenth of their speed)."""
+    n = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q, per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    eff = n if quota is None else max(1, min(n, int(quota + 0.5)))
+    return eff, n, quota
+
+
 def cpu_baseline_child(workload, budget_s):
     """The CPU oracle (a port: the reference itself is Python and cannot travel) on the host cores: same stream
     generator, same features, same action distribution.  The oracle is driven through oracle_rollout - T steps per
@@ -132,7 +152,7 @@ def cpu_baseline_child(workload, budget_s):
 
     from rl4mm_amd import _capi
 
-    cores = len(os.sched_getaffinity(0))
+    cores, visible, quota = effective_cpus()
     T, chunks_max, per_thread = 500, 24, 64
     streams = build_streams(workload, T * chunks_max * STEP_US // 1_000_000 + 1)
     lib = ol.oracle_binding().lib
@@ -170,14 +190,16 @@ def cpu_baseline_child(workload, budget_s):
     one_v, one_steps, one_dt, _ = run(1, per_thread, budget_s / 3)
     return {
         "value": all_v, "unit": "env-steps/s", "cores": cores, "threads": cores, "per_core": one_v, "kind": "port",
+        "visible_cpus": visible, "cgroup_cpu_quota": quota,
         "sample": f"all cores: {per_thread * cores} envs, {all_steps} env-steps in {all_dt:.1f} s (+{all_reset:.1f} s reset incl. 3000 warm-up steps per env); "
                   f"1 thread: {per_thread} envs, {one_steps} env-steps in {one_dt:.1f} s; oracle/lobsim_oracle.c through oracle_rollout "
-                  f"({T} steps per env per OpenMP region, static schedule, OMP_PROC_BIND=close), workload '{workload}'",
+                  f"({T} steps per env per OpenMP region, static schedule, OMP_PROC_BIND=close), workload '{workload}'; cores = CPUs usable: "
+                  f"{visible} visible, cgroup quota {quota}",
     }  # fmt: skip
 
 
 def cpu_baseline(workload, budget_s=10.0):
-    env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores", OMP_NUM_THREADS=str(len(os.sched_getaffinity(0))))
+    env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores", OMP_NUM_THREADS=str(effective_cpus()[0]))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--cpu-baseline-only", "--workload", workload, "--cpu-budget", str(budget_s)],
@@ -382,7 +404,7 @@ def main():
         sample = range(0, N, max(1, N // 64))
         st_bad = sum(sim.env_state(int(e))["status"] != 0 for e in sample)
         traffic, traffic_src = pmc_traffic(wl, N)
-        kernel = "lob_rollout_kernel (T=1)" if wl == "teradactyl" else "lob_step_kernel"
+        kernel = "lob_step_kernel"  # (Teradactyl: lobsim_rollout_device with T = 1 runs the step kernel, the policy in its prologue)
         out = {
             "metric": "env-steps/sec (batched LOB sims)", "value": world * N * K / elapsed, "unit": "env-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,

@@ -74,6 +74,11 @@ struct StepArgs {
     double* reward;
     uint8_t* done;
     double* return_acc;     // or null: per-env sum of rewards (episode return), accumulated here
+    // lobsim_rollout_device with T == 1 runs here too: the action of an on-device policy is worked out in the prologue
+    int32_t policy;         // LOBSIM_POLICY_GIVEN: `actions` holds it
+    int32_t pad;
+    double params[8];       // policy parameters (lobsim.h)
+    int32_t* steps_taken;   // or null: 1 per env that stepped, 0 for an env that was already done
 };
 
 struct ResetArgs {
@@ -1740,10 +1745,16 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
 #ifdef LOBSIM_PROFILE_MSG
     for (int k = 0; k < 8; k++) { S.pm_cycles[k] = 0; S.pm_count[k] = 0; }
 #endif
-    const double* ap = A.actions + (size_t)env * AD;
     Act5 act;
-    act.v0 = ap[0]; act.v1 = ap[1];
-    act.v2 = AD > 2 ? ap[2] : 0.0; act.v3 = AD > 3 ? ap[3] : 0.0; act.v4 = AD > 4 ? ap[4] : 0.0;
+    if (A.policy == LOBSIM_POLICY_GIVEN) {
+        const double* ap = A.actions + (size_t)env * AD;
+        act.v0 = ap[0]; act.v1 = ap[1];
+        act.v2 = AD > 2 ? ap[2] : 0.0; act.v3 = AD > 3 ? ap[3] : 0.0; act.v4 = AD > 4 ? ap[4] : 0.0;
+    } else if (A.policy == LOBSIM_POLICY_FIXED) {
+        act.v0 = A.params[0]; act.v1 = A.params[1]; act.v2 = A.params[2]; act.v3 = A.params[3]; act.v4 = A.params[4];
+    } else {  // Teradactyl on the observation's inventory entry = that feature's current value
+        act = teradactyl_action(A.params, P.feat[(size_t)env * LOBSIM_MAX_FEATURES + (int)A.params[5]].current_value);
+    }
     int64_t now = H.now_us, cursor = H.msg_cursor;
     int stream_id = H.stream_id;
     MsgBatch first = {INT64_MAX, 0, 0, 0};
@@ -1779,6 +1790,7 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
     double price = H.price, reward = 0.0;
     int done = 0;
     FeatState fs = FeatState();
+    const int entry_status = S.status;
     if (!S.status) {
         const int64_t inv0 = cur_inv(L), cash0 = cur_cash(L);
         const double p0 = price;
@@ -1827,7 +1839,11 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
         if (A.obs) A.obs[(size_t)env * D + ln] = val;
         if (A.obs_f32) A.obs_f32[(size_t)env * D + ln] = (float)val;
     }
-    if (ln == 0) { A.reward[env] = reward; A.done[env] = (uint8_t)done; if (A.return_acc) A.return_acc[env] += reward; }
+    if (ln == 0) {
+        A.reward[env] = reward; A.done[env] = (uint8_t)done;
+        if (A.return_acc) A.return_acc[env] += reward;
+        if (A.steps_taken) A.steps_taken[env] = entry_status ? 0 : 1;
+    }
     if (ln < F) P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln] = fs;
     store_env(L, S, P, env, H);
     if (ln == 0) {
