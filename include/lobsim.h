@@ -216,6 +216,44 @@ int lobsim_rollout_device(lobsim_t* h, int32_t policy, const double* params8, in
                           const uint8_t* d_active, double* d_obs, float* d_obs_f32, double* d_reward, uint8_t* d_done,
                           double* d_return_acc, int32_t* d_steps_taken);
 
+/* --- info arrays (rl4mm/gym/order_tracking/InfoCalculators.py:17-89, SimpleInfoCalculator) ------------------------- */
+/* One row of doubles per env: what SimpleInfoCalculator.calculate(state_after_step, action) returns, computed in the step
+ * kernel's epilogue.  (Its `agent_weighted_spread` entry is the literal [1] in the reference; the value it computes and
+ * then drops is kept here.)  market_order_count / market_order_total_volume accumulate for the lifetime of the env, like the
+ * reference's calculator object. */
+enum lobsim_info_col {
+    LOBSIM_INFO_ASSET_PRICE = 0,
+    LOBSIM_INFO_INVENTORY = 1,
+    LOBSIM_INFO_CASH = 2,
+    LOBSIM_INFO_AUM = 3,
+    LOBSIM_INFO_MARKET_SPREAD = 4,
+    LOBSIM_INFO_AGENT_SPREAD = 5,
+    LOBSIM_INFO_AGENT_WEIGHTED_SPREAD = 6,
+    LOBSIM_INFO_MIDPRICE_OFFSET = 7,
+    LOBSIM_INFO_WEIGHTED_MIDPRICE_OFFSET = 8,
+    LOBSIM_INFO_MARKET_ORDER_COUNT = 9,
+    LOBSIM_INFO_MARKET_ORDER_TOTAL_VOLUME = 10,
+    LOBSIM_INFO_DIM = 11
+};
+/* d_info: DEVICE buffer [n_envs][LOBSIM_INFO_DIM] f64 that every later lobsim_step / lobsim_step_device /
+ * lobsim_rollout_device fills for the envs that stepped (NULL: off, the default - the reference's default is
+ * info_calculator=None).  Rows of envs that did not step keep their previous contents. */
+int lobsim_set_info_buffer(lobsim_t* h, double* d_info);
+/* Per-step series of a multi-step launch, the columns get_episode_summary_dict reads (rl4mm/gym/utils.py:145-198):
+ * d_trace: DEVICE buffer [t_capacity][n_envs][LOBSIM_TRACE_DIM] f64; lobsim_rollout_device (T <= t_capacity) writes row t of
+ * every env that took step t.  NULL: off. */
+enum lobsim_trace_col {
+    LOBSIM_TRACE_REWARD = 0,
+    LOBSIM_TRACE_AUM = 1,
+    LOBSIM_TRACE_INVENTORY = 2,
+    LOBSIM_TRACE_ASSET_PRICE = 3,
+    LOBSIM_TRACE_MARKET_SPREAD = 4,
+    LOBSIM_TRACE_WEIGHTED_MIDPRICE_OFFSET = 5,
+    LOBSIM_TRACE_ACTION = 6, /* .. +LOBSIM_MAX_ACTION_DIM: the action taken (what an on-device policy chose) */
+    LOBSIM_TRACE_DIM = 11
+};
+int lobsim_set_trace_buffer(lobsim_t* h, double* d_trace, int32_t t_capacity);
+
 int lobsim_obs_dim(const lobsim_t* h);
 
 /* --- inspection (parity tests, info dicts) ---------------------------------------------------------------- */

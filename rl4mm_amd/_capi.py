@@ -23,6 +23,10 @@ F_SPREAD, F_PRICE_MOVE, F_VOLATILITY, F_INVENTORY, F_EPISODE_PROPORTION, F_TIME_
 F_TRADE_DIRECTION_IMBALANCE, F_TRADE_VOLUME_IMBALANCE, F_BOOK_IMBALANCE, F_PRICE_RANGE, F_PRICE, F_AMIHUD_LAMBDA = 7, 8, 9, 10, 11, 12
 R_PNL, R_INVENTORY_ADJUSTED, R_ROLLING_SHARPE = 1, 2, 3
 POLICY_GIVEN, POLICY_FIXED, POLICY_TERADACTYL = 0, 1, 2
+INFO_COLS = ["asset_price", "inventory", "cash", "aum", "market_spread", "agent_spread", "agent_weighted_spread_value", "midprice_offset",
+             "weighted_midprice_offset", "market_order_count", "market_order_total_volume"]  # enum lobsim_info_col
+TRACE_COLS = ["reward", "aum", "inventory", "asset_price", "market_spread", "weighted_midprice_offset", "a0", "a1", "a2", "a3", "a4"]  # enum lobsim_trace_col
+INFO_DIM, TRACE_DIM = len(INFO_COLS), len(TRACE_COLS)
 
 
 class FeatureDesc(C.Structure):
@@ -127,6 +131,8 @@ PROTOTYPES = {
     "step_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sync": (C.c_int, [C.c_void_p]),
     "rollout_device": (C.c_int, [C.c_void_p, C.c_int32, _PD, C.c_int32] + [C.c_void_p] * 8),
+    "set_info_buffer": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "set_trace_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "obs_dim": (C.c_int, [C.c_void_p]),
     "get_env_state": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(EnvState)]),
     "get_portfolios": (C.c_int, [C.c_void_p, _P64, _P64, _PD]),
@@ -137,7 +143,7 @@ PROTOTYPES = {
     "debug_process_orders": (C.c_int, [C.c_void_p, C.c_int32, _P64, C.c_int32, _P64]),
 }
 # the oracle has no device entry points
-ORACLE_SKIP = {"set_stream", "step_device", "sync", "rollout_device"}
+ORACLE_SKIP = {"set_stream", "step_device", "sync", "rollout_device", "set_info_buffer", "set_trace_buffer"}
 
 
 def _ptr(a: Optional[np.ndarray], typ):
@@ -296,6 +302,12 @@ class Sim:
 
     def sync(self):
         self._check(self.b.fn["sync"](self.h), "sync")
+
+    def set_info_buffer(self, d_info: int):
+        self._check(self.b.fn["set_info_buffer"](self.h, d_info), "set_info_buffer")
+
+    def set_trace_buffer(self, d_trace: int, t_capacity: int):
+        self._check(self.b.fn["set_trace_buffer"](self.h, d_trace, int(t_capacity)), "set_trace_buffer")
 
     def set_stream(self, hip_stream: int):
         self._check(self.b.fn["set_stream"](self.h, hip_stream), "set_stream")

@@ -79,6 +79,7 @@ struct StepArgs {
     int32_t pad;
     double params[8];       // policy parameters (lobsim.h)
     int32_t* steps_taken;   // or null: 1 per env that stepped, 0 for an env that was already done
+    double* info;           // or null: [n_envs][LOBSIM_INFO_DIM] info arrays (lobsim_set_info_buffer)
 };
 
 struct ResetArgs {
@@ -99,6 +100,8 @@ struct RolloutArgs {
     uint8_t* done;
     double* return_acc;
     int32_t* steps_taken;
+    double* info;           // or null: [n_envs][LOBSIM_INFO_DIM], the info of the last step each env took
+    double* trace;          // or null: [T][n_envs][LOBSIM_TRACE_DIM] per-step series (lobsim_set_trace_buffer)
 };
 
 // Everything below is a member of Eng<LVT>: LVT = price levels per side the LDS-resident ladder holds (64 or 128; the HBM
@@ -123,6 +126,7 @@ struct Lds {
     // step kernel: the two ring words each feature lane will read, asked for right after the env state and parked here until
     // the feature phase (one HBM round trip less at the end of the step)
     int64_t rstash[LOBSIM_MAX_FEATURES][2];
+    int32_t info_q[4];  // SimpleInfoCalculator: first quoted level and volume-weighted level sum per side of this step's action
     // Wave-uniform state that is touched rarely (a level opens or empties, the agent trades, an execution is counted).
     // It lives here and not in scalar registers: the replay loop would otherwise carry ~35 SGPRs through every one of
     // its merge points (copies and spills on the scalar unit, which is what bounds this kernel at 16 waves per CU).
@@ -672,7 +676,7 @@ SDI void push_op(Lds& L, Scal& S, int type, int side, int idx, int32_t vol) {
 
 // Builds L.ops from the action and the PRE-step book; nothing is mutated (the reference computes the whole
 // order list first and only then hands it to the simulator).
-SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action) {
+SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, bool want_info = false) {
     const lobsim_cfg& c = C.c;
     const int Q = C.Q, ln = lane();
     const int64_t tick = c.tick_size;
@@ -700,6 +704,11 @@ SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action) {
         desired = (int32_t)rint(L.pdf[my_side][my_k] / s * 100.0);  // np.round(dist * active_volume).astype(int)
     }
     SUBSTAMP(2);
+    if (want_info) {  // InfoCalculators.py:60-79 works on the action's volumes as the distributor gives them (before any clearing)
+        const uint64_t qb = ballot(quoting && my_side == 0 && desired > 0), qs = ballot(quoting && my_side == 1 && desired > 0);
+        const int32_t db = wave_sum(quoting && my_side == 0 ? desired * my_k : 0), ds = wave_sum(quoting && my_side == 1 ? desired * my_k : 0);
+        if (ln == 0) { L.info_q[0] = qb ? ffs64(qb) : 0; L.info_q[1] = qs ? ffs64(qs) - Q : 0; L.info_q[2] = db; L.info_q[3] = ds; }  // np.sign(..).argmax()
+    }
     const int64_t inv = cur_inv(L);
     int64_t abs_inv = inv < 0 ? -inv : inv;
     bool clearing = c.market_order_clearing && (double)abs_inv > act_at(action, c.action_dim - 1);
@@ -1583,6 +1592,37 @@ SDI double step_reward(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, int e
     return reward_of(r, inv0, cash0, p0, cur_inv(L), cur_cash(L), price);
 }
 
+// SimpleInfoCalculator.calculate (rl4mm/gym/order_tracking/InfoCalculators.py:31-89) on the state after the step and the
+// action just taken, as one row of doubles (lobsim.h: enum lobsim_info_col).  The persistent market-order counters live
+// in the env header.  `out` may be null (then only the counters advance).
+SDI void write_info(const Lds& L, const Scal& S, const DevCfg& C, EnvHdr& H, const Act5& act, double price, double* out) {
+    if (lane() != 0) return;
+    const lobsim_cfg& c = C.c;
+    const int64_t inv = L.inv, cash = L.cash;
+    const double bb = S.n_lv[0] ? (double)L.price[0][0] : 0.0, bs = S.n_lv[1] ? (double)L.price[1][0] : (double)INFINITY;
+    const double market_spread = bs - bb;  // Orderbook.spread (models.py:99-101)
+    const int best_buy = L.info_q[0], best_sell = L.info_q[1];
+    const double midprice_offset = (double)(best_sell - best_buy) / 2;
+    double spread = (double)(best_buy + best_sell);
+    const double buy_com = (double)L.info_q[2] / 100.0, sell_com = (double)L.info_q[3] / 100.0;  // np.dot(orders, levels) / total_volume
+    const double weighted_offset = (sell_com - buy_com) / 2;
+    double weighted_spread = buy_com + sell_com;
+    if (!c.enter_spread) { spread += market_spread; weighted_spread += market_spread; }
+    int64_t moc_count = H.info_moc_count;
+    double moc_volume = H.info_moc_volume;
+    if (c.market_order_clearing) {  // :52-56: with the post-step inventory
+        const double thr = act.at(c.action_dim - 1);
+        const int64_t a = inv < 0 ? -inv : inv;
+        if ((double)a > thr) { moc_count += 1; moc_volume += rint((double)a * c.market_order_fraction_of_inventory); H.info_moc_count = moc_count; H.info_moc_volume = moc_volume; }
+    }
+    if (!out) return;
+    out[LOBSIM_INFO_ASSET_PRICE] = price; out[LOBSIM_INFO_INVENTORY] = (double)inv; out[LOBSIM_INFO_CASH] = (double)cash;
+    out[LOBSIM_INFO_AUM] = (double)cash + price * (double)inv;
+    out[LOBSIM_INFO_MARKET_SPREAD] = market_spread; out[LOBSIM_INFO_AGENT_SPREAD] = spread; out[LOBSIM_INFO_AGENT_WEIGHTED_SPREAD] = weighted_spread;
+    out[LOBSIM_INFO_MIDPRICE_OFFSET] = midprice_offset; out[LOBSIM_INFO_WEIGHTED_MIDPRICE_OFFSET] = weighted_offset;
+    out[LOBSIM_INFO_MARKET_ORDER_COUNT] = (double)moc_count; out[LOBSIM_INFO_MARKET_ORDER_TOTAL_VOLUME] = moc_volume;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // env state <-> LDS
 // ---------------------------------------------------------------------------------------------------------------
@@ -1794,7 +1834,7 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
     if (!S.status) {
         const int64_t inv0 = cur_inv(L), cash0 = cur_cash(L);
         const double p0 = price;
-        build_agent_ops(L, S, C, act);  // convert_action_to_orders on the pre-step state
+        build_agent_ops(L, S, C, act, A.info != nullptr);  // convert_action_to_orders on the pre-step state
 #if LOBSIM_FEAT_PF
         if (ln < F) { L.rstash[ln][0] = rw0; L.rstash[ln][1] = rw1; }
 #endif
@@ -1845,6 +1885,7 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
         if (A.steps_taken) A.steps_taken[env] = entry_status ? 0 : 1;
     }
     if (ln < F) P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln] = fs;
+    if (A.info && !entry_status && !S.status) write_info(L, S, C, H, act, price, A.info + (size_t)env * LOBSIM_INFO_DIM);
     store_env(L, S, P, env, H);
     if (ln == 0) {
         H.now_us = now; H.msg_cursor = cursor; H.price = price; H.n_resyncs = n_resyncs;
@@ -1935,7 +1976,8 @@ SDI void rollout_body(const DevCfg& C, const DevPtrs& P, const RolloutArgs& A) {
         reward = 0.0;
         MsgBatch first = {INT64_MAX, 0, 0, 0};
         if (stream_id >= 0) first = fetch_messages(P.streams[stream_id], cursor);
-        build_agent_ops(L, S, C, act);
+        const bool want_info = A.info != nullptr || A.trace != nullptr;
+        build_agent_ops(L, S, C, act, want_info);
         if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true, first);
         if (!S.status) {
             StepView v = make_view(L, S, price, now);
@@ -1958,6 +2000,19 @@ SDI void rollout_body(const DevCfg& C, const DevPtrs& P, const RolloutArgs& A) {
         if (S.status) { done = 1; reward = 0.0; }
         ret += reward;
         steps++;
+        if (want_info && !S.status) {
+            write_info(L, S, C, H, act, price, A.info ? A.info + (size_t)env * LOBSIM_INFO_DIM : nullptr);
+            if (A.trace && ln == 0) {  // the series get_episode_summary_dict reads (rl4mm/gym/utils.py:145-198)
+                double* tr = A.trace + ((size_t)t * N + env) * LOBSIM_TRACE_DIM;
+                const int64_t inv = L.inv, cash = L.cash;
+                tr[LOBSIM_TRACE_REWARD] = reward; tr[LOBSIM_TRACE_AUM] = (double)cash + price * (double)inv; tr[LOBSIM_TRACE_INVENTORY] = (double)inv;
+                tr[LOBSIM_TRACE_ASSET_PRICE] = price;
+                tr[LOBSIM_TRACE_MARKET_SPREAD] = (S.n_lv[1] ? (double)L.price[1][0] : (double)INFINITY) - (S.n_lv[0] ? (double)L.price[0][0] : 0.0);
+                tr[LOBSIM_TRACE_WEIGHTED_MIDPRICE_OFFSET] = ((double)L.info_q[3] / 100.0 - (double)L.info_q[2] / 100.0) / 2;
+                tr[LOBSIM_TRACE_ACTION] = act.v0; tr[LOBSIM_TRACE_ACTION + 1] = act.v1; tr[LOBSIM_TRACE_ACTION + 2] = act.v2;
+                tr[LOBSIM_TRACE_ACTION + 3] = act.v3; tr[LOBSIM_TRACE_ACTION + 4] = act.v4;
+            }
+        }
     }
     double val = 0.0;
     if (ln < F) val = fval;

@@ -71,6 +71,8 @@ struct alignas(16) EnvHdr {
     // fills of the last step
     int64_t agent_fill_count, agent_vol[2], ext_count[2], ext_vol[2];
     int64_t cash_delta;
+    int64_t info_moc_count;    // SimpleInfoCalculator.market_order_count / market_order_total_volume (InfoCalculators.py:26-27, 85-87):
+    double info_moc_volume;    // live as long as the env object, never reset
     double prev_action[LOBSIM_MAX_ACTION_DIM];
 };
 

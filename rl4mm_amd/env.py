@@ -293,8 +293,27 @@ class SimpleInfoCalculator:
         self.quote_levels, self.active_volume = quote_levels, active_volume  # BetaOrderDistributor defaults (:29)
         self.market_order_count = None
         self.market_order_total_volume = None
+        self._device_rows = None
+
+    def attach(self, sim):
+        """Have the step kernel compute the info arrays in its epilogue (lobsim_set_info_buffer): calculate_arrays then
+        costs one device-to-host copy instead of bulk getters plus a host-side Beta evaluation."""
+        import torch
+
+        self._device_rows = torch.zeros((sim.n_envs, _capi.INFO_DIM), dtype=torch.float64, device=torch.device("cuda", sim.cfg.device_id))
+        torch.cuda.synchronize()
+        sim.set_info_buffer(self._device_rows.data_ptr())
+        return self
 
     def calculate_arrays(self, sim, actions: np.ndarray) -> Dict[str, np.ndarray]:
+        if self._device_rows is not None:
+            sim.sync()
+            rows = self._device_rows.cpu().numpy()
+            out = {name: rows[:, i].copy() for i, name in enumerate(_capi.INFO_COLS)}
+            for k in ("inventory", "cash", "market_order_count"):
+                out[k] = out[k].astype(np.int64)
+            out["market_spread"] = out["market_spread"].astype(np.int64) if np.all(np.isfinite(out["market_spread"])) else out["market_spread"]
+            return out
         actions = np.asarray(actions, dtype=np.float64)
         n = actions.shape[0]
         if self.market_order_count is None:

@@ -763,3 +763,68 @@ def test_info_calculator_on_device_state_matches_reference(name):
         got = np.array([float(arr[c][0]) for c in cols])
         assert np.array_equal(got, z["info"][k]), f"{name} step {k}"
     sim.close()
+
+
+@pytest.mark.parametrize("name", ["synth_info_moc", "synth_info_spread"])
+def test_info_arrays_computed_on_the_device_match_reference(name):
+    """lobsim_set_info_buffer: the step kernel's epilogue writes SimpleInfoCalculator's entries itself (no host-side Beta
+    evaluation, no bulk getters); every column of every step = the info dict the reference returned."""
+    from rl4mm_amd.env import SimpleInfoCalculator
+
+    g, z = ol.load_traj(name)
+    sim = _lib.new_sim(ol.cfg_from_golden(g, n_envs=3))
+    sid = sim.add_stream(ol.golden_stream(g["stream_file"]))
+    sim.set_portfolio(g["initial_inventory"], g["initial_cash"])
+    sim.reset(np.full(3, g["starts_us"][0]), sid)
+    calc = SimpleInfoCalculator(g["market_order_fraction_of_inventory"], g["enter_spread"], concentration=g["concentration"] if g["use_concentration"] else None).attach(sim)
+    cols = ["asset_price", "inventory", "cash", "aum", "market_spread", "agent_spread", "midprice_offset", "weighted_midprice_offset",
+            "market_order_count", "market_order_total_volume"]  # fmt: skip
+    for k in range(len(z["reward"])):
+        act = np.tile(z["actions"][k][None, :], (3, 1))
+        sim.step(act)
+        arr = calc.calculate_arrays(sim, act)
+        for e in range(3):
+            got = np.array([float(arr[c][e]) for c in cols])
+            assert np.array_equal(got, z["info"][k]), f"{name} step {k} env {e}: {got} vs {z['info'][k]}"
+    sim.close()
+
+
+@pytest.mark.parametrize("agent_kind", ["fixed", "teradactyl"])
+def test_batched_episode_summary_equals_host_trajectories(agent_kind):
+    """rl4mm/gym/utils.py:100-257: get_episode_summary_dict over a batch (one rollout launch, the series written by the
+    kernel) against generate_trajectory driven step by step from the host with the info calculator attached."""
+    from datetime import datetime, timedelta
+
+    from rl4mm_amd import agents, env as E, summary
+
+    cat = E.StreamCatalog().add(ol.golden_stream("synth_small"))
+    ms = timedelta(seconds=0.1)
+    feats = lambda: [E.Spread(), E.PriceMove(name="pm1", update_frequency=ms, lookback_periods=1), E.Volatility(name="v", update_frequency=ms, lookback_periods=20), E.Inventory()]  # noqa: E731
+    start = timedelta(hours=9, minutes=59, seconds=20)
+    kw = dict(catalog=cat, ticker="SYN", step_size=ms, episode_length=timedelta(seconds=12), min_date=datetime(2018, 2, 21), max_date=datetime(2018, 2, 21),
+              min_start_timedelta=start, max_end_timedelta=start + timedelta(seconds=12), n_levels=10, enter_spread=True, initial_portfolio=E.Portfolio(inventory=0, cash=10**9),
+              per_step_reward_function=E.get_reward_function("PnL"), terminal_reward_function=E.get_reward_function("PnL"))  # fmt: skip
+    agent = agents.FixedActionAgent(np.array([2.0, 3.0, 3.0, 2.0])) if agent_kind == "fixed" else agents.Teradactyl(max_inventory=200, default_kappa=8.0, max_kappa=10.0, inventory_index=3)
+    n = 5
+    cat_kw = dict(kw)
+    cat_kw.pop("catalog")
+    venv = E.HistoricalOrderbookVectorEnv(n, cat, features=feats(), **cat_kw)
+    esd = summary.get_episode_summary_dict(agent, venv)
+    venv.close()
+    calc = E.SimpleInfoCalculator(0.0, True)
+    single = E.HistoricalOrderbookEnvironment(features=feats(), info_calculator=calc, **kw)
+    d = E.generate_trajectory(agent, single)
+    single.close()
+    T = len(d["rewards"])
+    assert T == 120 and all(len(x) == T for x in esd["equity_curves"])
+    aum = np.array([float(i["aum"]) for i in d["infos"]])
+    inv = np.array([float(i["inventory"]) for i in d["infos"]])
+    price = np.array([float(i["asset_price"]) for i in d["infos"]])
+    off = np.array([float(i["weighted_midprice_offset"]) for i in d["infos"]])
+    spread = np.array([float(i["market_spread"]) for i in d["infos"]])
+    for e in range(n):  # every env of the batch starts at the same (only possible) time: identical trajectories
+        assert np.array_equal(esd["equity_curves"][e], aum) and np.array_equal(esd["inventories"][e], inv) and np.array_equal(esd["asset_prices"][e], price)
+        assert np.array_equal(esd["agent_midprice_offsets"][e], off) and np.array_equal(np.array(esd["reward_series"][e]), np.array(d["rewards"]))
+        assert esd["rewards"][e] == np.mean(d["rewards"]) and esd["spread"][e] == np.mean(spread) and esd["inventory"][e] == np.mean(inv)
+        assert np.allclose(esd["actions"][e], np.mean(np.array(d["actions"]), axis=0)[:-1], rtol=1e-15, atol=0)
+    assert agent_kind != "fixed" or np.abs(inv).max() > 0  # the fixed quotes inside the spread are filled
