@@ -108,10 +108,20 @@ def _open_text(path: Union[str, Path]):
     return open(path, "r")
 
 
+_POW10 = 10 ** np.arange(19, dtype=np.int64)
+
+
 def _id_suffix_order(t_us: np.ndarray, id_index: np.ndarray) -> np.ndarray:
-    """Permutation sorting rows by (t_us, str(id_index)) - the (timestamp, id) order of Q2."""
-    suffix = np.array([str(int(i)) for i in id_index])
-    return np.lexsort((suffix, t_us))
+    """Permutation sorting rows by (t_us, str(id_index)) - the (timestamp, id) order of Q2.
+
+    The string comparison is done on integers: decimal strings compare like their digits left-aligned to a common width
+    ("10" -> 10, "9" -> 90), and a string that is a proper prefix of another ("1", "10") sorts first, i.e. by length."""
+    ids = np.asarray(id_index, dtype=np.int64)
+    assert ids.size == 0 or (ids.min() >= 0 and ids.max() < 10**18)
+    ndig = np.maximum(np.searchsorted(_POW10, ids, side="right"), 1)  # digits of str(id); str(0) has one
+    width = int(ndig.max()) if ids.size else 1
+    left_aligned = ids * _POW10[width - ndig]
+    return np.lexsort((ndig, left_aligned, t_us))
 
 
 def _snapshot_rows(ts_ns: np.ndarray, freq: Optional[str]) -> np.ndarray:

@@ -175,3 +175,49 @@ def test_nasdaq_trading_calendar():
     assert tc.get_next_trading_dt(datetime(2018, 3, 30)) == datetime(2018, 4, 2, 9, 30)
     assert tc.get_last_trading_dt(datetime(2018, 4, 1)) == datetime(2018, 3, 29, 16)
     assert [d.day for d in tc.get_trading_datetimes(datetime(2018, 12, 24), datetime(2018, 12, 27))] == [24, 26, 27]
+
+
+def test_ingest_archives_and_multi_day_catalog(tmp_path):
+    """rl4mm_amd/ingest.py against run_populate_database_from_zipped.py:50-109 / populate_database.py:38-95: archives named like
+    LOBSTER's monthly downloads are taken in date order (not in download-counter order), their trading days (NASDAQ
+    sessions only) are packed, the extracted CSVs are deleted again, a second run re-adds nothing, the cache serves repeats."""
+    import zipfile
+
+    from rl4mm_amd import ingest
+    from rl4mm_amd.env import StreamCatalog
+    from rl4mm_amd.synth import generate_lobster, write_lobster_csv
+
+    assert ingest.parse_archive_name("_data_dwn_50_385__KO_2018-04-01_2018-04-30_200.7z") == ("KO", datetime(2018, 4, 1), datetime(2018, 4, 30), 200)
+    days = {"_data_dwn_9_385__SYN_2018-03-29_2018-04-02_10.zip": ["2018-03-29", "2018-04-02"], "_data_dwn_9_390__SYN_2018-02-20_2018-02-21_10.zip": ["2018-02-20", "2018-02-21"]}
+    packed = {}
+    for k, (arc, dates) in enumerate(days.items()):
+        with zipfile.ZipFile(tmp_path / arc, "w") as z:
+            for j, d in enumerate(dates):
+                g = generate_lobster(100 * k + j, 10, 150.0, 9.5 * 3600, 9.5 * 3600 + 20)
+                sub = tmp_path / f"raw{k}{j}"
+                mp_, bp_ = write_lobster_csv(g, sub, "SYN", d, 10)
+                z.write(mp_, mp_.name); z.write(bp_, bp_.name)
+                packed[d] = pack_lobster(mp_, bp_, "SYN", d, 10, "S")
+    cat = ingest.populate_catalog_from_archives(StreamCatalog(), tmp_path, "S", cache_dir=tmp_path / "cache")
+    keys = [k for k, _ in cat.items()]
+    assert keys == [("SYN", "2018-02-20"), ("SYN", "2018-02-21"), ("SYN", "2018-03-29"), ("SYN", "2018-04-02")]  # date order; 30 March 2018 (Good Friday) and the weekend are no sessions
+    for (_, d), ps in cat.items():
+        assert np.array_equal(ps.msgs, packed[d].msgs) and np.array_equal(ps.snaps, packed[d].snaps)
+    assert not list(tmp_path.glob("*.csv")) and len(list((tmp_path / "cache").glob("*.npz"))) == 4
+    n = len(cat)
+    ingest.populate_catalog_from_archives(cat, tmp_path, "S", cache_dir=tmp_path / "cache")
+    assert len(cat) == n
+    cat2 = ingest.populate_catalog_from_archives(StreamCatalog(), tmp_path, "S", cache_dir=tmp_path / "cache")  # served by the cache
+    assert [k for k, _ in cat2.items()] == keys
+
+
+def test_id_suffix_order_equals_string_sort():
+    """Q2 (ORDER BY timestamp, id with a string id): the integer restatement against an actual string sort."""
+    from rl4mm_amd.stream import _id_suffix_order
+
+    rng = np.random.default_rng(3)
+    for n, batch in ((5000, 1000), (30000, 1_000_000)):
+        t = np.sort(rng.integers(0, n // 4, size=n))
+        ids = np.arange(n) + (np.arange(n) // batch) * batch
+        ref = np.lexsort((np.array([str(int(i)) for i in ids]), t))
+        assert np.array_equal(_id_suffix_order(t, ids), ref)
