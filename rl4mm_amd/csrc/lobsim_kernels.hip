@@ -2182,7 +2182,10 @@ SDI void process_orders_body(const DevCfg& C, const DevPtrs& P, int env, const i
 
 // kernels: one wave per env; LVT selects the LDS ladder capacity (lobsim_host.inc picks it per handle)
 #ifndef LOBSIM_STEP_WAVES
-#define LOBSIM_STEP_WAVES 4  // waves per SIMD the step kernel is register-budgeted for (4 = 16 envs per CU)
+#define LOBSIM_STEP_WAVES 5  // waves per SIMD the step kernel is register-budgeted for.  Measured (tools/ab_libs.py, w4 / w5): the 80-VGPR
+                             // build that a budget of 5 gives is as fast per wave as the 126-VGPR one (4096 envs: 108.5 vs 106.7 M
+                             // env-steps/s) and, with 7.6 KB of LDS per env, keeps 20 envs per CU resident: 5120 envs 126.6 vs 92.8 M,
+                             // 8192 envs 129.4 vs 117.7 M, 16384 envs 152.6 vs 133.7 M
 #endif
 #ifndef LOBSIM_ROLLOUT_WAVES
 #define LOBSIM_ROLLOUT_WAVES 4

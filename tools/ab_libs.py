@@ -9,7 +9,8 @@ sys.path.insert(0, str(ROOT))
 import bench
 from rl4mm_amd import _capi
 
-N, K = 4096, 200
+import os
+N, K = int(os.environ.get("AB_ENVS", 4096)), 200
 dev = torch.device("cuda", 0)
 stream = bench.build_stream(80)
 starts = (36_000 + np.random.default_rng(1).integers(0, 60, size=N)) * 1_000_000
