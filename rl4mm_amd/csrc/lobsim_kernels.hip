@@ -2187,11 +2187,14 @@ SDI void process_orders_body(const DevCfg& C, const DevPtrs& P, int env, const i
                              // env-steps/s) and, with 7.6 KB of LDS per env, keeps 20 envs per CU resident: 5120 envs 126.6 vs 92.8 M,
                              // 8192 envs 129.4 vs 117.7 M, 16384 envs 152.6 vs 133.7 M
 #endif
+#ifndef LOBSIM_STEP_WAVES_DEEP
+#define LOBSIM_STEP_WAVES_DEEP 4  // the 128-level build: 10.2 KB of LDS per env = 15 envs per CU whatever the register budget allows
+#endif
 #ifndef LOBSIM_ROLLOUT_WAVES
 #define LOBSIM_ROLLOUT_WAVES 4
 #endif
 template <bool EXTRAS, int LVT>
-__global__ __launch_bounds__(64, LOBSIM_STEP_WAVES) void lob_step_kernel(DevCfg C, DevPtrs P, StepArgs A) { Eng<LVT>::template step_body<EXTRAS>(C, P, A); }
+__global__ __launch_bounds__(64, LVT == 64 ? LOBSIM_STEP_WAVES : LOBSIM_STEP_WAVES_DEEP) void lob_step_kernel(DevCfg C, DevPtrs P, StepArgs A) { Eng<LVT>::template step_body<EXTRAS>(C, P, A); }
 template <bool EXTRAS, int LVT>
 __global__ __launch_bounds__(64, LOBSIM_ROLLOUT_WAVES) void lob_rollout_kernel(DevCfg C, DevPtrs P, RolloutArgs A) { Eng<LVT>::template rollout_body<EXTRAS>(C, P, A); }
 template <bool EXTRAS, int LVT>
