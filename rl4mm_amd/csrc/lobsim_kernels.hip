@@ -57,6 +57,12 @@ namespace lobk {
 #ifndef LOBSIM_FEAT_PF
 #define LOBSIM_FEAT_PF 1      // step kernel: feature scalars and the ring words they name are asked for at the top of the step
 #endif
+#ifndef LOBSIM_DEDUPE_HASH
+#define LOBSIM_DEDUPE_HASH 1  // lane-parallel cancellations: duplicates are looked for exactly only when a hash test says there may be one
+#endif
+#ifndef LOBSIM_SCAN_WIDTH
+#define LOBSIM_SCAN_WIDTH 4   // slab chunks a queue scan keeps in flight (2 or 4)
+#endif
 #ifndef LOBSIM_TOMB
 #define LOBSIM_TOMB 128  // tombstones a level may hold before its slab is squeezed.  Measured 8 .. 384: with queue scans
                          // on every cancellation the optimum was 16-32; now that the position cache answers most of them, 128
@@ -177,6 +183,7 @@ struct Scal {
 #endif
 #ifdef LOBSIM_PROFILE
     uint32_t ev_chunks, ev_compact, ev_ladder, ev_exec_levels, ev_rare, ev_serial_ops;  // event counts (diagnostic build only)
+    uint32_t ev_x[9];  // serial removals, of them unknown ids, unknown in a queue span <= 4 / <= 64, serial limits, serial markets, segments, batches, -
     uint64_t sub_t[10];                                                   // sub-phase stamps (diagnostic build only)
 #endif
 };
@@ -374,10 +381,13 @@ SDI uint64_t compact_level(Lds& L, Scal& S, int side, int idx, uint64_t m) {
     Slot* sl = S.slots + (size_t)slab * SLOTS;
     uint64_t below = (1ull << ln) - 1;
     int out = 0;
+    Slot nxt = load_slot(sl, (head >> 6) * 64 + ln, head, tail);
     for (int c = head >> 6; c * 64 < tail; c++) {
-        Slot s = load_slot(sl, c * 64 + ln, head, tail);
+        const Slot s = nxt;
+        nxt = load_slot(sl, (c + 1) * 64 + ln, head, tail);  // the next chunk is on its way while this one is squeezed (a chunk's
+                                                              // survivors land at or below its own first slot: never in the next chunk)
         uint64_t b = ballot(s.kind != K_DEAD);
-        wsync();  // every lane's load has landed before any lane stores
+        wsync();  // every lane's load has been issued before any lane stores
         if (s.kind != K_DEAD) {
             int np = out + popc64(b & below);
             sl[np] = s;
@@ -453,6 +463,23 @@ SDI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, in
     int first_live = -1;
     int32_t hk = K_DEAD, hv = 0;
 #endif
+#if LOBSIM_SCAN_WIDTH == 4
+    for (int c = head >> 6; c * 64 < tail; c += 4) {  // 1 KiB chunks, four loads in flight; a ballot per chunk finds the order
+        EVENT(ev_chunks);
+        Slot sc[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) sc[k] = load_slot(sl, (c + k) * 64 + ln, head, tail);  // beyond the tail: no lane loads
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint64_t b = ballot(sc[k].kind == kind && sc[k].id == id);
+            if (b) { int l = fls64(b); pos = (c + k) * 64 + l; pv = rl32(sc[k].vol, l); }
+            if (first_live < 0) {
+                const uint64_t lv = ballot(sc[k].kind != K_DEAD);
+                if (lv) { int l = ffs64(lv); first_live = (c + k) * 64 + l; hk = rl32(sc[k].kind, l); hv = rl32(sc[k].vol, l); }
+            }
+        }
+    }
+#else
     for (int c = head >> 6; c * 64 < tail; c += 2) {  // 1 KiB chunks, two loads in flight; a ballot per chunk finds the order
         EVENT(ev_chunks);
         const Slot s0 = load_slot(sl, c * 64 + ln, head, tail);
@@ -468,8 +495,12 @@ SDI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, in
         }
 #endif
     }
+#endif
     int32_t pk = kind;
     int64_t pid = id;
+#ifdef LOBSIM_PROFILE
+    if (kind == K_EXT) { S.ev_x[0]++; if (pos < 0) { S.ev_x[1]++; if (tail - head <= 4) S.ev_x[2]++; if (tail - head <= 64) S.ev_x[3]++; } }
+#endif
     if (pos < 0) {
         // unknown id: if the head - the first slot that is not a tombstone - is a snapshot order (internal_id == -1)
         // it absorbs the removal (:133-137)
@@ -619,6 +650,10 @@ SDI void submit_limit(Lds& L, Scal& S, int side, int64_t price, int32_t vol, boo
 SDI void process_message(Lds& L, Scal& S, int type, int side, int64_t price, int64_t vol64, int64_t ext_id) {
     if (vol64 == 0) { S.status |= LOBSIM_ST_ASSERT; return; }  // assert order.volume > 0 (the packed field is unsigned)
     int32_t vol = (vol64 >> 31) ? 0x7fffffff : (int32_t)vol64;
+#ifdef LOBSIM_PROFILE
+    if (type == LOBSIM_LIMIT) S.ev_x[4]++;
+    if (type == LOBSIM_MARKET) S.ev_x[5]++;
+#endif
     switch (type) {
     case LOBSIM_LIMIT: submit_limit(L, S, side, price, vol, false, ext_id); break;
     case LOBSIM_MARKET: execute(L, S, side, false, true, 0, vol); break;
@@ -1151,7 +1186,23 @@ SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt,
     if (rem) cs = S.slots[(size_t)cslab * SLOTS + cpos];
     rem = rem && cs.kind == K_EXT && cs.id == b.eid;
     const int rkey = (cslab << 16) | cpos;
-    for (uint64_t todo = ballot(rem); todo;) {  // duplicates: same slot named twice -> keep the first lane only
+    // duplicates: same slot named twice -> keep the first lane only.  Rare, so first a cheap test: every lane drops its
+    // number into a 64-entry table at a hash of its slot; a lane that reads back another number shares the entry (a true
+    // duplicate or a hash clash), and only then does the exact loop run (one turn per distinct slot).
+    uint64_t todo = 0;
+#if LOBSIM_DEDUPE_HASH
+    {
+        uint32_t* tbl = reinterpret_cast<uint32_t*>(&L.cur[0][0]);
+        const uint32_t h = ((uint32_t)rkey * 0x9E3779B1u) >> 26;
+        if (rem) tbl[h] = (uint32_t)ln;
+        wsync();
+        const bool clash = rem && tbl[h] != (uint32_t)ln;
+        if (ballot(clash)) todo = ballot(rem);
+    }
+#else
+    todo = ballot(rem);
+#endif
+    for (; todo;) {
         const int f = ffs64(todo);
         const int k = rl32(rkey, f);
         const uint64_t grp = ballot(rem && rkey == k);
@@ -1209,6 +1260,7 @@ SDI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, 
         for (int j = 0; j < cnt && !S.status; j++) {
             if (j >= classified) {
                 int seg_end;
+                EVENT(ev_x[6]);
                 applied |= append_segment(L, S, b, j, cnt, seg_end, li_memo, memo_ver);
                 classified = seg_end + 1;  // the message at seg_end goes through the general routine as it is
             }
@@ -1780,6 +1832,7 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
     Scal S;
 #ifdef LOBSIM_PROFILE
     S.ev_chunks = S.ev_compact = S.ev_ladder = S.ev_exec_levels = S.ev_rare = S.ev_serial_ops = 0;
+    for (int k = 0; k < 9; k++) S.ev_x[k] = 0;
     for (int k = 0; k < 10; k++) S.sub_t[k] = 0;
 #endif
 #ifdef LOBSIM_PROFILE_MSG
@@ -1900,7 +1953,7 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
         P.prof[(size_t)env * 8 + 7] += 1;
         uint64_t* ev = P.prof + (size_t)gridDim.x * 8 + (size_t)env * 16;  // event counts share the message-class block
         ev[0] += S.ev_chunks; ev[1] += S.ev_compact; ev[2] += S.ev_ladder; ev[3] += S.ev_exec_levels; ev[4] += S.ev_rare; ev[5] += S.ev_serial_ops;
-        for (int k = 0; k < 9; k++) ev[6 + k] += S.sub_t[k + 1] > S.sub_t[k] ? S.sub_t[k + 1] - S.sub_t[k] : 0;  // sub-phase k
+        for (int k = 0; k < 9; k++) ev[6 + k] += S.ev_x[k];
 #ifdef LOBSIM_PROFILE_MSG
         uint64_t* pm = P.prof + (size_t)gridDim.x * 8 + (size_t)env * 16;
         for (int k = 0; k < 8; k++) { pm[k] = S.pm_cycles[k]; pm[8 + k] += S.pm_count[k]; }  // (overwrites the event counts)

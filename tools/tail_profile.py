@@ -67,6 +67,7 @@ X = np.column_stack([nm, ev[:, 0], ev[:, 1], ev[:, 2], np.ones(len(nm))])
 coef = np.linalg.lstsq(X, mc, rcond=None)[0]
 print("message-phase cycles ~ " + " + ".join(f"{c:.0f}*{n}" for c, n in zip(coef, ["msgs", "chunks", "compactions", "ladder_ops", "1"])))
 sub = np.array([r["sub"] for r in rows]).mean(axis=0)
+print("per env-step (mean env): serial removals %.2f, of them unknown ids %.2f (queue span <= 4: %.2f, <= 64: %.2f); serial limit messages %.2f, serial market messages %.2f; segments %.2f" % tuple(sub[:7]))
 print("op-list generation sub-phases (mean env cycles): pdf %.0f | normalise+round %.0f | inventory/best prices %.0f | agent entries -> levels %.0f | diff publish %.0f... candidates %.0f | op list %.0f" % tuple(sub[:7][[0, 1, 2, 3, 4, 4, 5]]) if False else "op-list sub-phases (mean env cycles): " + ", ".join(f"{x:.0f}" for x in sub[:6]) + f"; feature state load {sub[7]:.0f}, make_view {sub[8]:.0f}")
 if "msg" not in sys.argv: sys.exit(0)
 pmsg = np.zeros((N, 16), dtype=np.uint64)
