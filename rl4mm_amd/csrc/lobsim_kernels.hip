@@ -63,6 +63,9 @@ namespace lobk {
 #ifndef LOBSIM_SCAN_WIDTH
 #define LOBSIM_SCAN_WIDTH 4   // slab chunks a queue scan keeps in flight (2 or 4)
 #endif
+#ifndef LOBSIM_EARLY_BOOK_STORE
+#define LOBSIM_EARLY_BOOK_STORE 1  // step kernel: ladder / agent orders are written back before the feature phase, not after it
+#endif
 #ifndef LOBSIM_TOMB
 #define LOBSIM_TOMB 128  // tombstones a level may hold before its slab is squeezed.  Measured 8 .. 384: with queue scans
                          // on every cancellation the optimum was 16-32; now that the position cache answers most of them, 128
@@ -1721,9 +1724,12 @@ SDI void load_env(Lds& L, Scal& S, const DevPtrs& P, int env, const EnvHdr& H) {
     wsync();
 }
 
-SDI void store_env(const Lds& L, const Scal& S, const DevPtrs& P, int env, EnvHdr& H) {
+// The book (ladder, agent orders, free masks) and the rest of the header can be written back separately: the step kernel
+// writes the book as soon as the message window is replayed, so that those stores travel while the features are computed.
+SDI void store_env(const Lds& L, const Scal& S, const DevPtrs& P, int env, EnvHdr& H, bool book = true, bool rest = true) {
     int ln = lane();
     wsync();
+    if (book) {
     Ladder& G = P.ladder[env];
 #pragma unroll
     for (int s = 0; s < 2; s++)
@@ -1735,14 +1741,16 @@ SDI void store_env(const Lds& L, const Scal& S, const DevPtrs& P, int env, EnvHd
     const uint64_t af0 = lds_u64(L.agent_free[0]) | lds_u64(L.agent_pending[0]), af1 = lds_u64(L.agent_free[1]) | lds_u64(L.agent_pending[1]);
     if (!((af0 >> ln) & 1)) { A[ln] = L.agent[ln]; AP[ln] = L.apos[ln]; }  // live entries only (see load_env)
     if (af1 != ~0ull && !((af1 >> ln) & 1)) { A[ln + 64] = L.agent[ln + 64]; AP[ln + 64] = L.apos[ln + 64]; }
+    if (ln < NSLAB / 64) H.slab_free[ln] = L.slab_free[ln];
+    if (ln < NA / 64) H.agent_free[ln] = L.agent_free[ln] | L.agent_pending[ln];
+    if (ln == 0) { H.n_lv[0] = S.n_lv[0]; H.n_lv[1] = S.n_lv[1]; H.agent_seq = L.agent_seq; }
+    }
+    if (!rest) return;
     if (ln == 0) {
-        H.n_lv[0] = S.n_lv[0]; H.n_lv[1] = S.n_lv[1];
-        H.status = S.status; H.inventory = L.inv; H.cash = L.cash; H.agent_seq = L.agent_seq;
+        H.status = S.status; H.inventory = L.inv; H.cash = L.cash;
         H.agent_fill_count = L.ag_cnt[0] + L.ag_cnt[1]; H.agent_vol[0] = L.ag_vol[0]; H.agent_vol[1] = L.ag_vol[1];
         H.ext_count[0] = L.ext_cnt[0]; H.ext_count[1] = L.ext_cnt[1]; H.ext_vol[0] = L.ext_vol[0]; H.ext_vol[1] = L.ext_vol[1];
     }
-    if (ln < NSLAB / 64) H.slab_free[ln] = L.slab_free[ln];
-    if (ln < NA / 64) H.agent_free[ln] = L.agent_free[ln] | L.agent_pending[ln];
 }
 
 SDI void clear_step_fills(Lds& L) {
@@ -1884,6 +1892,7 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
     int done = 0;
     FeatState fs = FeatState();
     const int entry_status = S.status;
+    bool book_stored = false;
     if (!S.status) {
         const int64_t inv0 = cur_inv(L), cash0 = cur_cash(L);
         const double p0 = price;
@@ -1902,6 +1911,10 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
         STAMP(4);
         SUBSTAMP(7);
         if (ln < F) fs = P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln];  // loaded late: not live across the order loops
+#if LOBSIM_EARLY_BOOK_STORE
+        store_env(L, S, P, env, H, true, false);  // the book is final: its stores travel while the features are computed
+        book_stored = true;
+#endif
         SUBSTAMP(8);
         if (!S.status) {
             StepView v = make_view(L, S, price, now);
@@ -1939,7 +1952,7 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
     }
     if (ln < F) P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln] = fs;
     if (A.info && !entry_status && !S.status) write_info(L, S, C, H, act, price, A.info + (size_t)env * LOBSIM_INFO_DIM);
-    store_env(L, S, P, env, H);
+    store_env(L, S, P, env, H, !book_stored, true);
     if (ln == 0) {
         H.now_us = now; H.msg_cursor = cursor; H.price = price; H.n_resyncs = n_resyncs;
         H.min_buy = R.min_buy; H.max_sell = R.max_sell;
