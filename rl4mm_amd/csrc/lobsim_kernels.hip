@@ -461,6 +461,9 @@ SDI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, in
     const Slot* sl = S.slots + (size_t)m_slab(m) * SLOTS;
     int pos = -1;
     int32_t pv = 0;
+#ifdef LOBSIM_PROFILE
+    bool prof_not_oldest = false, prof_any_ext = false;
+#endif
 #if LOBSIM_MERGED_SCAN
     // the same pass notes the head - the first slot that is not a tombstone - for the unknown-id rule below
     int first_live = -1;
@@ -472,6 +475,13 @@ SDI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, in
         Slot sc[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) sc[k] = load_slot(sl, (c + k) * 64 + ln, head, tail);  // beyond the tail: no lane loads
+#ifdef LOBSIM_PROFILE
+        for (int k = 0; k < 4; k++) {  // (diagnostic) is the id older than every tracked order of the queue?
+            const uint64_t older = ballot(sc[k].kind == K_EXT && sc[k].id < id), any = ballot(sc[k].kind == K_EXT);
+            if (older) prof_not_oldest = true;
+            if (any) prof_any_ext = true;
+        }
+#endif
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint64_t b = ballot(sc[k].kind == kind && sc[k].id == id);
@@ -502,7 +512,7 @@ SDI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, in
     int32_t pk = kind;
     int64_t pid = id;
 #ifdef LOBSIM_PROFILE
-    if (kind == K_EXT) { S.ev_x[0]++; if (pos < 0) { S.ev_x[1]++; if (tail - head <= 4) S.ev_x[2]++; if (tail - head <= 64) S.ev_x[3]++; } }
+    if (kind == K_EXT) { S.ev_x[0]++; if (pos < 0) { S.ev_x[1]++; if (tail - head <= 4) S.ev_x[2]++; if (tail - head <= 64) S.ev_x[3]++; if (!prof_not_oldest && prof_any_ext) S.ev_x[7]++; if (hk == K_SNAP) S.ev_x[8]++; } }
 #endif
     if (pos < 0) {
         // unknown id: if the head - the first slot that is not a tombstone - is a snapshot order (internal_id == -1)
