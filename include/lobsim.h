@@ -60,7 +60,8 @@ enum lobsim_status {
     LOBSIM_ST_LEVEL_OVERFLOW = 4,  /* more price levels on one side than the build holds */
     LOBSIM_ST_QUEUE_OVERFLOW = 8,  /* more live orders at one price than the build holds */
     LOBSIM_ST_AGENT_OVERFLOW = 16, /* more live agent orders than the build holds */
-    LOBSIM_ST_STREAM_END = 32,     /* stepped past the end of the loaded stream */
+    LOBSIM_ST_STREAM_END = 32,     /* no snapshot at or before the episode's start, or a step that ends 2 s or more beyond the
+                                      last message / snapshot of the loaded stream */
     LOBSIM_ST_ASSERT = 64,         /* `assert order.volume > 0` (Exchange.py:59-60) and similar */
     LOBSIM_ST_NOT_RESET = 128
 };

@@ -116,6 +116,7 @@ typedef struct {
     int64_t n_msgs;
     const int64_t* snaps;
     int64_t n_snaps;
+    int64_t end_sec; /* first whole second (since midnight) that lies 2 s or more beyond the last message / snapshot */
 } Stream;
 
 typedef struct {
@@ -556,6 +557,9 @@ static void forward_step(oracle_t* h, Env* e, int64_t until, Order* internal, in
     }
     e->now_us = until;
     if (e->status) return;
+    /* not a reference behaviour but the boundary's (lobsim.h, LOBSIM_ST_STREAM_END): a step that ends two seconds or more
+     * beyond the loaded data is a usage error, flagged instead of silently replaying nothing */
+    if (e->stream_id >= 0 && until / 1000000 >= h->streams[e->stream_id].end_sec) { e->status |= LOBSIM_ST_STREAM_END; return; }
     if (e->stream_id >= 0 && near_exit(h, e) && e->now_us % 1000000 == 0) update_outer_levels(h, e, &c);
 }
 
@@ -1061,6 +1065,13 @@ int oracle_add_stream(oracle_t* h, const int64_t* msgs, int64_t n_msgs, const in
     int64_t* m = (int64_t*)malloc(mb ? mb : 8); memcpy(m, msgs, mb);
     int64_t* sn = (int64_t*)malloc(sb ? sb : 8); memcpy(sn, snaps, sb);
     s->msgs = m; s->n_msgs = n_msgs; s->snaps = sn; s->n_snaps = n_snaps;
+    {
+        int64_t sw = 2 + 4 * (int64_t)h->cfg.n_levels, tmax = INT64_MIN;
+        if (n_msgs) tmax = m[4 * (n_msgs - 1)];
+        if (n_snaps && sn[sw * (n_snaps - 1)] > tmax) tmax = sn[sw * (n_snaps - 1)];
+        if (tmax == INT64_MIN) tmax = 0;
+        s->end_sec = (tmax >= 0 ? tmax / 1000000 : -((-tmax + 999999) / 1000000)) + 3;
+    }
     return h->n_streams++;
 }
 

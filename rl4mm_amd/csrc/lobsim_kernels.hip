@@ -1805,6 +1805,10 @@ SDI void advance_one_step(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, in
     if (stream_id >= 0 && !S.status) replay_messages(L, S, P.streams[stream_id], cursor, until, first);
     now_us = until;
     if (S.status) return;
+    if (stream_id >= 0) {  // LOBSIM_ST_STREAM_END: every message is consumed and the step ends 2 s or more beyond the loaded data
+        const StreamDev& st = P.streams[stream_id];
+        if (cursor >= st.n_msgs && until / 1000000 - st.first_sec >= st.n_secs) { S.status |= LOBSIM_ST_STREAM_END; return; }
+    }
     if (stream_id >= 0 && now_us % 1000000 == 0) {
         bool near = best_buy_d(L, S) < R.min_buy + C.outer_prop * R.init_buy || best_sell_d(L, S) > R.max_sell - C.outer_prop * R.init_sell;
         if (near) { n_resyncs++; resync_outer_levels(L, S, C, P.streams[stream_id], now_us, R); }

@@ -828,3 +828,32 @@ def test_batched_episode_summary_equals_host_trajectories(agent_kind):
         assert esd["rewards"][e] == np.mean(d["rewards"]) and esd["spread"][e] == np.mean(spread) and esd["inventory"][e] == np.mean(inv)
         assert np.allclose(esd["actions"][e], np.mean(np.array(d["actions"]), axis=0)[:-1], rtol=1e-15, atol=0)
     assert agent_kind != "fixed" or np.abs(inv).max() > 0  # the fixed quotes inside the spread are filled
+
+
+def test_stepping_past_the_end_of_the_stream_is_flagged():
+    """LOBSIM_ST_STREAM_END: an episode that runs 2 s or more beyond the last message of its stream stops with the flag (the
+    reference's database would serve empty windows for ever); device and oracle flag the same step."""
+    stream = ol.golden_stream("synth_small")
+    t_last = int(stream.msgs[-1, 0])
+    cfg = _capi.make_cfg(3, 10, _short_features(), step_us=100_000, episode_us=60_000_000)
+    gpu, cpu = _lib.new_sim(cfg), ol.oracle_sim(cfg)
+    start = (t_last // 1_000_000 - 6) * 1_000_000
+    for sim in (gpu, cpu):
+        sim.add_stream(stream)
+        sim.set_portfolio(0, 10**9)
+        sim.reset(np.full(3, start), 0)
+    rng = np.random.Generator(np.random.PCG64(2))
+    flagged_at = None
+    for t in range(120):
+        act = rng.uniform(0, 10, size=(3, 4))
+        og, rg, dg = gpu.step(act)
+        oc, rc, dc = cpu.step(act)
+        assert np.array_equal(dg, dc), t
+        if dg.all():
+            flagged_at = t
+            break
+        assert np.allclose(og, oc, rtol=RTOL, atol=ATOL)
+    assert flagged_at is not None and 60 <= flagged_at <= 100
+    for e in range(3):
+        assert gpu.env_state(e)["status"] == cpu.env_state(e)["status"] == _capi.ST_STREAM_END
+    gpu.close()
