@@ -116,10 +116,23 @@ struct RolloutArgs {
 // Everything below is a member of Eng<LVT>: LVT = price levels per side the LDS-resident ladder holds (64 or 128; the HBM
 // image always has room for lobk::LV = 128).  The 64-level build is the one the 10-level configurations run: 7.5 KB of
 // ladder + agent state per env leaves LDS room for the message batch and the feature state to be prefetched by LDS-DMA.
-template <int LVT>
+// SPEC = the kernels of the reference's DEFAULT env configuration with its constants folded at compile time: 10 quote levels
+// from the touch (min_quote_level 0, max_quote_level 10), tick 100, 0.1 s steps, a 4-dim action, no concentration / market
+// order clearing / enter_spread (rl4mm/helpers/main_helper.py:70-100; lobsim_host.inc picks it when the cfg says exactly
+// that).  Measured +3 % per step; every other configuration reads the same values from the kernel arguments.
+template <int LVT, bool SPEC = false>
 struct Eng {
 static constexpr int LV = LVT;
 static constexpr int HALVES = LVT / 64;  // ladder entries per lane
+#define CFG_Q(C) (SPEC ? 10 : (C).Q)
+#define CFG_TICK(C) (SPEC ? 100 : (C).c.tick_size)
+#define CFG_MINQ(C) (SPEC ? 0 : (C).c.min_quote_level)
+#define CFG_CONC(C) (SPEC ? 0 : (C).c.use_concentration)
+#define CFG_MOC(C) (SPEC ? 0 : (C).c.market_order_clearing)
+#define CFG_SPREAD(C) (SPEC ? 0 : (C).c.enter_spread)
+#define CFG_STEP_US(C) (SPEC ? 100000ll : (C).c.step_us)
+#define CFG_ADIM(C) (SPEC ? 4 : (C).c.action_dim)
+#define CFG_MAGIC(C) (SPEC ? 42949673u : (C).tick_magic)
 
 // 9.4 KB per env -> 16 envs (waves) per CU: all 4096 envs of a launch are resident at once
 struct Lds {
@@ -685,7 +698,7 @@ SDI void process_op(Lds& L, Scal& S, const DevCfg& C, Op8 op) {
     if (type == LOBSIM_MARKET) { execute(L, S, side, true, true, 0, op.vol); return; }
     int64_t price;
     if (type == LOBSIM_LIMIT && !from_agent) {
-        int64_t off = (int64_t)(C.c.min_quote_level + idx) * C.c.tick_size;
+        int64_t off = (int64_t)(CFG_MINQ(C) + idx) * CFG_TICK(C);
         price = side == LOBSIM_BUY ? S.q_buy - off : S.q_sell + off;
     } else price = uni64(L.agent[idx].price);
     if (type == LOBSIM_LIMIT) submit_limit(L, S, side, price, op.vol, true, 0);
@@ -726,8 +739,8 @@ SDI void push_op(Lds& L, Scal& S, int type, int side, int idx, int32_t vol) {
 // order list first and only then hands it to the simulator).
 SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, bool want_info = false) {
     const lobsim_cfg& c = C.c;
-    const int Q = C.Q, ln = lane();
-    const int64_t tick = c.tick_size;
+    const int Q = CFG_Q(C), ln = lane();
+    const int64_t tick = CFG_TICK(C);
     S.n_ops = 0;
     SUBSTAMP(0);
     // ---- BetaOrderDistributor.convert_action (OrderDistributors.py:23-25,39-56); lane = side * Q + k
@@ -736,7 +749,7 @@ SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, b
     bool quoting = ln < 2 * Q;
     if (quoting) {
         double a, b;
-        if (c.use_concentration) { a = (my_side ? action.v1 : action.v0) + EPS; b = c.concentration - a + EPS; }
+        if (CFG_CONC(C)) { a = (my_side ? action.v1 : action.v0) + EPS; b = c.concentration - a + EPS; }
         else { a = (my_side ? action.v2 : action.v0) + EPS; b = (my_side ? action.v3 : action.v1) + EPS; }
         // beta.pdf up to the 1/B(a,b) that cancels in the normalisation below; x^(a-1) (1-x)^(b-1) as one exp over
         // host-tabulated logs (two pow() calls were a quarter of this kernel's fixed VALU work).  Only the integer
@@ -759,12 +772,12 @@ SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, b
     }
     const int64_t inv = cur_inv(L);
     int64_t abs_inv = inv < 0 ? -inv : inv;
-    bool clearing = c.market_order_clearing && (double)abs_inv > act_at(action, c.action_dim - 1);
+    bool clearing = CFG_MOC(C) && (double)abs_inv > act_at(action, CFG_ADIM(C) - 1);
     if (clearing) desired = 0;
     // ---- _get_best_prices (:298-322)
     if (S.n_lv[LOBSIM_SELL] == 0) { S.status |= LOBSIM_ST_EMPTY_BOOK; return; }  // np.arange(inf) raises
     int64_t best_buy = S.n_lv[LOBSIM_BUY] ? uni64(L.price[LOBSIM_BUY][0]) : 0, best_sell = uni64(L.price[LOBSIM_SELL][0]);
-    if (c.enter_spread) {
+    if (CFG_SPREAD(C)) {
         double mid = ((double)best_sell + (double)best_buy) / 2;
         best_buy = (int64_t)(floor(mid / (double)tick) * (double)tick);
         best_sell = (int64_t)(ceil(mid / (double)tick) * (double)tick);
@@ -782,12 +795,12 @@ SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, b
             int s = o.seq_side >> 31;
             int64_t d = s == LOBSIM_BUY ? best_buy - o.price : o.price - best_sell;
             ek[r] = -1;  // negative, not a tick multiple or beyond the quoted range: "wide"
-            if (d >= 0 && d < (int64_t)(c.min_quote_level + Q) * tick) {  // small: 32-bit divide
+            if (d >= 0 && d < (int64_t)(CFG_MINQ(C) + Q) * tick) {  // small: 32-bit divide
                 uint32_t du = (uint32_t)d, tu = (uint32_t)tick;
                 // d / tick: multiply-high by ceil(2^32 / tick) is exact while d * tick < 2^32 (the host checks the quoted
                 // range against that, tick_magic = 0 otherwise); a run-time 32-bit division is ~30 instructions per entry
-                uint32_t qd = C.tick_magic ? __umulhi(du, C.tick_magic) : du / tu;
-                int kk = (int)qd - c.min_quote_level;
+                uint32_t qd = CFG_MAGIC(C) ? __umulhi(du, CFG_MAGIC(C)) : du / tu;
+                int kk = (int)qd - CFG_MINQ(C);
                 if (qd * tu == du && kk >= 0) ek[r] = kk;
             }
             if (ek[r] >= 0) atomicAdd(&L.cur[s][ek[r]], o.vol);
@@ -925,7 +938,7 @@ SDI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
     const bool is_limit = have && type == LOBSIM_LIMIT && op.vol > 0, is_cancel = have && type == LOBSIM_CANCELLATION && op.vol > 0;
     int64_t price = 0;
     if (is_limit) {
-        int64_t off = (int64_t)(C.c.min_quote_level + idx) * C.c.tick_size;
+        int64_t off = (int64_t)(CFG_MINQ(C) + idx) * CFG_TICK(C);
         price = side == LOBSIM_BUY ? S.q_buy - off : S.q_sell + off;
     }
     if (is_cancel) price = L.agent[idx].price;
@@ -1801,7 +1814,7 @@ SDI void run_agent_ops(Lds& L, Scal& S, const DevCfg& C) {
 SDI void advance_one_step(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, int stream_id, int64_t& cursor, int64_t& now_us,
                          Ranges& R, int& n_resyncs, double& price, bool with_ops, const MsgBatch& first) {
     if (with_ops) run_agent_ops(L, S, C);
-    int64_t until = now_us + C.c.step_us;
+    int64_t until = now_us + CFG_STEP_US(C);
     if (stream_id >= 0 && !S.status) replay_messages(L, S, P.streams[stream_id], cursor, until, first);
     now_us = until;
     if (S.status) return;
@@ -1846,7 +1859,7 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
     const int env = blockIdx.x, ln = lane();
     if (A.active && !A.active[env]) return;
     EnvHdr& H = P.hdr[env];
-    const int F = C.c.n_features, AD = C.c.action_dim, D = C.obs_dim;
+    const int F = C.c.n_features, AD = CFG_ADIM(C), D = C.obs_dim;
 #ifdef LOBSIM_PROFILE
     uint64_t prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -1895,7 +1908,7 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
 #endif
     STAMP(1);
     {   // longest-job-first from the start of the step (replay_messages sets the same level again)
-        const int c0 = popc64(ballot(first.t <= now + C.c.step_us));
+        const int c0 = popc64(ballot(first.t <= now + CFG_STEP_US(C)));
         if (c0 >= LOBSIM_PRIO_C) __builtin_amdgcn_s_setprio(3);
         else if (c0 >= LOBSIM_PRIO_B) __builtin_amdgcn_s_setprio(2);
         else if (c0 >= LOBSIM_PRIO_A) __builtin_amdgcn_s_setprio(1);
@@ -1943,7 +1956,7 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
         }
         if (!S.status) {
             reward = step_reward<EXTRAS>(L, S, C, P, env, false, inv0, cash0, p0, price);
-            if (2 * (H.terminal_us - now) < C.c.step_us) {  // terminal_time - now < step_size / 2 (:172-174)
+            if (2 * (H.terminal_us - now) < CFG_STEP_US(C)) {  // terminal_time - now < step_size / 2 (:172-174)
                 reward = step_reward<EXTRAS>(L, S, C, P, env, true, inv0, cash0, p0, price);
                 done = 1;
             }
@@ -2273,10 +2286,10 @@ SDI void process_orders_body(const DevCfg& C, const DevPtrs& P, int env, const i
 #ifndef LOBSIM_ROLLOUT_WAVES
 #define LOBSIM_ROLLOUT_WAVES 4
 #endif
-template <bool EXTRAS, int LVT>
-__global__ __launch_bounds__(64, LVT == 64 ? LOBSIM_STEP_WAVES : LOBSIM_STEP_WAVES_DEEP) void lob_step_kernel(DevCfg C, DevPtrs P, StepArgs A) { Eng<LVT>::template step_body<EXTRAS>(C, P, A); }
-template <bool EXTRAS, int LVT>
-__global__ __launch_bounds__(64, LOBSIM_ROLLOUT_WAVES) void lob_rollout_kernel(DevCfg C, DevPtrs P, RolloutArgs A) { Eng<LVT>::template rollout_body<EXTRAS>(C, P, A); }
+template <bool EXTRAS, int LVT, bool SPEC = false>
+__global__ __launch_bounds__(64, LVT == 64 ? LOBSIM_STEP_WAVES : LOBSIM_STEP_WAVES_DEEP) void lob_step_kernel(DevCfg C, DevPtrs P, StepArgs A) { Eng<LVT, SPEC>::template step_body<EXTRAS>(C, P, A); }
+template <bool EXTRAS, int LVT, bool SPEC = false>
+__global__ __launch_bounds__(64, LOBSIM_ROLLOUT_WAVES) void lob_rollout_kernel(DevCfg C, DevPtrs P, RolloutArgs A) { Eng<LVT, SPEC>::template rollout_body<EXTRAS>(C, P, A); }
 template <bool EXTRAS, int LVT>
 __global__ __launch_bounds__(64, 4) void lob_reset_kernel(DevCfg C, DevPtrs P, ResetArgs A) { Eng<LVT>::template reset_body<EXTRAS>(C, P, A); }
 template <int LVT>

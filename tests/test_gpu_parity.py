@@ -857,3 +857,41 @@ def test_stepping_past_the_end_of_the_stream_is_flagged():
     for e in range(3):
         assert gpu.env_state(e)["status"] == cpu.env_state(e)["status"] == _capi.ST_STREAM_END
     gpu.close()
+
+
+def test_specialised_default_config_kernels_equal_generic_ones():
+    """The reference's default configuration runs kernels with its constants folded at compile time (Eng<64, true>); the same
+    configuration forced onto the generic 128-level kernels (cfg.ladder_levels = 128) must give every output bit for bit,
+    per step and through the multi-step launch."""
+    import torch
+
+    import bench
+
+    n, steps = 256, 80
+    stream = bench.build_streams("random", 20)[0]
+    feats = bench.default_features(_capi)
+    sims = [_lib.new_sim(_capi.make_cfg(n, 10, feats, step_us=100_000, episode_us=1_800_000_000, ladder_levels=lv)) for lv in (0, 128)]
+    starts, sids = bench.workload_starts("random", n, 1, 5)
+    rng = np.random.Generator(np.random.PCG64(6))
+    acts = rng.uniform(0, 10, size=(steps, n, 4))
+    outs = []
+    for sim in sims:
+        sim.add_stream(stream)
+        sim.set_portfolio(0, 10**12)
+        rec = [sim.reset(starts, sids)]
+        for t in range(steps // 2):
+            rec += list(sim.step(acts[t]))
+        D = sim.obs_dim
+        obs, reward, done = torch.zeros((n, D), dtype=torch.float64).cuda(), torch.zeros(n, dtype=torch.float64).cuda(), torch.zeros(n, dtype=torch.uint8).cuda()
+        d_acts = _dev(acts[steps // 2 :])
+        sim.rollout_device(_capi.POLICY_GIVEN, [], steps - steps // 2, d_acts.data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr(), 0, 0)
+        sim.sync()
+        rec += [obs.cpu().numpy(), reward.cpu().numpy(), *sim.portfolios()]
+        outs.append(rec)
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    assert np.abs(outs[0][-3]).max() > 0
+    for e in (0, 100, 255):
+        assert np.array_equal(sims[0].queues(e), sims[1].queues(e))
+    for s in sims:
+        s.close()
