@@ -482,8 +482,20 @@ SDI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, in
     int first_live = -1;
     int32_t hk = K_DEAD, hv = 0;
 #endif
+#if LOBSIM_TRUST_APOS
+    // one of the agent's own live orders: its slot index is in apos and its volume is mirrored in L.agent (see
+    // apply_agent_ops_parallel) - no queue scan
+    bool known_agent = false;
+    if (kind == K_AGENT && id >= 0 && id < NA) {
+        const int32_t av = uni(L.agent[id].vol);
+        const int ap = (int)uni((int32_t)L.apos[id]);
+        if (av > 0 && ap >= head && ap < tail) { pos = ap; pv = av; known_agent = true; }
+    }
+#else
+    const bool known_agent = false;
+#endif
 #if LOBSIM_SCAN_WIDTH == 4
-    for (int c = head >> 6; c * 64 < tail; c += 4) {  // 1 KiB chunks, four loads in flight; a ballot per chunk finds the order
+    for (int c = head >> 6; c * 64 < tail && !known_agent; c += 4) {  // 1 KiB chunks, four loads in flight; a ballot per chunk finds the order
         EVENT(ev_chunks);
         Slot sc[4];
 #pragma unroll
