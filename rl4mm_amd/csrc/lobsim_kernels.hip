@@ -66,6 +66,9 @@ namespace lobk {
 #ifndef LOBSIM_EARLY_BOOK_STORE
 #define LOBSIM_EARLY_BOOK_STORE 1  // step kernel: ladder / agent orders are written back before the feature phase, not after it
 #endif
+#ifndef LOBSIM_SLOT_EARLY
+#define LOBSIM_SLOT_EARLY 1   // lane-parallel cancellations: cache entries read once per batch, the slot asked for before the segment's appends
+#endif
 #ifndef LOBSIM_TOMB
 #define LOBSIM_TOMB 128  // tombstones a level may hold before its slab is squeezed.  Measured 8 .. 384: with queue scans
                          // on every cancellation the optimum was 16-32; now that the position cache answers most of them, 128
@@ -1170,7 +1173,7 @@ SDI MsgBatch fetch_messages(const StreamDev& st, int64_t cursor) {
 // cancellation never changes where an append lands (tail positions only grow); compaction and level creation are not
 // taken here.  Returns the lanes appended; `seg_end` = first lane that needs the general routine first (or cnt).
 // Half of all messages take this path with no scalar-unit work per message.
-SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt, int& seg_end, int& li_memo, uint32_t& memo_levels) {
+SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt, int& seg_end, int& li_memo, uint32_t& memo_levels, uint64_t ce_batch) {
     const int ln = lane();
     const bool in = ln >= j0 && ln < cnt;
     const int type = (int)((b.meta >> LOBSIM_TYPE_SHIFT) & 0xf), side = (int)((b.meta >> LOBSIM_SIDE_SHIFT) & 1);
@@ -1184,9 +1187,17 @@ SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt,
     }
     const int li = (is_lim || is_rem) ? li_memo : -1;
     const uint64_t m = li >= 0 ? L.meta[side][li] : 0;
+#if LOBSIM_SLOT_EARLY
+    // cancellations: the position-cache entries were read once for the whole batch (replay_messages; an entry only changes
+    // when its order is appended or moved in this very batch, and then the stale copy fails the verification below and the
+    // message takes the general routine).  That lets the SLOT be asked for here, before the appends are booked, so that
+    // its round trip travels behind them instead of after them.
+    const uint64_t ce = (is_rem && li >= 0) ? ce_batch : 0;
+#else
     // cancellations: ask the position cache now, so the answer is in flight while the appends are booked
     uint64_t ce = 0;
     if (is_rem && li >= 0) ce = S.idc[(uint64_t)b.eid & (IDC_N - 1)];
+#endif
     bool cross = false;
     if (is_lim && S.n_lv[side ^ 1] > 0) { const int64_t bp = L.price[side ^ 1][0]; cross = side == LOBSIM_BUY ? b.price >= bp : b.price <= bp; }
     const bool plain = is_lim && vol64 > 0 && vol64 < (1ll << 31) && li >= 0 && !cross && m_live(m) > 0 &&
@@ -1195,6 +1206,13 @@ SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt,
     seg_end = stop ? ffs64(stop) : cnt;
     const bool app = plain && ln < seg_end;
     const uint64_t below = (1ull << ln) - 1;
+#if LOBSIM_SLOT_EARLY
+    const int cslab = (int)((ce >> 16) & 0xffff), cpos = (int)(ce & 0xffff);
+    // (range check against the level's meta word as it is BEFORE this segment's appends: they only move the tail up)
+    bool rem = is_rem && ln < seg_end && li >= 0 && (uint32_t)(ce >> 32) == idc_tag(b.eid) && cslab == m_slab(m) && cpos >= m_head(m) && cpos < m_tail(m);
+    Slot cs = dead_slot();
+    if (rem) cs = S.slots[(size_t)cslab * SLOTS + cpos];
+#endif
     const int key = (side << 8) | li;
     int rank = 0;
     for (uint64_t todo = ballot(app); todo;) {  // one turn per distinct level hit
@@ -1216,12 +1234,14 @@ SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt,
     // A lane takes this path only when its entry points into the live range [head, tail) of the slab of the level its
     // price names and that slot holds exactly this external order; the first lane wins when two messages of the
     // segment name one order (the other, later one is replayed by the general routine afterwards, in order).
+#if !LOBSIM_SLOT_EARLY
     bool rem = is_rem && ln < seg_end && li >= 0 && (uint32_t)(ce >> 32) == idc_tag(b.eid);
     const int cslab = (int)((ce >> 16) & 0xffff), cpos = (int)(ce & 0xffff);
     const uint64_t m2 = rem ? L.meta[side][li] : 0;  // after the appends of this segment
     rem = rem && cslab == m_slab(m2) && cpos >= m_head(m2) && cpos < m_tail(m2);
     Slot cs = dead_slot();
     if (rem) cs = S.slots[(size_t)cslab * SLOTS + cpos];
+#endif
     rem = rem && cs.kind == K_EXT && cs.id == b.eid;
     const int rkey = (cslab << 16) | cpos;
     // duplicates: same slot named twice -> keep the first lane only.  Rare, so first a cheap test: every lane drops its
@@ -1293,13 +1313,20 @@ SDI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, 
         else __builtin_amdgcn_s_setprio(0);
         int li_memo = -1;                             // per lane: level index of this lane's price ...
         uint32_t memo_ver = S.ladder_ver + 0x80000000u;  // ... as of this ladder version (none yet)
+        uint64_t ce_batch = 0;
+#if LOBSIM_SLOT_EARLY
+        {
+            const int ty = (int)((b.meta >> LOBSIM_TYPE_SHIFT) & 0xf);
+            if (ln < cnt && (ty == LOBSIM_CANCELLATION || ty == LOBSIM_DELETION)) ce_batch = S.idc[(uint64_t)b.eid & (IDC_N - 1)];
+        }
+#endif
         uint64_t applied = 0;  // lanes whose limit order the lane-parallel pass has already booked
         int classified = 0;    // lanes below this have been through append_segment
         for (int j = 0; j < cnt && !S.status; j++) {
             if (j >= classified) {
                 int seg_end;
                 EVENT(ev_x[6]);
-                applied |= append_segment(L, S, b, j, cnt, seg_end, li_memo, memo_ver);
+                applied |= append_segment(L, S, b, j, cnt, seg_end, li_memo, memo_ver, ce_batch);
                 classified = seg_end + 1;  // the message at seg_end goes through the general routine as it is
             }
             if ((applied >> j) & 1) continue;
