@@ -2,7 +2,7 @@
 import ctypes as C, os, sys, time
 from pathlib import Path
 import numpy as np
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import bench, oracle_lib as ol
 from rl4mm_amd import _capi

@@ -3,7 +3,7 @@ through 300-step rollout launches and by one handle through single steps.  usage
 import subprocess, sys, time
 from pathlib import Path
 import numpy as np, torch
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import multiprocessing as mp
 import bench, oracle_lib as ol
