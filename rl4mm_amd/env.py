@@ -428,6 +428,7 @@ class HistoricalOrderbookVectorEnv:
         n_levels: int = 50,
         outer_levels: int = 20,
         device_id: int = 0,
+        ladder_levels: int = 0,
     ):
         # action space, HistoricalOrderbookEnvironment.py:85-94
         if concentration is not None:
@@ -465,6 +466,9 @@ class HistoricalOrderbookVectorEnv:
             concentration=concentration, market_order_clearing=market_order_clearing, market_order_fraction_of_inventory=market_order_fraction_of_inventory,
             enter_spread=enter_spread, inc_prev_action_in_obs=inc_prev_action_in_obs, per_step_reward=self.per_step_reward_function.desc(),
             terminal_reward=self.terminal_reward_function.desc(), device_id=device_id,
+            ladder_levels=ladder_levels,  # price levels per side an env can hold (0 = 64 for books of <= 16 visible levels, else 128): the
+                                          # reference keeps stale levels that left LOBSTER's visible range for the rest of the episode, so a
+                                          # strongly trending day wants 128; beyond the capacity an env stops with LOBSIM_ST_LEVEL_OVERFLOW
         )  # fmt: skip
         self.sim = _lib.new_sim(cfg)  # raises if the HIP library or the GPU is missing: there is no CPU path
         self._stream_ids: Dict[Tuple[str, str], int] = {}
