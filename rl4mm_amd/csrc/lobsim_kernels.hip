@@ -2031,11 +2031,12 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
         P.prof[(size_t)env * 8 + 6] += S.n_ops;
         P.prof[(size_t)env * 8 + 7] += 1;
         uint64_t* ev = P.prof + (size_t)gridDim.x * 8 + (size_t)env * 16;  // event counts share the message-class block
+#ifndef LOBSIM_PROFILE_MSG
         ev[0] += S.ev_chunks; ev[1] += S.ev_compact; ev[2] += S.ev_ladder; ev[3] += S.ev_exec_levels; ev[4] += S.ev_rare; ev[5] += S.ev_serial_ops;
         for (int k = 0; k < 9; k++) ev[6 + k] += S.ev_x[k];
-#ifdef LOBSIM_PROFILE_MSG
+#else
         uint64_t* pm = P.prof + (size_t)gridDim.x * 8 + (size_t)env * 16;
-        for (int k = 0; k < 8; k++) { pm[k] = S.pm_cycles[k]; pm[8 + k] += S.pm_count[k]; }  // (overwrites the event counts)
+        for (int k = 0; k < 8; k++) { pm[k] += S.pm_cycles[k]; pm[8 + k] += S.pm_count[k]; }  // (in the place of the event counts)
 #endif
     }
 #endif

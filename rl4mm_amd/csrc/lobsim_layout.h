@@ -26,7 +26,10 @@ constexpr int LV = 128;          // price levels per side (2 per lane)
 constexpr int SLOTS = 512;       // order slots per price level (8 chunks of one wave-load each; 8 KiB slab)
 constexpr int NSLAB = 2 * LV;    // slabs per env
 constexpr int NA = 128;          // live agent orders per env (2 per lane)
-constexpr int IDC_N = 32768;     // entries of the per-env external-order position cache (256 KiB; a cache: every hit is
+#ifndef LOBSIM_IDC_N
+#define LOBSIM_IDC_N 32768
+#endif
+constexpr int IDC_N = LOBSIM_IDC_N;    // entries of the per-env external-order position cache (256 KiB; a cache: every hit is
                                  // verified against the slot it points to, misses take the queue scan)
 constexpr int QMAX = 32;         // quote levels per side (2 * QMAX <= 64 lanes)
 constexpr int OPS_MAX = 2 * QMAX + NA + 8;  // agent op list: limits + cancels + market order (resync re-adds reuse it)
