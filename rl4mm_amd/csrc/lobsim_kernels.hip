@@ -752,33 +752,57 @@ SDI void push_op(Lds& L, Scal& S, int type, int side, int idx, int32_t vol) {
 
 // Builds L.ops from the action and the PRE-step book; nothing is mutated (the reference computes the whole
 // order list first and only then hands it to the simulator).
-SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, bool want_info = false) {
+// BetaOrderDistributor.convert_action (OrderDistributors.py:23-25,39-56); lane = side * Q + k -> the volume the action asks
+// for at quote level k of that side.  Needs the action only (L.pdf is its scratch), so the step kernel runs it while the
+// env state is on its way from HBM.
+struct BetaLogs { double lx, l1x; };  // ln x_k, ln(1 - x_k) of this lane's quote level
+SDI BetaLogs beta_logs(const DevCfg& C) {
+    const int Q = CFG_Q(C), ln = lane();
+    const int k = ln < 2 * Q ? ln - (ln / Q) * Q : 0;
+    BetaLogs t = {C.log_x[k], C.log_1mx[k]};
+    return t;
+}
+
+SDI int32_t beta_volumes(Lds& L, const DevCfg& C, const Act5& action, const BetaLogs& T) {
     const lobsim_cfg& c = C.c;
     const int Q = CFG_Q(C), ln = lane();
-    const int64_t tick = CFG_TICK(C);
-    S.n_ops = 0;
-    SUBSTAMP(0);
-    // ---- BetaOrderDistributor.convert_action (OrderDistributors.py:23-25,39-56); lane = side * Q + k
     const double EPS = 0.000001;
     int my_side = ln / Q, my_k = ln - my_side * Q;
     bool quoting = ln < 2 * Q;
-    if (quoting) {
+    {
         double a, b;
         if (CFG_CONC(C)) { a = (my_side ? action.v1 : action.v0) + EPS; b = c.concentration - a + EPS; }
         else { a = (my_side ? action.v2 : action.v0) + EPS; b = (my_side ? action.v3 : action.v1) + EPS; }
         // beta.pdf up to the 1/B(a,b) that cancels in the normalisation below; x^(a-1) (1-x)^(b-1) as one exp over
         // host-tabulated logs (two pow() calls were a quarter of this kernel's fixed VALU work).  Only the integer
         // volumes after rounding are observable: tests pin them against a 320k-value scipy table.
-        L.pdf[my_side][my_k] = exp((a - 1.0) * C.log_x[my_k] + (b - 1.0) * C.log_1mx[my_k]);
+        double arg = (a - 1.0) * T.lx + (b - 1.0) * T.l1x;
+        // The exponent is pinned here, outside the branch: left alone the compiler sinks the table loads into the branch,
+        // behind every other load of the step's prologue.  The exp itself stays under the narrow mask - a wave's f64
+        // instruction takes as many passes as it has active 16-lane groups, so 20 active lanes cost half of 64.
+        asm volatile("" : "+v"(arg));
+        if (quoting) L.pdf[my_side][my_k] = exp(arg);
     }
-    if (ln < 2 * QMAX) L.cur[ln / QMAX][ln % QMAX] = 0;
     wsync();
-    SUBSTAMP(1);
     int32_t desired = 0;
     if (quoting) {
         double s = np_pairwise_sum(L.pdf[my_side], Q);
         desired = (int32_t)rint(L.pdf[my_side][my_k] / s * 100.0);  // np.round(dist * active_volume).astype(int)
     }
+    wsync();  // (L.pdf is reused by build_agent_ops)
+    return desired;
+}
+
+SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, int32_t desired, bool want_info = false) {
+    const lobsim_cfg& c = C.c;
+    const int Q = CFG_Q(C), ln = lane();
+    const int64_t tick = CFG_TICK(C);
+    S.n_ops = 0;
+    SUBSTAMP(0);
+    int my_side = ln / Q, my_k = ln - my_side * Q;
+    bool quoting = ln < 2 * Q;
+    if (ln < 2 * QMAX) L.cur[ln / QMAX][ln % QMAX] = 0;
+    wsync();
     SUBSTAMP(2);
     if (want_info) {  // InfoCalculators.py:60-79 works on the action's volumes as the distributor gives them (before any clearing)
         const uint64_t qb = ballot(quoting && my_side == 0 && desired > 0), qs = ballot(quoting && my_side == 1 && desired > 0);
@@ -925,6 +949,10 @@ SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, b
 }
 
 // per-lane binary search of a price in the sorted ladder of one side; -1 if there is no such level
+SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, bool want_info = false) {
+    build_agent_ops(L, S, C, action, beta_volumes(L, C, action, beta_logs(C)), want_info);
+}
+
 SDI int lane_find_level(const Lds& L, int side, int n, int64_t price) {
     int lo = 0, hi = n;
     while (lo < hi) {
@@ -1154,16 +1182,15 @@ struct MsgBatch { int64_t t, eid, price, meta; };
 typedef long long ll2_t __attribute__((ext_vector_type(2)));
 typedef const ll2_t __attribute__((address_space(1)))* GlobalI64x2;  // global (not flat) loads of the packed stream
 
-SDI MsgBatch fetch_messages(const StreamDev& st, int64_t cursor) {
-    MsgBatch b = {INT64_MAX, 0, 0, 0};
-    const int64_t i = cursor + lane();
-    if (i < st.n_msgs) {
-        GlobalI64x2 m = (GlobalI64x2)(st.msgs + i * LOBSIM_MSG_WORDS);
-        ll2_t a = m[0], c = m[1];  // 2 x dwordx4, 32 contiguous bytes per lane
-        b.t = a.x; b.eid = a.y; b.price = c.x; b.meta = c.y;
-    }
+// No bounds test: the host appends 64 sentinel rows (t = INT64_MAX) to every stream (lobsim_add_stream), and a load inside
+// a branch makes the compiler wait for it at the end of the branch (phi copies), with every older load of the wave.
+SDI MsgBatch fetch_messages(const int64_t* msgs, int64_t cursor) {
+    GlobalI64x2 m = (GlobalI64x2)(msgs + (cursor + lane()) * LOBSIM_MSG_WORDS);
+    const ll2_t a = m[0], c = m[1];  // 2 x dwordx4, 32 contiguous bytes per lane
+    MsgBatch b = {a.x, a.y, c.x, c.y};
     return b;
 }
+SDI MsgBatch fetch_messages(const StreamDev& st, int64_t cursor) { return fetch_messages(st.msgs, cursor); }
 
 // Lane-parallel pass over the messages j0.. of a batch (appends, then cancellations): every plain limit order (rests at an existing level with room,
 // does not cross) up to the first message that is neither that nor a cancellation/deletion is appended at once - lane
@@ -1293,7 +1320,16 @@ SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt,
 // the window (now, until] of historical messages, in stream order (OrderbookSimulator.py:70-85).  `b` is the batch
 // at `cursor`, requested by the caller as early as it knew the cursor (the step kernel asks for it before it builds
 // the agent's orders, so the stream's HBM latency hides behind that work).
-SDI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, int64_t until_us, MsgBatch b) {
+// the position-cache entries of the cancellations / deletions among the in-window messages of batch b (see append_segment)
+SDI uint64_t batch_cache_entries(const Scal& S, const MsgBatch& b, int64_t until_us) {
+    const int ty = (int)((b.meta >> LOBSIM_TYPE_SHIFT) & 0xf);
+    uint64_t ce = 0;
+    if (b.t <= until_us && (ty == LOBSIM_CANCELLATION || ty == LOBSIM_DELETION)) ce = S.idc[(uint64_t)b.eid & (IDC_N - 1)];
+    return ce;
+}
+
+// `ce_first` (when have_ce): batch_cache_entries of the first batch, asked for by the caller ahead of time.
+SDI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, int64_t until_us, MsgBatch b, uint64_t ce_first = 0, bool have_ce = false) {
     const int ln = lane();
     while (!S.status) {
         uint64_t bm = ballot(b.t <= until_us);
@@ -1315,10 +1351,8 @@ SDI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, 
         uint32_t memo_ver = S.ladder_ver + 0x80000000u;  // ... as of this ladder version (none yet)
         uint64_t ce_batch = 0;
 #if LOBSIM_SLOT_EARLY
-        {
-            const int ty = (int)((b.meta >> LOBSIM_TYPE_SHIFT) & 0xf);
-            if (ln < cnt && (ty == LOBSIM_CANCELLATION || ty == LOBSIM_DELETION)) ce_batch = S.idc[(uint64_t)b.eid & (IDC_N - 1)];
-        }
+        if (have_ce) { ce_batch = ce_first; have_ce = false; }
+        else ce_batch = batch_cache_entries(S, b, until_us);
 #endif
         uint64_t applied = 0;  // lanes whose limit order the lane-parallel pass has already booked
         int classified = 0;    // lanes below this have been through append_segment
@@ -1743,31 +1777,61 @@ SDI void write_info(const Lds& L, const Scal& S, const DevCfg& C, EnvHdr& H, con
 // ---------------------------------------------------------------------------------------------------------------
 // env state <-> LDS
 // ---------------------------------------------------------------------------------------------------------------
-SDI void load_env(Lds& L, Scal& S, const DevPtrs& P, int env, const EnvHdr& H) {
+struct EnvRegs {  // the env state between its loads and its LDS stores
+    int64_t pb, psl; uint64_t mb, ms; int32_t vb, vs;
+    AgentOrd a0, a1;
+    uint16_t q0, q1;
+};
+
+// What load_env needs of the header, read as one cluster of scalar loads (one wait) by whoever knows the header address
+// first - read field by field where it is used, every use was a round trip of its own.
+struct HdrRegs {
+    uint64_t sf0, sf1, sf2, sf3, af0, af1;
+    int64_t inventory, cash;
+    uint32_t agent_seq;
+    int32_t status, n_lv0, n_lv1;
+};
+static_assert(NSLAB == 256 && NA == 128, "HdrRegs holds the free masks as scalars");
+
+SDI HdrRegs read_hdr(const EnvHdr& H) {
+    HdrRegs h = {H.slab_free[0], H.slab_free[1], H.slab_free[2], H.slab_free[3], H.agent_free[0], H.agent_free[1],
+                 H.inventory, H.cash, H.agent_seq, H.status, H.n_lv[0], H.n_lv[1]};
+    return h;
+}
+
+SDI EnvRegs load_env_issue(Scal& S, const DevPtrs& P, int env, const HdrRegs& H) {
     int ln = lane();
     const Ladder& G = P.ladder[env];
-    S.n_lv.v = (uint32_t)H.n_lv[0] | ((uint32_t)H.n_lv[1] << 16);
+    S.n_lv.v = (uint32_t)H.n_lv0 | ((uint32_t)H.n_lv1 << 16);
     // every global load of the common case (<= 64 levels per side) is issued before the first LDS store: one HBM
     // round trip for the whole env state instead of one per loop
-    const int nb = S.n_lv[0], ns = S.n_lv[1];
-    const bool hb = ln < nb, hs = ln < ns;
+    // (ladder and agent loads sit in branches - lanes beyond the live levels / free agent entries load nothing - but no
+    // value they load is touched inside its branch, so none of them makes the compiler wait there.  Reading clamped
+    // addresses without branches instead was measured: no faster.)
+    const bool hb = ln < S.n_lv[0], hs = ln < S.n_lv[1];
     int64_t pb = 0, psl = 0; uint64_t mb = 0, ms = 0; int32_t vb = 0, vs = 0;
     if (hb) { pb = G.price[0][ln]; mb = G.meta[0][ln]; vb = G.vol[0][ln]; }
     if (hs) { psl = G.price[1][ln]; ms = G.meta[1][ln]; vs = G.vol[1][ln]; }
-    // agent entries: only the live ones travel (the free mask in the header says which; entries are handed out lowest
-    // index first, so the upper half is usually all free and skipped by the whole wave)
     const AgentOrd* A = P.agent + (size_t)env * NA;
     const uint16_t* AP = P.apos + (size_t)env * NA;
-    const uint64_t af0 = H.agent_free[0], af1 = H.agent_free[1];
+    const uint64_t af0 = H.af0, af1 = H.af1;
     AgentOrd a0, a1;
     a0.price = 0; a0.vol = 0; a0.seq_side = 0; a1 = a0;
     uint16_t q0 = 0, q1 = 0;
     if (!((af0 >> ln) & 1)) { a0 = A[ln]; q0 = AP[ln]; }
     if (af1 != ~0ull && !((af1 >> ln) & 1)) { a1 = A[ln + 64]; q1 = AP[ln + 64]; }
-    if (hb) { L.price[0][ln] = pb; L.meta[0][ln] = mb; L.vol[0][ln] = vb; }
-    if (hs) { L.price[1][ln] = psl; L.meta[1][ln] = ms; L.vol[1][ln] = vs; }
-    L.agent[ln] = a0; L.agent[ln + 64] = a1;
-    L.apos[ln] = q0; L.apos[ln + 64] = q1;
+    EnvRegs r = {pb, psl, mb, ms, vb, vs, a0, a1, q0, q1};
+    return r;
+}
+
+SDI void load_env_commit(Lds& L, Scal& S, const DevPtrs& P, int env, const HdrRegs& H, const EnvRegs& r) {
+    int ln = lane();
+    const Ladder& G = P.ladder[env];
+    const bool hb = ln < S.n_lv[0], hs = ln < S.n_lv[1];
+    if (hb) { L.price[0][ln] = r.pb; L.meta[0][ln] = r.mb; L.vol[0][ln] = r.vb; }
+    if (hs) { L.price[1][ln] = r.psl; L.meta[1][ln] = r.ms; L.vol[1][ln] = r.vs; }
+    L.agent[ln] = r.a0; L.agent[ln + 64] = r.a1;
+    L.apos[ln] = r.q0; L.apos[ln + 64] = r.q1;
 #pragma unroll
     for (int s = 0; s < 2; s++)
         for (int i = ln + 64; i < S.n_lv[s]; i += 64) {
@@ -1775,8 +1839,8 @@ SDI void load_env(Lds& L, Scal& S, const DevPtrs& P, int env, const EnvHdr& H) {
         }
     if (ln < NA / 64) L.freed[ln] = 0;
     S.status = H.status; S.n_ops = 0; S.ladder_ver = 0;
-    if (ln < NSLAB / 64) L.slab_free[ln] = H.slab_free[ln];
-    if (ln < NA / 64) { L.agent_free[ln] = H.agent_free[ln]; L.agent_pending[ln] = 0; }
+    if (ln < NSLAB / 64) L.slab_free[ln] = ln == 0 ? H.sf0 : ln == 1 ? H.sf1 : ln == 2 ? H.sf2 : H.sf3;
+    if (ln < NA / 64) { L.agent_free[ln] = ln == 0 ? H.af0 : H.af1; L.agent_pending[ln] = 0; }
     if (ln == 0) {
         L.inv = H.inventory; L.cash = H.cash; L.agent_seq = H.agent_seq;
         L.ag_cnt[0] = L.ag_cnt[1] = 0; L.ag_vol[0] = L.ag_vol[1] = 0; L.ext_cnt[0] = L.ext_cnt[1] = 0; L.ext_vol[0] = L.ext_vol[1] = 0;
@@ -1784,6 +1848,12 @@ SDI void load_env(Lds& L, Scal& S, const DevPtrs& P, int env, const EnvHdr& H) {
     S.slots = P.slots + (size_t)env * NSLAB * SLOTS;
     S.idc = P.idc + (size_t)env * IDC_N;
     wsync();
+}
+
+SDI void load_env(Lds& L, Scal& S, const DevPtrs& P, int env, const EnvHdr& H) {
+    const HdrRegs h = read_hdr(H);
+    const EnvRegs r = load_env_issue(S, P, env, h);
+    load_env_commit(L, S, P, env, h, r);
 }
 
 // The book (ladder, agent orders, free masks) and the rest of the header can be written back separately: the step kernel
@@ -1851,10 +1921,10 @@ SDI void run_agent_ops(Lds& L, Scal& S, const DevCfg& C) {
 // OrderbookSimulator.forward_step (:70-88) + update_internal_state (HistoricalOrderbookEnvironment.py:199-204):
 // agent ops first, then the message window, clock, resync check, new price.
 SDI void advance_one_step(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, int stream_id, int64_t& cursor, int64_t& now_us,
-                         Ranges& R, int& n_resyncs, double& price, bool with_ops, const MsgBatch& first) {
+                         Ranges& R, int& n_resyncs, double& price, bool with_ops, const MsgBatch& first, uint64_t ce_first = 0, bool have_ce = false) {
     if (with_ops) run_agent_ops(L, S, C);
     int64_t until = now_us + CFG_STEP_US(C);
-    if (stream_id >= 0 && !S.status) replay_messages(L, S, P.streams[stream_id], cursor, until, first);
+    if (stream_id >= 0 && !S.status) replay_messages(L, S, P.streams[stream_id], cursor, until, first, ce_first, have_ce);
     now_us = until;
     if (S.status) return;
     if (stream_id >= 0) {  // LOBSIM_ST_STREAM_END: every message is consumed and the step ends 2 s or more beyond the loaded data
@@ -1912,6 +1982,17 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
 #ifdef LOBSIM_PROFILE_MSG
     for (int k = 0; k < 8; k++) { S.pm_cycles[k] = 0; S.pm_count[k] = 0; }
 #endif
+    // ---- prologue: every load the step needs up front is ISSUED before anything waits.  Vector-memory loads return in
+    // order and the compiler waits for a load wherever its value is first touched - a copy at the end of a branch is enough -
+    // so the order below is: header scalars (one cluster), then, with no branch in between that touches a loaded value,
+    // the Beta tables, the message batch, the feature bookkeeping, ladder, agent orders.
+    const HdrRegs hr = read_hdr(H);
+    int64_t now = H.now_us, cursor = H.msg_cursor;
+    const int stream_id = H.stream_id;
+    const int64_t terminal_us = H.terminal_us;
+    Ranges R = {H.min_buy, H.max_sell, H.init_buy_range, H.init_sell_range};
+    int n_resyncs = H.n_resyncs;
+    double price = H.price;
     Act5 act;
     if (A.policy == LOBSIM_POLICY_GIVEN) {
         const double* ap = A.actions + (size_t)env * AD;
@@ -1922,29 +2003,31 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
     } else {  // Teradactyl on the observation's inventory entry = that feature's current value
         act = teradactyl_action(A.params, P.feat[(size_t)env * LOBSIM_MAX_FEATURES + (int)A.params[5]].current_value);
     }
-    int64_t now = H.now_us, cursor = H.msg_cursor;
-    int stream_id = H.stream_id;
-    MsgBatch first = {INT64_MAX, 0, 0, 0};
-    if (stream_id >= 0) first = fetch_messages(P.streams[stream_id], cursor);  // in flight while the agent's orders are built
-#if LOBSIM_FEAT_PF
-    // (only what the ring addresses need travels early; asked for together with the env state)
-    int fkind = 0, flb = 0, fcount = 0, fpos = 0, froff = 0;
-    if (ln < F) {
-        fkind = C.c.features[ln].kind; flb = C.c.features[ln].lookback; froff = C.ring_off[ln];
-        const FeatState& g = P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln];
-        fcount = g.count; fpos = g.pos;
-    }
-#endif
-    load_env(L, S, P, env, H);
-#if LOBSIM_FEAT_PF
+    const BetaLogs bl = beta_logs(C);  // first in the queue: the Beta volumes are computed while the rest travels
+    const int64_t* msgs0 = stream_id >= 0 ? P.streams[stream_id].msgs : P.streams[0].msgs;  // (a handle has >= 1 stream once reset)
+    const MsgBatch first_raw = fetch_messages(msgs0, stream_id >= 0 ? cursor : 0);  // in flight while the agent's orders are built
+    // (only what the ring addresses need travels early; lanes beyond the features read feature 0's: no branch)
+    const int lf = ln < F ? ln : 0;
+    const int fkind = C.c.features[lf].kind, flb = C.c.features[lf].lookback, froff = C.ring_off[lf];
+    const FeatState& g0 = P.feat[(size_t)env * LOBSIM_MAX_FEATURES + lf];
+    const int fcount = g0.count, fpos = g0.pos;
+    const EnvRegs er = load_env_issue(S, P, env, hr);
+    const int32_t desired = beta_volumes(L, C, act, bl);  // needs the action only
+    load_env_commit(L, S, P, env, hr, er);
+    MsgBatch first = first_raw;
+    if (stream_id < 0) first.t = INT64_MAX;
+    // the first batch of messages landed with the env state: its cancellations' position-cache entries are asked for now
+    // and travel while the agent's orders are built and booked (a stale entry is only a miss, see append_segment)
+    uint64_t ce_first = 0;
+    const bool have_ce = LOBSIM_SLOT_EARLY && stream_id >= 0;
+    if (have_ce) ce_first = batch_cache_entries(S, first, now + CFG_STEP_US(C));
     int64_t rw0 = 0, rw1 = 0;
-    if (ln < F) {  // (landed with the env state: vector-memory loads return in order)
+    {   // (landed with the env state: vector-memory loads return in order)
         int i0, i1;
         ring_idx(fkind, flb, fcount, fpos, i0, i1);
         const int64_t* ring = P.rings + (size_t)env * C.ring_words + froff;
         rw0 = ring[i0]; rw1 = ring[i1];  // in flight while the agent's orders are built
     }
-#endif
     STAMP(1);
     {   // longest-job-first from the start of the step (replay_messages sets the same level again)
         const int c0 = popc64(ballot(first.t <= now + CFG_STEP_US(C)));
@@ -1952,9 +2035,7 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
         else if (c0 >= LOBSIM_PRIO_B) __builtin_amdgcn_s_setprio(2);
         else if (c0 >= LOBSIM_PRIO_A) __builtin_amdgcn_s_setprio(1);
     }
-    Ranges R = {H.min_buy, H.max_sell, H.init_buy_range, H.init_sell_range};
-    int n_resyncs = H.n_resyncs;
-    double price = H.price, reward = 0.0;
+    double reward = 0.0;
     int done = 0;
     FeatState fs = FeatState();
     const int entry_status = S.status;
@@ -1962,17 +2043,15 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
     if (!S.status) {
         const int64_t inv0 = cur_inv(L), cash0 = cur_cash(L);
         const double p0 = price;
-        build_agent_ops(L, S, C, act, A.info != nullptr);  // convert_action_to_orders on the pre-step state
-#if LOBSIM_FEAT_PF
+        build_agent_ops(L, S, C, act, desired, A.info != nullptr);  // convert_action_to_orders on the pre-step state
         if (ln < F) { L.rstash[ln][0] = rw0; L.rstash[ln][1] = rw1; }
-#endif
         STAMP(2);
 #ifdef LOBSIM_PROFILE
         if (!S.status) run_agent_ops(L, S, C);
         STAMP(3);
-        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, false, first);
+        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, false, first, ce_first, have_ce);
 #else
-        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true, first);
+        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true, first, ce_first, have_ce);
 #endif
         STAMP(4);
         SUBSTAMP(7);
@@ -1995,7 +2074,7 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
         }
         if (!S.status) {
             reward = step_reward<EXTRAS>(L, S, C, P, env, false, inv0, cash0, p0, price);
-            if (2 * (H.terminal_us - now) < CFG_STEP_US(C)) {  // terminal_time - now < step_size / 2 (:172-174)
+            if (2 * (terminal_us - now) < CFG_STEP_US(C)) {  // terminal_time - now < step_size / 2 (:172-174)
                 reward = step_reward<EXTRAS>(L, S, C, P, env, true, inv0, cash0, p0, price);
                 done = 1;
             }
