@@ -194,6 +194,9 @@ struct Scal {
     int32_t status;
     int32_t n_ops;
     uint32_t ladder_ver;    // bumped whenever a level is opened or removed (indices into the ladder shift)
+    int32_t msgs_step;      // messages replayed in this step so far (is this a light step? see squeeze_ahead) ...
+    bool ahead = false;     // ... and does this kernel squeeze ahead of time at all (the per-step kernel does: it is the one whose
+                            // launches end with their slowest env; a multi-step launch only pays for the extra squeezes)
     int64_t q_buy, q_sell;  // best prices the current op list was built against (_get_best_prices)
     Slot* slots;            // this env's slabs
     uint64_t* idc;          // this env's position cache of external orders (see IDC_N)
@@ -400,20 +403,28 @@ SDI uint64_t compact_level(Lds& L, Scal& S, int side, int idx, uint64_t m) {
     Slot* sl = S.slots + (size_t)slab * SLOTS;
     uint64_t below = (1ull << ln) - 1;
     int out = 0;
-    Slot nxt = load_slot(sl, (head >> 6) * 64 + ln, head, tail);
-    for (int c = head >> 6; c * 64 < tail; c++) {
-        const Slot s = nxt;
-        nxt = load_slot(sl, (c + 1) * 64 + ln, head, tail);  // the next chunk is on its way while this one is squeezed (a chunk's
-                                                              // survivors land at or below its own first slot: never in the next chunk)
-        uint64_t b = ballot(s.kind != K_DEAD);
-        wsync();  // every lane's load has been issued before any lane stores
-        if (s.kind != K_DEAD) {
-            int np = out + popc64(b & below);
-            sl[np] = s;
-            if (s.kind == K_AGENT) L.apos[s.id] = (uint16_t)np;
-            if (s.kind == K_EXT) idc_put(S, s.id, slab, np);
+#ifndef LOBSIM_COMPACT_WIDTH
+#define LOBSIM_COMPACT_WIDTH 4
+#endif
+    // A squeeze runs when 128 tombstones have piled up, i.e. over 3 to 8 chunks: LOBSIM_COMPACT_WIDTH of them are read
+    // with one round trip (one chunk per round trip made a squeeze the most expensive event of a step: ~10k cycles).
+    // A chunk's survivors land at or below its own first slot, so the stores of a group never reach a chunk not yet read.
+    for (int c = head >> 6; c * 64 < tail; c += LOBSIM_COMPACT_WIDTH) {
+        Slot s[LOBSIM_COMPACT_WIDTH];
+#pragma unroll
+        for (int k = 0; k < LOBSIM_COMPACT_WIDTH; k++) s[k] = load_slot(sl, (c + k) * 64 + ln, head, tail);  // beyond the tail: no lane loads
+        wsync();  // every lane's loads have been issued before any lane stores
+#pragma unroll
+        for (int k = 0; k < LOBSIM_COMPACT_WIDTH; k++) {
+            const uint64_t b = ballot(s[k].kind != K_DEAD);
+            if (s[k].kind != K_DEAD) {
+                int np = out + popc64(b & below);
+                sl[np] = s[k];
+                if (s[k].kind == K_AGENT) L.apos[s[k].id] = (uint16_t)np;
+                if (s[k].kind == K_EXT) idc_put(S, s[k].id, slab, np);
+            }
+            out += popc64(b);
         }
-        out += popc64(b);
         wsync();
     }
     return mk_meta(slab, 0, out, m_live(m));
@@ -433,6 +444,44 @@ SDI void level_append(Lds& L, Scal& S, int side, int idx, int64_t id, int32_t vo
         L.meta[side][idx] = mk_meta(m_slab(m), live == 0 ? tail : m_head(m), tail + 1, live + 1);
         atomicAdd(&L.vol[side][idx], vol);  // ds_add, no read-modify-write round trip
     }
+    wsync();
+}
+
+// Squeezes are due when a level holds LOBSIM_TOMB tombstones, whichever step that happens in - and a launch lasts as long
+// as its slowest env, which is slow because its window is long.  So an env whose window was SHORT squeezes ahead of time:
+// the level with the most tombstones, if it has at least LOBSIM_TOMB_AHEAD of them (or its slab is nearly full).  A squeeze
+// only moves slots inside a slab (FIFO order kept, position caches updated), so when it happens is unobservable.
+#ifndef LOBSIM_TOMB_AHEAD
+#define LOBSIM_TOMB_AHEAD 64
+#endif
+#ifndef LOBSIM_LIGHT_MSGS
+#define LOBSIM_LIGHT_MSGS 20
+#endif
+SDI void squeeze_ahead(Lds& L, Scal& S) {
+    const int ln = lane();
+    int best = 0;  // tombstones << 8 | side << 7 | index, of this lane's worst level
+#pragma unroll
+    for (int side = 0; side < 2; side++)
+#pragma unroll
+        for (int r = 0; r < HALVES; r++) {
+            const int i = ln + 64 * r;
+            if (i < S.n_lv[side]) {
+                const uint64_t m = L.meta[side][i];
+                int t = m_tail(m) - m_head(m) - m_live(m);
+                if (m_tail(m) > SLOTS - 2 * WAVE) t = LOBSIM_TOMB;  // nearly full
+                if (t >= LOBSIM_TOMB_AHEAD) best = max(best, (t << 8) | (side << 7) | i);
+            }
+        }
+    if (!ballot(best != 0)) return;
+    int w = best;  // wave maximum
+#pragma unroll
+    for (int o = 32; o; o >>= 1) w = max(w, __shfl_xor(w, o));
+    w = uni(w);
+    const int side = (w >> 7) & 1, idx = w & 127;
+    const uint64_t m = (uint64_t)uni64((int64_t)L.meta[side][idx]);
+    if (m_tail(m) - m_head(m) == m_live(m)) return;  // (nearly full but without a tombstone: nothing to gain)
+    const uint64_t nm = compact_level(L, S, side, idx, m);
+    if (ln == 0) L.meta[side][idx] = nm;
     wsync();
 }
 
@@ -540,7 +589,7 @@ SDI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, in
     int32_t pk = kind;
     int64_t pid = id;
 #ifdef LOBSIM_PROFILE
-    if (kind == K_EXT) { S.ev_x[0]++; if (pos < 0) { S.ev_x[1]++; if (tail - head <= 4) S.ev_x[2]++; if (tail - head <= 64) S.ev_x[3]++; if (!prof_not_oldest && prof_any_ext) S.ev_x[7]++; if (hk == K_SNAP) S.ev_x[8]++; } }
+    if (kind == K_EXT) { S.ev_x[0]++; if (pos < 0) { S.ev_x[1]++; } }
 #endif
     if (pos < 0) {
         // unknown id: if the head - the first slot that is not a tombstone - is a snapshot order (internal_id == -1)
@@ -564,10 +613,24 @@ SDI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, in
 }
 
 // cuts strictly inside the executed interval (from, from + ex) of one resting order (all lanes run the same trip count)
+// (the cuts are cumulative volumes, ascending: a long run - a burst of 30 or 40 executions is what the busiest env of a
+// launch replays - is searched, not walked: a walk per resting order made such a run cost 20k cycles)
 SDI int32_t cuts_inside(const int32_t* cuts, int n_cuts, int32_t from, int32_t ex) {
-    int32_t k = 0;
-    for (int i = 0; i < n_cuts; i++) { const int32_t c = cuts[i]; k += (c > from && c < from + ex) ? 1 : 0; }
-    return k;
+    if (n_cuts <= 4) {
+        int32_t k = 0;
+        for (int i = 0; i < n_cuts; i++) { const int32_t c = cuts[i]; k += (c > from && c < from + ex) ? 1 : 0; }
+        return k;
+    }
+    // cuts below from + ex minus cuts below from + 1, both by a branch-free binary search over at most 63 entries
+    int lo_a = 0, lo_b = 0;
+#pragma unroll
+    for (int step = 32; step; step >>= 1) {
+        const int ta = lo_a + step, tb = lo_b + step;
+        const int32_t ca = cuts[min(ta, 2 * QMAX) - 1], cb = cuts[min(tb, 2 * QMAX) - 1];
+        if (ta <= n_cuts && ca < from + ex) lo_a = ta;
+        if (tb <= n_cuts && cb < from + 1) lo_b = tb;
+    }
+    return lo_a - lo_b;
 }
 
 // execute_order (Exchange.py:85-120): the aggressor (side, limit price or market) sweeps the opposite side level by
@@ -1237,8 +1300,9 @@ SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt,
     const int cslab = (int)((ce >> 16) & 0xffff), cpos = (int)(ce & 0xffff);
     // (range check against the level's meta word as it is BEFORE this segment's appends: they only move the tail up)
     bool rem = is_rem && ln < seg_end && li >= 0 && (uint32_t)(ce >> 32) == idc_tag(b.eid) && cslab == m_slab(m) && cpos >= m_head(m) && cpos < m_tail(m);
-    Slot cs = dead_slot();
-    if (rem) cs = S.slots[(size_t)cslab * SLOTS + cpos];
+    // (no branch around the load: the compiler would wait for it at the end of the branch, i.e. before the appends instead
+    // of behind them; a lane without a removal reads slot 0 of slab 0 and ignores it)
+    const Slot cs = S.slots[rem ? (size_t)cslab * SLOTS + cpos : (size_t)0];
 #endif
     const int key = (side << 8) | li;
     int rank = 0;
@@ -1360,7 +1424,13 @@ SDI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, 
             if (j >= classified) {
                 int seg_end;
                 EVENT(ev_x[6]);
+#ifdef LOBSIM_PROFILE
+                const uint64_t ts0 = __builtin_amdgcn_s_memtime();
+#endif
                 applied |= append_segment(L, S, b, j, cnt, seg_end, li_memo, memo_ver, ce_batch);
+#ifdef LOBSIM_PROFILE
+                S.ev_x[2] += (uint32_t)(__builtin_amdgcn_s_memtime() - ts0);  // cycles in the lane-parallel passes
+#endif
                 classified = seg_end + 1;  // the message at seg_end goes through the general routine as it is
             }
             if ((applied >> j) & 1) continue;
@@ -1374,11 +1444,17 @@ SDI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, 
                 const uint64_t sm = ballot(same) >> j;
                 const int run = sm == ~0ull ? 64 - j : ffs64(~sm);  // consecutive lanes from j on
                 if (run >= 2) {
+#ifdef LOBSIM_PROFILE
+                    const uint64_t tr0 = __builtin_amdgcn_s_memtime();
+#endif
                     const int32_t pre = wave_incl_scan((ln >= j && ln < j + run) ? (int32_t)lv : 0);
                     if (ln >= j && ln < j + run - 1) L.cur[0][ln - j] = pre;
                     wsync();
                     execute(L, S, (int)((mm >> LOBSIM_SIDE_SHIFT) & 1), false, true, 0, rl32(pre, j + run - 1), run - 1);
                     j += run - 1;
+#ifdef LOBSIM_PROFILE
+                    S.ev_x[7] += (uint32_t)(__builtin_amdgcn_s_memtime() - tr0);  // cycles in execution runs
+#endif
                     continue;
                 }
             }
@@ -1394,7 +1470,13 @@ SDI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, 
             const uint64_t t0 = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_sched_barrier(0);
 #endif
+#if defined(LOBSIM_PROFILE) && !defined(LOBSIM_PROFILE_MSG)
+            const uint64_t tp0 = __builtin_amdgcn_s_memtime();
+#endif
             process_message(L, S, (int)((mm >> LOBSIM_TYPE_SHIFT) & 0xf), (int)((mm >> LOBSIM_SIDE_SHIFT) & 1), rl64(b.price, j), mm & LOBSIM_VOL_MASK, rl64(b.eid, j));
+#if defined(LOBSIM_PROFILE) && !defined(LOBSIM_PROFILE_MSG)
+            S.ev_x[3] += (uint32_t)(__builtin_amdgcn_s_memtime() - tp0);  // cycles in single messages through the general routines
+#endif
 #ifdef LOBSIM_PROFILE_MSG
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_sched_barrier(0);
@@ -1411,6 +1493,7 @@ SDI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, 
 #endif
         }
         cursor += cnt;
+        S.msgs_step += cnt;
         if (cnt < 64) break;
         b = fetch_messages(st, cursor);
     }
@@ -1838,7 +1921,7 @@ SDI void load_env_commit(Lds& L, Scal& S, const DevPtrs& P, int env, const HdrRe
             L.price[s][i] = G.price[s][i]; L.meta[s][i] = G.meta[s][i]; L.vol[s][i] = G.vol[s][i];
         }
     if (ln < NA / 64) L.freed[ln] = 0;
-    S.status = H.status; S.n_ops = 0; S.ladder_ver = 0;
+    S.status = H.status; S.n_ops = 0; S.ladder_ver = 0; S.msgs_step = 0;
     if (ln < NSLAB / 64) L.slab_free[ln] = ln == 0 ? H.sf0 : ln == 1 ? H.sf1 : ln == 2 ? H.sf2 : H.sf3;
     if (ln < NA / 64) { L.agent_free[ln] = ln == 0 ? H.af0 : H.af1; L.agent_pending[ln] = 0; }
     if (ln == 0) {
@@ -1912,7 +1995,16 @@ SDI void run_agent_ops(Lds& L, Scal& S, const DevCfg& C) {
     if (S.n_ops > 0) has_market = (uni(L.ops[S.n_ops - 1].code) & 0xf) == LOBSIM_MARKET;  // the clearing order is last
     if (S.n_ops <= 64 && !has_market && S.q_buy < S.q_sell) todo = apply_agent_ops_parallel(L, S, C);
     if (S.n_ops <= 64) {
-        while (todo && !S.status) { int k = ffs64(todo); todo &= todo - 1; EVENT(ev_serial_ops); process_op(L, S, C, L.ops[k]); }
+        while (todo && !S.status) {
+            int k = ffs64(todo); todo &= todo - 1; EVENT(ev_serial_ops);
+#ifdef LOBSIM_PROFILE
+            const uint64_t t0 = __builtin_amdgcn_s_memtime();
+#endif
+            process_op(L, S, C, L.ops[k]);
+#ifdef LOBSIM_PROFILE
+            S.ev_x[8] += (uint32_t)(__builtin_amdgcn_s_memtime() - t0);  // cycles in serially replayed agent ops
+#endif
+        }
     } else {
         for (int k = 0; k < S.n_ops && !S.status; k++) process_op(L, S, C, L.ops[k]);
     }
@@ -1921,15 +2013,21 @@ SDI void run_agent_ops(Lds& L, Scal& S, const DevCfg& C) {
 // OrderbookSimulator.forward_step (:70-88) + update_internal_state (HistoricalOrderbookEnvironment.py:199-204):
 // agent ops first, then the message window, clock, resync check, new price.
 SDI void advance_one_step(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, int stream_id, int64_t& cursor, int64_t& now_us,
-                         Ranges& R, int& n_resyncs, double& price, bool with_ops, const MsgBatch& first, uint64_t ce_first = 0, bool have_ce = false) {
+                         Ranges& R, int& n_resyncs, double& price, bool with_ops, const MsgBatch& first, int64_t n_msgs, uint64_t ce_first = 0, bool have_ce = false) {
     if (with_ops) run_agent_ops(L, S, C);
     int64_t until = now_us + CFG_STEP_US(C);
     if (stream_id >= 0 && !S.status) replay_messages(L, S, P.streams[stream_id], cursor, until, first, ce_first, have_ce);
     now_us = until;
     if (S.status) return;
+#if LOBSIM_TOMB_AHEAD
+    if (S.ahead && S.msgs_step <= LOBSIM_LIGHT_MSGS) squeeze_ahead(L, S);
+    S.msgs_step = 0;
+#endif
     if (stream_id >= 0) {  // LOBSIM_ST_STREAM_END: every message is consumed and the step ends 2 s or more beyond the loaded data
+        // (n_msgs = the stream's message count, read by the caller before its first global store: after one the compiler takes a
+        // uniform load for a vector load and waits for it - and for every store in flight - right here, every step)
         const StreamDev& st = P.streams[stream_id];
-        if (cursor >= st.n_msgs && until / 1000000 - st.first_sec >= st.n_secs) { S.status |= LOBSIM_ST_STREAM_END; return; }
+        if (cursor >= n_msgs && until / 1000000 - st.first_sec >= st.n_secs) { S.status |= LOBSIM_ST_STREAM_END; return; }
     }
     if (stream_id >= 0 && now_us % 1000000 == 0) {
         bool near = best_buy_d(L, S) < R.min_buy + C.outer_prop * R.init_buy || best_sell_d(L, S) > R.max_sell - C.outer_prop * R.init_sell;
@@ -1987,6 +2085,7 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
     // so the order below is: header scalars (one cluster), then, with no branch in between that touches a loaded value,
     // the Beta tables, the message batch, the feature bookkeeping, ladder, agent orders.
     const HdrRegs hr = read_hdr(H);
+    S.ahead = true;
     int64_t now = H.now_us, cursor = H.msg_cursor;
     const int stream_id = H.stream_id;
     const int64_t terminal_us = H.terminal_us;
@@ -2004,7 +2103,9 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
         act = teradactyl_action(A.params, P.feat[(size_t)env * LOBSIM_MAX_FEATURES + (int)A.params[5]].current_value);
     }
     const BetaLogs bl = beta_logs(C);  // first in the queue: the Beta volumes are computed while the rest travels
-    const int64_t* msgs0 = stream_id >= 0 ? P.streams[stream_id].msgs : P.streams[0].msgs;  // (a handle has >= 1 stream once reset)
+    const StreamDev& st0 = P.streams[stream_id >= 0 ? stream_id : 0];  // (a handle has >= 1 stream once reset)
+    const int64_t* msgs0 = st0.msgs;
+    const int64_t n_msgs0 = st0.n_msgs;
     const MsgBatch first_raw = fetch_messages(msgs0, stream_id >= 0 ? cursor : 0);  // in flight while the agent's orders are built
     // (only what the ring addresses need travels early; lanes beyond the features read feature 0's: no branch)
     const int lf = ln < F ? ln : 0;
@@ -2049,24 +2150,35 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
 #ifdef LOBSIM_PROFILE
         if (!S.status) run_agent_ops(L, S, C);
         STAMP(3);
-        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, false, first, ce_first, have_ce);
+        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, false, first, n_msgs0, ce_first, have_ce);
 #else
-        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true, first, ce_first, have_ce);
+        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true, first, n_msgs0, ce_first, have_ce);
 #endif
         STAMP(4);
         SUBSTAMP(7);
         if (ln < F) fs = P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln];  // loaded late: not live across the order loops
+        // This lane's feature description, all of it in one batch with the feature state: read field by field where
+        // feature_update uses it, every field was a dependent round trip of its own (five in a row).
+        lobsim_feature dsc;
+        {
+            const lobsim_feature& g = C.c.features[lf];
+            dsc.kind = fkind; dsc.lookback = flb;
+            dsc.update_us = g.update_us; dsc.min_value = g.min_value; dsc.max_value = g.max_value;
+            dsc.dparam = g.dparam; dsc.iparam = g.iparam; dsc.norm_len = g.norm_len;
+        }
 #if LOBSIM_EARLY_BOOK_STORE
         store_env(L, S, P, env, H, true, false);  // the book is final: its stores travel while the features are computed
         book_stored = true;
 #endif
+        // (pinned here, or the compiler sinks each load back into the branch that uses it)
+        asm volatile("" : "+v"(dsc.update_us), "+v"(dsc.min_value), "+v"(dsc.max_value), "+v"(dsc.dparam), "+v"(dsc.iparam));
         SUBSTAMP(8);
         if (!S.status) {
             StepView v = make_view(L, S, price, now);
             SUBSTAMP(9);
             bool ok = true;
 #if LOBSIM_FEAT_PF
-            if (ln < F) ok = feature_update<EXTRAS>(C.c.features[ln], fs, P.rings + (size_t)env * C.ring_words + C.ring_off[ln], v, norm_history(C, P, env, ln), true, L.rstash[ln][0], L.rstash[ln][1]);
+            if (ln < F) ok = feature_update<EXTRAS>(dsc, fs, P.rings + (size_t)env * C.ring_words + froff, v, norm_history(C, P, env, ln), true, L.rstash[ln][0], L.rstash[ln][1]);
 #else
             if (ln < F) ok = feature_update<EXTRAS>(C.c.features[ln], fs, P.rings + (size_t)env * C.ring_words + C.ring_off[ln], v, norm_history(C, P, env, ln));
 #endif
@@ -2166,6 +2278,12 @@ SDI void rollout_body(const DevCfg& C, const DevPtrs& P, const RolloutArgs& A) {
     if (ln < F) fval = P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln].current_value;
     int64_t now = H.now_us, cursor = H.msg_cursor;
     const int stream_id = H.stream_id;
+    // (what the loop needs of the stream table, the header and the feature table is read here, before the first global
+    // store: after one, the compiler turns every uniform load into a vector load with a wait of its own)
+    const StreamDev& st0 = P.streams[stream_id >= 0 ? stream_id : 0];
+    const int64_t n_msgs_all = st0.n_msgs;
+    const int64_t* msgs_all = st0.msgs;
+    const int64_t terminal_us = H.terminal_us;
     Ranges R = {H.min_buy, H.max_sell, H.init_buy_range, H.init_sell_range};
     int n_resyncs = H.n_resyncs;
     double price = H.price, reward = 0.0, ret = 0.0;
@@ -2186,11 +2304,11 @@ SDI void rollout_body(const DevCfg& C, const DevPtrs& P, const RolloutArgs& A) {
         const int64_t inv0 = cur_inv(L), cash0 = cur_cash(L);
         const double p0 = price;
         reward = 0.0;
-        MsgBatch first = {INT64_MAX, 0, 0, 0};
-        if (stream_id >= 0) first = fetch_messages(P.streams[stream_id], cursor);
+        MsgBatch first = fetch_messages(msgs_all, stream_id >= 0 ? cursor : 0);
+        if (stream_id < 0) first.t = INT64_MAX;
         const bool want_info = A.info != nullptr || A.trace != nullptr;
         build_agent_ops(L, S, C, act, want_info);
-        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true, first);
+        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true, first, n_msgs_all);
         if (!S.status) {
             StepView v = make_view(L, S, price, now);
             bool ok = true;
@@ -2204,7 +2322,7 @@ SDI void rollout_body(const DevCfg& C, const DevPtrs& P, const RolloutArgs& A) {
         }
         if (!S.status) {
             reward = step_reward<EXTRAS>(L, S, C, P, env, false, inv0, cash0, p0, price);
-            if (2 * (H.terminal_us - now) < C.c.step_us) {
+            if (2 * (terminal_us - now) < C.c.step_us) {
                 reward = step_reward<EXTRAS>(L, S, C, P, env, true, inv0, cash0, p0, price);
                 done = 1;
             }
@@ -2264,6 +2382,7 @@ SDI void reset_body(const DevCfg& C, const DevPtrs& P, const ResetArgs& A) {
     clear_step_fills(L);
     const int stream_id = A.stream_ids[k];
     const StreamDev& st = P.streams[stream_id];
+    const int64_t n_msgs_all = st.n_msgs;
     const int64_t start = A.start_us[k];
     int64_t now = start - C.c.warmup_us;
     // get_historical_start_book: last snapshot at or before `now` (whole second)
@@ -2298,7 +2417,7 @@ SDI void reset_body(const DevCfg& C, const DevPtrs& P, const ResetArgs& A) {
     const int64_t n_warm = C.c.warmup_us / C.c.step_us;
     for (int64_t s = 0; s < n_warm && !S.status; s++) {
         clear_step_fills(L);
-        advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, false, fetch_messages(st, cursor));
+        advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, false, fetch_messages(st, cursor), n_msgs_all);
         if (S.status) break;
         StepView v = make_view(L, S, price, now);
         bool ok = true;
