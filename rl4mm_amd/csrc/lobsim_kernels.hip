@@ -2414,6 +2414,7 @@ SDI void reset_body(const DevCfg& C, const DevPtrs& P, const ResetArgs& A) {
         }
         if (ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
     }
+    S.ahead = true;  // the episode starts with its levels squeezed (the warm-up's windows are all "short": no agent, no tail to protect)
     const int64_t n_warm = C.c.warmup_us / C.c.step_us;
     for (int64_t s = 0; s < n_warm && !S.status; s++) {
         clear_step_fills(L);
