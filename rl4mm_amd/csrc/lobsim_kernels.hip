@@ -1339,8 +1339,9 @@ SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt,
     // number into a 64-entry table at a hash of its slot; a lane that reads back another number shares the entry (a true
     // duplicate or a hash clash), and only then does the exact loop run (one turn per distinct slot).
     uint64_t todo = 0;
+    const uint64_t rem_lanes = ballot(rem);
 #if LOBSIM_DEDUPE_HASH
-    {
+    if (rem_lanes & (rem_lanes - 1)) {  // (two or more removals: only then can two of them name one slot)
         uint32_t* tbl = reinterpret_cast<uint32_t*>(&L.cur[0][0]);
         const uint32_t h = ((uint32_t)rkey * 0x9E3779B1u) >> 26;
         if (rem) tbl[h] = (uint32_t)ln;
@@ -1370,7 +1371,7 @@ SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt,
     }
     wsync();
     // levels emptied by these removals leave the ladder (rare; sequential, looked up again by price)
-    for (uint64_t em = ballot(rem && gone && m_live(L.meta[side][li]) == 0); em;) {
+    for (uint64_t em = ballot(rem && gone) ? ballot(rem && gone && m_live(L.meta[side][li]) == 0) : 0; em;) {
         const int j = ffs64(em);
         em &= em - 1;
         const int sd = rl32(side, j);
