@@ -737,6 +737,9 @@ SDI void submit_limit(Lds& L, Scal& S, int side, int64_t price, int32_t vol, boo
     }
     if (idx < 0) {
         idx = insert_pos(L, S, side, price);
+#ifdef LOBSIM_PROFILE
+        if (!is_agent && idx == 0) S.ev_rare++;  // (diagnostic) an external limit that opens a new best level
+#endif
         if (!ladder_insert(L, S, side, idx, price)) return;
         m = (uint64_t)uni64((int64_t)L.meta[side][idx]);
     }

@@ -66,7 +66,7 @@ other = tt - mc
 fo = np.polyfit(ops, other, 1)
 print(f"non-message cycles ~ {fo[0]:.0f} * agent_ops + {fo[1]:.0f}; percentiles 50/99/max {np.percentile(other, [50, 99, 100]).round(0).tolist()}; agent ops mean {ops.mean():.1f} max {ops.max():.0f}")
 ev = np.concatenate(A('ev')); evm = np.array([r['ev_max'] for r in rows])
-evn = ["slab chunks read", "compactions", "ladder inserts+removes", "levels swept by executions", "snapshot-head lookups", "agent ops left to the serial path"]
+evn = ["slab chunks read", "compactions", "ladder inserts+removes", "levels swept by executions", "limits opening a new best", "agent ops left to the serial path"]
 print("events per env-step (whole step: agent ops + messages):")
 for k, n in enumerate(evn): print(f"  {n:28s} mean env {ev[:, k].mean():7.2f}   slowest env {evm[:, k].mean():7.2f}")
 X = np.column_stack([nm, ev[:, 0], ev[:, 1], ev[:, 2], np.ones(len(nm))])
