@@ -860,9 +860,12 @@ def test_stepping_past_the_end_of_the_stream_is_flagged():
 
 
 def test_specialised_default_config_kernels_equal_generic_ones():
-    """The reference's default configuration runs kernels with its constants folded at compile time (Eng<64, true>); the same
-    configuration forced onto the generic 128-level kernels (cfg.ladder_levels = 128) must give every output bit for bit,
-    per step and through the multi-step launch."""
+    """The reference's default configuration runs kernels with its constants folded at compile time (Eng<64, true>, and
+    Eng<128, true> when cfg.ladder_levels = 128); the same configuration through the generic kernels (128 and 64 levels,
+    LOBSIM_GENERIC_KERNELS set while the handle is created) must give every output bit for bit, per step and through the
+    multi-step launch."""
+    import os
+
     import torch
 
     import bench
@@ -870,7 +873,14 @@ def test_specialised_default_config_kernels_equal_generic_ones():
     n, steps = 256, 80
     stream = bench.build_streams("random", 20)[0]
     feats = bench.default_features(_capi)
-    sims = [_lib.new_sim(_capi.make_cfg(n, 10, feats, step_us=100_000, episode_us=1_800_000_000, ladder_levels=lv)) for lv in (0, 128)]
+    sims = []
+    for lv, generic in ((0, False), (128, False), (128, True), (64, True)):
+        if generic:
+            os.environ["LOBSIM_GENERIC_KERNELS"] = "1"
+        try:
+            sims.append(_lib.new_sim(_capi.make_cfg(n, 10, feats, step_us=100_000, episode_us=1_800_000_000, ladder_levels=lv)))
+        finally:
+            os.environ.pop("LOBSIM_GENERIC_KERNELS", None)
     starts, sids = bench.workload_starts("random", n, 1, 5)
     rng = np.random.Generator(np.random.PCG64(6))
     acts = rng.uniform(0, 10, size=(steps, n, 4))
@@ -888,10 +898,12 @@ def test_specialised_default_config_kernels_equal_generic_ones():
         sim.sync()
         rec += [obs.cpu().numpy(), reward.cpu().numpy(), *sim.portfolios()]
         outs.append(rec)
-    for a, b in zip(*outs):
-        assert np.array_equal(a, b)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b)
     assert np.abs(outs[0][-3]).max() > 0
     for e in (0, 100, 255):
-        assert np.array_equal(sims[0].queues(e), sims[1].queues(e))
+        for other in sims[1:]:
+            assert np.array_equal(sims[0].queues(e), other.queues(e))
     for s in sims:
         s.close()
