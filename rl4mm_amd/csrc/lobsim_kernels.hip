@@ -205,6 +205,7 @@ struct Scal {
 #endif
 #ifdef LOBSIM_PROFILE
     uint32_t ev_chunks, ev_compact, ev_ladder, ev_exec_levels, ev_rare, ev_serial_ops;  // event counts (diagnostic build only)
+    uint32_t t_after;  // cycles of a step after its message window (squeeze ahead, stream end, resync, microprice)
     uint32_t ev_x[9];  // serial removals, of them unknown ids, unknown in a queue span <= 4 / <= 64, serial limits, serial markets, segments, batches, -
     uint64_t sub_t[10];                                                   // sub-phase stamps (diagnostic build only)
 #endif
@@ -1399,6 +1400,10 @@ SDI uint64_t batch_cache_entries(const Scal& S, const MsgBatch& b, int64_t until
 // `ce_first` (when have_ce): batch_cache_entries of the first batch, asked for by the caller ahead of time.
 SDI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, int64_t until_us, MsgBatch b, uint64_t ce_first = 0, bool have_ce = false) {
     const int ln = lane();
+#ifdef LOBSIM_PROFILE
+    const uint64_t t_entry = __builtin_amdgcn_s_memtime();
+    bool first_pass = true;
+#endif
     while (!S.status) {
         uint64_t bm = ballot(b.t <= until_us);
         int cnt = popc64(bm);  // the stream is time-sorted: the in-window lanes are a prefix
@@ -1430,6 +1435,7 @@ SDI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, 
                 EVENT(ev_x[6]);
 #ifdef LOBSIM_PROFILE
                 const uint64_t ts0 = __builtin_amdgcn_s_memtime();
+                if (first_pass) { S.ev_x[8] += (uint32_t)(ts0 - t_entry); first_pass = false; }  // cycles from the top of the window to its first pass
 #endif
                 applied |= append_segment(L, S, b, j, cnt, seg_end, li_memo, memo_ver, ce_batch);
 #ifdef LOBSIM_PROFILE
@@ -2006,7 +2012,7 @@ SDI void run_agent_ops(Lds& L, Scal& S, const DevCfg& C) {
 #endif
             process_op(L, S, C, L.ops[k]);
 #ifdef LOBSIM_PROFILE
-            S.ev_x[8] += (uint32_t)(__builtin_amdgcn_s_memtime() - t0);  // cycles in serially replayed agent ops
+            (void)t0;
 #endif
         }
     } else {
@@ -2023,6 +2029,10 @@ SDI void advance_one_step(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, in
     if (stream_id >= 0 && !S.status) replay_messages(L, S, P.streams[stream_id], cursor, until, first, ce_first, have_ce);
     now_us = until;
     if (S.status) return;
+#ifdef LOBSIM_PROFILE
+    const uint64_t t_after0 = __builtin_amdgcn_s_memtime();
+    struct After { Scal& S; uint64_t t0; __device__ ~After() { S.t_after += (uint32_t)(__builtin_amdgcn_s_memtime() - t0); } } after_guard{S, t_after0};
+#endif
 #if LOBSIM_TOMB_AHEAD
     if (S.ahead && S.msgs_step <= LOBSIM_LIGHT_MSGS) squeeze_ahead(L, S);
     S.msgs_step = 0;
@@ -2079,6 +2089,7 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
 #ifdef LOBSIM_PROFILE
     S.ev_chunks = S.ev_compact = S.ev_ladder = S.ev_exec_levels = S.ev_rare = S.ev_serial_ops = 0;
     for (int k = 0; k < 9; k++) S.ev_x[k] = 0;
+    S.t_after = 0;
     for (int k = 0; k < 10; k++) S.sub_t[k] = 0;
 #endif
 #ifdef LOBSIM_PROFILE_MSG
@@ -2229,6 +2240,7 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
 #ifndef LOBSIM_PROFILE_MSG
         ev[0] += S.ev_chunks; ev[1] += S.ev_compact; ev[2] += S.ev_ladder; ev[3] += S.ev_exec_levels; ev[4] += S.ev_rare; ev[5] += S.ev_serial_ops;
         for (int k = 0; k < 9; k++) ev[6 + k] += S.ev_x[k];
+        ev[15] += S.t_after;
 #else
         uint64_t* pm = P.prof + (size_t)gridDim.x * 8 + (size_t)env * 16;
         for (int k = 0; k < 8; k++) { pm[k] += S.pm_cycles[k]; pm[8 + k] += S.pm_count[k]; }  // (in the place of the event counts)

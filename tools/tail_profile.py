@@ -46,11 +46,11 @@ for t in range(K):
     order = np.argsort(tot)
     i = order[-1]
     rows.append(dict(max=tot[i], mean=tot.mean(), p50=np.median(tot), p99=np.percentile(tot, 99), p999=np.percentile(tot, 99.9), ph_max=ph[i], ph_mean=ph.mean(axis=0), n_max=nmsg[i], n_mean=nmsg.mean(), n_top=nmsg.max(),
-                     cpm=ph[:, 3] / np.maximum(nmsg, 1), nmsg=nmsg.copy(), msgc=ph[:, 3].copy(), tot=tot.copy(), sec=sec_cross.copy(), ops=out[:, 6].astype(float), ev=evb[:, :6].astype(float), ev_max=evb[i, :6].astype(float), sub=evb[:, 6:15].astype(float).mean(axis=0), sub_max=evb[i, 6:15].astype(float)))
+                     cpm=ph[:, 3] / np.maximum(nmsg, 1), nmsg=nmsg.copy(), msgc=ph[:, 3].copy(), tot=tot.copy(), sec=sec_cross.copy(), ops=out[:, 6].astype(float), ev=evb[:, :6].astype(float), ev_max=evb[i, :6].astype(float), sub=evb[:, 6:16].astype(float).mean(axis=0), sub_max=evb[i, 6:16].astype(float)))
 if "rows" in sys.argv:  # the slowest env of each launch, one line per launch
-    print("slowest env per launch: total | load build agent msgs feat out | n_msgs | chunks compactions ladder_ops swept_levels rare serial_agent_ops | ser_rem unknown cyc_parallel cyc_serial_msgs ser_lim ser_mkt segments cyc_runs cyc_agent_serial")
+    print("slowest env per launch: total | load build agent msgs feat out | n_msgs | chunks compactions ladder_ops swept_levels rare serial_agent_ops | ser_rem unknown cyc_parallel cyc_serial_msgs ser_lim ser_mkt segments cyc_runs cyc_to_first_pass cyc_after_window")
     for r in rows[:40]:
-        print("%6d | %s | %2d | %s | %s" % (r["max"], " ".join("%5d" % x for x in r["ph_max"]), r["n_max"], " ".join("%2d" % x for x in r["ev_max"]), " ".join("%2d" % x if k not in (2, 3, 7, 8) else "%5d" % x for k, x in enumerate(r["sub_max"][:9]))))
+        print("%6d | %s | %2d | %s | %s" % (r["max"], " ".join("%5d" % x for x in r["ph_max"]), r["n_max"], " ".join("%2d" % x for x in r["ev_max"]), " ".join("%2d" % x if k not in (2, 3, 7, 8, 9) else "%5d" % x for k, x in enumerate(r["sub_max"][:10]))))
 A = lambda k: np.array([r[k] for r in rows])
 print(f"{N} envs, {len(rows)} launches: wave cycles  mean {A('mean').mean():.0f}  p50 {A('p50').mean():.0f}  p99 {A('p99').mean():.0f}  p99.9 {A('p999').mean():.0f}  MAX {A('max').mean():.0f}")
 print(f"messages in the slowest env {A('n_max').mean():.1f} (mean env {A('n_mean').mean():.1f}, busiest env {A('n_top').mean():.1f})")
@@ -74,8 +74,8 @@ coef = np.linalg.lstsq(X, mc, rcond=None)[0]
 print("message-phase cycles ~ " + " + ".join(f"{c:.0f}*{n}" for c, n in zip(coef, ["msgs", "chunks", "compactions", "ladder_ops", "1"])))
 sub = np.array([r["sub"] for r in rows]).mean(axis=0)
 subm = np.array([r["sub_max"] for r in rows]).mean(axis=0)
-print("slowest env of a launch: serial removals %.2f, unknown ids %.2f (cycles in lane-parallel passes %.0f, in single serial messages %.0f), serial limits %.2f, serial markets %.2f, segments %.2f, cycles in execution runs %.0f, in serial agent ops %.0f" % tuple(subm[:9]))
-print("per env-step (mean env): serial removals %.2f, of them unknown ids %.2f (cycles in lane-parallel passes %.0f, in single serial messages %.0f); serial limit messages %.2f, serial market messages %.2f; segments %.2f; cycles in execution runs %.0f, in serial agent ops %.0f" % tuple(sub[:9]))
+print("slowest env of a launch: serial removals %.2f, unknown ids %.2f (cycles in lane-parallel passes %.0f, in single serial messages %.0f), serial limits %.2f, serial markets %.2f, segments %.2f, cycles in execution runs %.0f, from the top of the window to its first pass %.0f, after the window %.0f" % tuple(subm[:10]))
+print("per env-step (mean env): serial removals %.2f, of them unknown ids %.2f (cycles in lane-parallel passes %.0f, in single serial messages %.0f); serial limit messages %.2f, serial market messages %.2f; segments %.2f; cycles in execution runs %.0f, from the top of the window to its first pass %.0f, after the window %.0f" % tuple(sub[:10]))
 print("op-list generation sub-phases (mean env cycles): pdf %.0f | normalise+round %.0f | inventory/best prices %.0f | agent entries -> levels %.0f | diff publish %.0f... candidates %.0f | op list %.0f" % tuple(sub[:7][[0, 1, 2, 3, 4, 4, 5]]) if False else "op-list sub-phases (mean env cycles): " + ", ".join(f"{x:.0f}" for x in sub[:6]) + f"; feature state load {sub[7]:.0f}, make_view {sub[8]:.0f}")
 if "msg" not in sys.argv: sys.exit(0)
 pmsg = np.zeros((N, 16), dtype=np.uint64)
