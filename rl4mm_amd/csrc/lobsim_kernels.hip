@@ -2023,7 +2023,8 @@ SDI void run_agent_ops(Lds& L, Scal& S, const DevCfg& C) {
 // OrderbookSimulator.forward_step (:70-88) + update_internal_state (HistoricalOrderbookEnvironment.py:199-204):
 // agent ops first, then the message window, clock, resync check, new price.
 SDI void advance_one_step(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, int stream_id, int64_t& cursor, int64_t& now_us,
-                         Ranges& R, int& n_resyncs, double& price, bool with_ops, const MsgBatch& first, int64_t n_msgs, uint64_t ce_first = 0, bool have_ce = false) {
+                         Ranges& R, int& n_resyncs, double& price, bool with_ops, const MsgBatch& first, int64_t n_msgs, uint64_t ce_first = 0, bool have_ce = false,
+                         EnvHdr* lazy = nullptr) {
     if (with_ops) run_agent_ops(L, S, C);
     int64_t until = now_us + CFG_STEP_US(C);
     if (stream_id >= 0 && !S.status) replay_messages(L, S, P.streams[stream_id], cursor, until, first, ce_first, have_ce);
@@ -2044,8 +2045,20 @@ SDI void advance_one_step(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, in
         if (cursor >= n_msgs && until / 1000000 - st.first_sec >= st.n_secs) { S.status |= LOBSIM_ST_STREAM_END; return; }
     }
     if (stream_id >= 0 && now_us % 1000000 == 0) {
+        // (`lazy`, the step kernel: the price ranges and the resync count are read from the header here, once a second, and
+        // written back at once.  Carried through the whole step in scalar registers, those ten registers pushed the
+        // allocator over a cliff: 1009 instead of 417 spill reloads in the kernel, +24 % VALU instructions per step.)
+        if (lazy) {
+            R.min_buy = rld(lazy->min_buy, 0); R.max_sell = rld(lazy->max_sell, 0);
+            R.init_buy = rld(lazy->init_buy_range, 0); R.init_sell = rld(lazy->init_sell_range, 0);
+            n_resyncs = uni(lazy->n_resyncs);
+        }
         bool near = best_buy_d(L, S) < R.min_buy + C.outer_prop * R.init_buy || best_sell_d(L, S) > R.max_sell - C.outer_prop * R.init_sell;
-        if (near) { n_resyncs++; resync_outer_levels(L, S, C, P.streams[stream_id], now_us, R); }
+        if (near) {
+            n_resyncs++;
+            resync_outer_levels(L, S, C, P.streams[stream_id], now_us, R);
+            if (lazy && lane() == 0) { lazy->min_buy = R.min_buy; lazy->max_sell = R.max_sell; lazy->n_resyncs = n_resyncs; }
+        }
     }
     if (S.status) return;
     if (!microprice(L, S, price)) S.status |= LOBSIM_ST_EMPTY_BOOK;
@@ -2104,8 +2117,8 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
     int64_t now = H.now_us, cursor = H.msg_cursor;
     const int stream_id = H.stream_id;
     const int64_t terminal_us = H.terminal_us;
-    Ranges R = {H.min_buy, H.max_sell, H.init_buy_range, H.init_sell_range};
-    int n_resyncs = H.n_resyncs;
+    Ranges R = {0.0, 0.0, 0.0, 0.0};  // (read where they are needed: advance_one_step, `lazy`)
+    int n_resyncs = 0;
     double price = H.price;
     Act5 act;
     if (A.policy == LOBSIM_POLICY_GIVEN) {
@@ -2117,6 +2130,7 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
     } else {  // Teradactyl on the observation's inventory entry = that feature's current value
         act = teradactyl_action(A.params, P.feat[(size_t)env * LOBSIM_MAX_FEATURES + (int)A.params[5]].current_value);
     }
+    const bool last_step = 2 * (terminal_us - (now + CFG_STEP_US(C))) < CFG_STEP_US(C);  // terminal_time - now < step_size / 2 (:172-174), as of the end of this step
     const BetaLogs bl = beta_logs(C);  // first in the queue: the Beta volumes are computed while the rest travels
     const StreamDev& st0 = P.streams[stream_id >= 0 ? stream_id : 0];  // (a handle has >= 1 stream once reset)
     const int64_t* msgs0 = st0.msgs;
@@ -2165,9 +2179,9 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
 #ifdef LOBSIM_PROFILE
         if (!S.status) run_agent_ops(L, S, C);
         STAMP(3);
-        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, false, first, n_msgs0, ce_first, have_ce);
+        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, false, first, n_msgs0, ce_first, have_ce, &H);
 #else
-        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true, first, n_msgs0, ce_first, have_ce);
+        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true, first, n_msgs0, ce_first, have_ce, &H);
 #endif
         STAMP(4);
         SUBSTAMP(7);
@@ -2201,7 +2215,7 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
         }
         if (!S.status) {
             reward = step_reward<EXTRAS>(L, S, C, P, env, false, inv0, cash0, p0, price);
-            if (2 * (terminal_us - now) < CFG_STEP_US(C)) {  // terminal_time - now < step_size / 2 (:172-174)
+            if (last_step) {
                 reward = step_reward<EXTRAS>(L, S, C, P, env, true, inv0, cash0, p0, price);
                 done = 1;
             }
@@ -2226,8 +2240,7 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
     if (A.info && !entry_status && !S.status) write_info(L, S, C, H, act, price, A.info + (size_t)env * LOBSIM_INFO_DIM);
     store_env(L, S, P, env, H, !book_stored, true);
     if (ln == 0) {
-        H.now_us = now; H.msg_cursor = cursor; H.price = price; H.n_resyncs = n_resyncs;
-        H.min_buy = R.min_buy; H.max_sell = R.max_sell;
+        H.now_us = now; H.msg_cursor = cursor; H.price = price;
         H.prev_action[0] = act.v0; H.prev_action[1] = act.v1; H.prev_action[2] = act.v2; H.prev_action[3] = act.v3; H.prev_action[4] = act.v4;
     }
 #ifdef LOBSIM_PROFILE
