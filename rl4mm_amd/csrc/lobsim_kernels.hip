@@ -152,6 +152,7 @@ struct Lds {
     // the feature phase (one HBM round trip less at the end of the step)
     int64_t rstash[LOBSIM_MAX_FEATURES][2];
     int32_t info_q[4];  // SimpleInfoCalculator: first quoted level and volume-weighted level sum per side of this step's action
+    double act[LOBSIM_MAX_ACTION_DIM];  // rollout kernel: the step's action, needed again only by the trace and at the end of the launch
     // Wave-uniform state that is touched rarely (a level opens or empties, the agent trades, an execution is counted).
     // It lives here and not in scalar registers: the replay loop would otherwise carry ~35 SGPRs through every one of
     // its merge points (copies and spills on the scalar unit, which is what bounds this kernel at 16 waves per CU).
@@ -2313,9 +2314,10 @@ SDI void rollout_body(const DevCfg& C, const DevPtrs& P, const RolloutArgs& A) {
     const int64_t n_msgs_all = st0.n_msgs;
     const int64_t* msgs_all = st0.msgs;
     const int64_t terminal_us = H.terminal_us;
-    Ranges R = {H.min_buy, H.max_sell, H.init_buy_range, H.init_sell_range};
-    int n_resyncs = H.n_resyncs;
+    Ranges R = {0.0, 0.0, 0.0, 0.0};  // (the ranges and the resync count stay in the header: advance_one_step, `lazy`)
+    int n_resyncs = 0;
     double price = H.price, reward = 0.0, ret = 0.0;
+    if (ln < LOBSIM_MAX_ACTION_DIM) L.act[ln] = H.prev_action[ln];  // (what the observation's tail shows if no step is taken)
     int done = S.status ? 1 : 0, steps = 0;
     Act5 act;
     act.v0 = H.prev_action[0]; act.v1 = H.prev_action[1]; act.v2 = H.prev_action[2]; act.v3 = H.prev_action[3]; act.v4 = H.prev_action[4];
@@ -2337,7 +2339,8 @@ SDI void rollout_body(const DevCfg& C, const DevPtrs& P, const RolloutArgs& A) {
         if (stream_id < 0) first.t = INT64_MAX;
         const bool want_info = A.info != nullptr || A.trace != nullptr;
         build_agent_ops(L, S, C, act, want_info);
-        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true, first, n_msgs_all);
+        if (ln == 0) { L.act[0] = act.v0; L.act[1] = act.v1; L.act[2] = act.v2; L.act[3] = act.v3; L.act[4] = act.v4; }
+        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true, first, n_msgs_all, 0, false, &H);
         if (!S.status) {
             StepView v = make_view(L, S, price, now);
             bool ok = true;
@@ -2360,7 +2363,8 @@ SDI void rollout_body(const DevCfg& C, const DevPtrs& P, const RolloutArgs& A) {
         ret += reward;
         steps++;
         if (want_info && !S.status) {
-            write_info(L, S, C, H, act, price, A.info ? A.info + (size_t)env * LOBSIM_INFO_DIM : nullptr);
+            Act5 a5; a5.v0 = L.act[0]; a5.v1 = L.act[1]; a5.v2 = L.act[2]; a5.v3 = L.act[3]; a5.v4 = L.act[4];
+            write_info(L, S, C, H, a5, price, A.info ? A.info + (size_t)env * LOBSIM_INFO_DIM : nullptr);
             if (A.trace && ln == 0) {  // the series get_episode_summary_dict reads (rl4mm/gym/utils.py:145-198)
                 double* tr = A.trace + ((size_t)t * N + env) * LOBSIM_TRACE_DIM;
                 const int64_t inv = L.inv, cash = L.cash;
@@ -2368,14 +2372,14 @@ SDI void rollout_body(const DevCfg& C, const DevPtrs& P, const RolloutArgs& A) {
                 tr[LOBSIM_TRACE_ASSET_PRICE] = price;
                 tr[LOBSIM_TRACE_MARKET_SPREAD] = (S.n_lv[1] ? (double)L.price[1][0] : (double)INFINITY) - (S.n_lv[0] ? (double)L.price[0][0] : 0.0);
                 tr[LOBSIM_TRACE_WEIGHTED_MIDPRICE_OFFSET] = ((double)L.info_q[3] / 100.0 - (double)L.info_q[2] / 100.0) / 2;
-                tr[LOBSIM_TRACE_ACTION] = act.v0; tr[LOBSIM_TRACE_ACTION + 1] = act.v1; tr[LOBSIM_TRACE_ACTION + 2] = act.v2;
-                tr[LOBSIM_TRACE_ACTION + 3] = act.v3; tr[LOBSIM_TRACE_ACTION + 4] = act.v4;
+                tr[LOBSIM_TRACE_ACTION] = L.act[0]; tr[LOBSIM_TRACE_ACTION + 1] = L.act[1]; tr[LOBSIM_TRACE_ACTION + 2] = L.act[2];
+                tr[LOBSIM_TRACE_ACTION + 3] = L.act[3]; tr[LOBSIM_TRACE_ACTION + 4] = L.act[4];
             }
         }
     }
     double val = 0.0;
     if (ln < F) val = fval;
-    else if (ln < D) val = act_at(act, ln - F);
+    else if (ln < D) val = L.act[ln - F];
     if (ln < D) {
         if (A.obs) A.obs[(size_t)env * D + ln] = val;
         if (A.obs_f32) A.obs_f32[(size_t)env * D + ln] = (float)val;
@@ -2387,9 +2391,8 @@ SDI void rollout_body(const DevCfg& C, const DevPtrs& P, const RolloutArgs& A) {
     }
     store_env(L, S, P, env, H);
     if (ln == 0) {
-        H.now_us = now; H.msg_cursor = cursor; H.price = price; H.n_resyncs = n_resyncs;
-        H.min_buy = R.min_buy; H.max_sell = R.max_sell;
-        H.prev_action[0] = act.v0; H.prev_action[1] = act.v1; H.prev_action[2] = act.v2; H.prev_action[3] = act.v3; H.prev_action[4] = act.v4;
+        H.now_us = now; H.msg_cursor = cursor; H.price = price;
+        H.prev_action[0] = L.act[0]; H.prev_action[1] = L.act[1]; H.prev_action[2] = L.act[2]; H.prev_action[3] = L.act[3]; H.prev_action[4] = L.act[4];
     }
 }
 
