@@ -18,6 +18,7 @@ are independent, the stream is replicated), the only collective is the episode-r
 Inputs (actions, stream, env state) are resident in HBM when the timed region starts.  Prints ONE JSON line.
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -344,6 +345,8 @@ def main():
         ev.record()  # a dry run: the very first timed event record of a process takes ~50 us on the host (lazy set-up of the
                      # profiling signals) - as much as 1.5 steps of a 20-step region - and none afterwards
     torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()  # (a cyclic collection inside a 0.7 ms region would be a third of it)
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -354,6 +357,7 @@ def main():
     ev_all[1].record()
     torch.cuda.synchronize()
     local_elapsed = time.perf_counter() - t0
+    gc.enable()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
