@@ -6,4 +6,4 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; shift
 mkdir -p $ROOT/build/variants
 cd $ROOT/rl4mm_amd/csrc
-hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -std=c++17 -mllvm -amdgpu-atomic-optimizer-strategy=None "$@" -o $ROOT/build/variants/$NAME.so lobsim_kernels.hip
+hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -std=c++17 -mllvm -amdgpu-atomic-optimizer-strategy=None -mllvm -amdgpu-sched-strategy=max-ilp "$@" -o $ROOT/build/variants/$NAME.so lobsim_kernels.hip
