@@ -603,6 +603,8 @@ def test_argument_validation_and_status_flags():
     corrupting the book (the reference has no such limit: the flag is how the difference shows)."""
     cfg = _small_cfg(2, 8)
     sim = _lib.new_sim(cfg)
+    obs, rew, done = sim.step(np.ones((2, 4)))  # no stream at all yet: the kernel's unconditional batch read must find valid memory
+    assert done.all() and sim.env_state(1)["status"] & _capi.ST_NOT_RESET
     with pytest.raises(_capi.LobsimError):
         sim.reset(np.array([36_000_000_500, 36_000_000_000]), 0)  # not on the second / unknown stream
     sim.add_stream(ol.golden_stream("synth_small").__class__("SYN", "2018-02-21", 8, np.zeros((0, 4), np.int64), np.zeros((0, 34), np.int64)))
