@@ -1021,6 +1021,21 @@ SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, b
     build_agent_ops(L, S, C, action, beta_volumes(L, C, action, beta_logs(C)), want_info);
 }
 
+// index of the r-th (0-based) set bit of a 32-bit word that has more than r set bits: five halvings, no loop over the bits
+SDI int nth_set_bit32(uint32_t x, int r) {
+    int base = 0;
+#pragma unroll
+    for (int sh = 16; sh; sh >>= 1) {
+        const uint32_t low = x & ((1u << sh) - 1);
+        const int c = __popc(low);
+        const bool up = r >= c;
+        r -= up ? c : 0;
+        base += up ? sh : 0;
+        x = up ? (x >> sh) : low;
+    }
+    return base;
+}
+
 SDI int lane_find_level(const Lds& L, int side, int n, int64_t price) {
     int lo = 0, hi = n;
     while (lo < hi) {
@@ -1066,10 +1081,12 @@ SDI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
     if (R > popc64(free0) + popc64(free1)) { lim_ok = false; lim_mask = 0; R = 0; }  // sequential path reports the overflow
     if (lim_ok) {
         int r = popc64(lim_mask & below);  // my rank among the appenders -> the r-th free agent entry
-        uint64_t w0 = free0, w1 = free1;
-        int c0 = popc64(w0), aidx;
-        if (r < c0) { for (int t = 0; t < r; t++) w0 &= w0 - 1; aidx = ffs64(w0); }
-        else { r -= c0; for (int t = 0; t < r; t++) w1 &= w1 - 1; aidx = 64 + ffs64(w1); }
+        // (the r-th set bit of the 128-bit free mask, by popcounts - a loop clearing r bits ran up to 20 turns per lane)
+        const uint32_t q0 = (uint32_t)free0, q1 = (uint32_t)(free0 >> 32), q2 = (uint32_t)free1, q3 = (uint32_t)(free1 >> 32);
+        const int c0 = __popc(q0), c1 = c0 + __popc(q1), c2 = c1 + __popc(q2);
+        const int word = (r >= c0) + (r >= c1) + (r >= c2);
+        const uint32_t qw = word == 0 ? q0 : word == 1 ? q1 : word == 2 ? q2 : q3;
+        const int aidx = 32 * word + nth_set_bit32(qw, r - (word == 0 ? 0 : word == 1 ? c0 : word == 2 ? c1 : c2));
         const int tail = m_tail(m), live = m_live(m);
         Slot w; w.id = aidx; w.vol = op.vol; w.kind = K_AGENT;
         sl[tail] = w;
@@ -1079,11 +1096,9 @@ SDI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
         o.seq_side = ((seq0 + (uint32_t)popc64(lim_mask & below)) & 0x7fffffffu) | ((uint32_t)side << 31);
         L.agent[aidx] = o;
         L.apos[aidx] = (uint16_t)tail;
+        atomicAnd(&L.agent_free[aidx >> 6], ~(1ull << (aidx & 63)));  // the entry is taken (every lane clears its own bit: no scalar loop over them)
     }
-    for (int t = 0; t < R; t++) {  // the R lowest free entries are now taken
-        if (free0) free0 &= free0 - 1; else free1 &= free1 - 1;
-    }
-    if (ln == 0 && R) { L.agent_free[0] = free0; L.agent_free[1] = free1; L.agent_seq = seq0 + (uint32_t)R; }
+    if (ln == 0 && R) L.agent_seq = seq0 + (uint32_t)R;
     // ---- cancellations: straight to the recorded slot
     bool can_ok = is_cancel && li >= 0;
     const int pos = can_ok ? L.apos[idx] : 0;
@@ -1444,7 +1459,13 @@ SDI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, 
 #endif
                 classified = seg_end + 1;  // the message at seg_end goes through the general routine as it is
             }
-            if ((applied >> j) & 1) continue;
+            {   // straight to the next classified message the pass has not booked (most are: no turn of the loop for those)
+                const int hi = classified < cnt ? classified : cnt;
+                const uint64_t range = (hi >= 64 ? ~0ull : (1ull << hi) - 1) & ~((1ull << j) - 1);
+                const uint64_t todo = ~applied & range;
+                if (!todo) { j = hi - 1; continue; }
+                j = ffs64(todo);
+            }
             int64_t mm = rl64(b.meta, j);
             if ((int)((mm >> LOBSIM_TYPE_SHIFT) & 0xf) == LOBSIM_MARKET) {
                 // A marketable order arrives as a run of execution messages, one per resting order it consumed; the
