@@ -461,27 +461,25 @@ SDI void level_append(Lds& L, Scal& S, int side, int idx, int64_t id, int32_t vo
 #endif
 SDI void squeeze_ahead(Lds& L, Scal& S) {
     const int ln = lane();
-    int best = 0;  // tombstones << 8 | side << 7 | index, of this lane's worst level
+    // the first level found with LOBSIM_TOMB_AHEAD tombstones or a nearly full slab (which one does not matter: one ballot
+    // per ladder half instead of a wave-wide maximum, which cost six cross-lane moves in every short window)
+    int side = -1, idx = 0;
 #pragma unroll
-    for (int side = 0; side < 2; side++)
+    for (int sd = 0; sd < 2; sd++)
 #pragma unroll
         for (int r = 0; r < HALVES; r++) {
             const int i = ln + 64 * r;
-            if (i < S.n_lv[side]) {
-                const uint64_t m = L.meta[side][i];
-                int t = m_tail(m) - m_head(m) - m_live(m);
-                if (m_tail(m) > SLOTS - 2 * WAVE) t = LOBSIM_TOMB;  // nearly full
-                if (t >= LOBSIM_TOMB_AHEAD) best = max(best, (t << 8) | (side << 7) | i);
+            bool due = false;
+            if (i < S.n_lv[sd]) {
+                const uint64_t m = L.meta[sd][i];
+                const int t = m_tail(m) - m_head(m) - m_live(m);
+                due = t >= LOBSIM_TOMB_AHEAD || (t > 0 && m_tail(m) > SLOTS - 2 * WAVE);
             }
+            const uint64_t b = ballot(due);
+            if (b && side < 0) { side = sd; idx = 64 * r + ffs64(b); }
         }
-    if (!ballot(best != 0)) return;
-    int w = best;  // wave maximum
-#pragma unroll
-    for (int o = 32; o; o >>= 1) w = max(w, __shfl_xor(w, o));
-    w = uni(w);
-    const int side = (w >> 7) & 1, idx = w & 127;
+    if (side < 0) return;
     const uint64_t m = (uint64_t)uni64((int64_t)L.meta[side][idx]);
-    if (m_tail(m) - m_head(m) == m_live(m)) return;  // (nearly full but without a tombstone: nothing to gain)
     const uint64_t nm = compact_level(L, S, side, idx, m);
     if (ln == 0) L.meta[side][idx] = nm;
     wsync();
