@@ -1775,9 +1775,12 @@ SDI bool feature_reset(const lobsim_feature& d, FeatState& f, int64_t* ring, con
 }
 
 template <bool EXTRAS>
-SDI bool feature_update(const lobsim_feature& d, FeatState& f, int64_t* ring, const StepView& v, double* hist, bool have_pre = false, int64_t pre0 = 0, int64_t pre1 = 0) {  // update, :80-86
+SDI bool feature_update(const lobsim_feature& d, FeatState& f, int64_t* ring, const StepView& v, double* hist, bool have_pre = false, int64_t pre0 = 0, int64_t pre1 = 0,
+                        bool* touched = nullptr) {  // update, :80-86.  *touched: the feature's state changed (else it need not be written back)
+    if (touched) *touched = false;
     if (v.now_us < f.first_usage_us) return true;
     if (d.update_us <= 0xffffffffll ? (v.now_mod_min % (uint32_t)d.update_us != 0) : ((int64_t)v.now_mod_min % d.update_us != 0)) return true;  // _now_is_multiple_of_update_freq
+    if (touched) *touched = true;
     if (!feature_raw(d, f, ring, v, have_pre, pre0, pre1)) return false;
     f.current_value = clampd(f.current_value, d.min_value, d.max_value);
     if constexpr (EXTRAS)
@@ -1971,7 +1974,9 @@ SDI void load_env(Lds& L, Scal& S, const DevPtrs& P, int env, const EnvHdr& H) {
 
 // The book (ladder, agent orders, free masks) and the rest of the header can be written back separately: the step kernel
 // writes the book as soon as the message window is replayed, so that those stores travel while the features are computed.
-SDI void store_env(const Lds& L, const Scal& S, const DevPtrs& P, int env, EnvHdr& H, bool book = true, bool rest = true) {
+// `prices`: false when no level was opened or removed since the ladder was loaded (S.ladder_ver == 0) - the price array in HBM
+// is then what it was, a third of the ladder's write-back.
+SDI void store_env(const Lds& L, const Scal& S, const DevPtrs& P, int env, EnvHdr& H, bool book = true, bool rest = true, bool prices = true) {
     int ln = lane();
     wsync();
     if (book) {
@@ -1979,7 +1984,8 @@ SDI void store_env(const Lds& L, const Scal& S, const DevPtrs& P, int env, EnvHd
 #pragma unroll
     for (int s = 0; s < 2; s++)
         for (int i = ln; i < S.n_lv[s]; i += 64) {
-            G.price[s][i] = L.price[s][i]; G.meta[s][i] = L.meta[s][i]; G.vol[s][i] = L.vol[s][i];
+            if (prices) G.price[s][i] = L.price[s][i];
+            G.meta[s][i] = L.meta[s][i]; G.vol[s][i] = L.vol[s][i];
         }
     AgentOrd* A = P.agent + (size_t)env * NA;
     uint16_t* AP = P.apos + (size_t)env * NA;
@@ -2188,6 +2194,7 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
     double reward = 0.0;
     int done = 0;
     FeatState fs = FeatState();
+    bool fs_touched = false;
     const int entry_status = S.status;
     bool book_stored = false;
     if (!S.status) {
@@ -2216,7 +2223,7 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
             dsc.dparam = g.dparam; dsc.iparam = g.iparam; dsc.norm_len = g.norm_len;
         }
 #if LOBSIM_EARLY_BOOK_STORE
-        store_env(L, S, P, env, H, true, false);  // the book is final: its stores travel while the features are computed
+        store_env(L, S, P, env, H, true, false, S.ladder_ver != 0);  // the book is final: its stores travel while the features are computed
         book_stored = true;
 #endif
         // (pinned here, or the compiler sinks each load back into the branch that uses it)
@@ -2227,9 +2234,9 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
             SUBSTAMP(9);
             bool ok = true;
 #if LOBSIM_FEAT_PF
-            if (ln < F) ok = feature_update<EXTRAS>(dsc, fs, P.rings + (size_t)env * C.ring_words + froff, v, norm_history(C, P, env, ln), true, L.rstash[ln][0], L.rstash[ln][1]);
+            if (ln < F) ok = feature_update<EXTRAS>(dsc, fs, P.rings + (size_t)env * C.ring_words + froff, v, norm_history(C, P, env, ln), true, L.rstash[ln][0], L.rstash[ln][1], &fs_touched);
 #else
-            if (ln < F) ok = feature_update<EXTRAS>(C.c.features[ln], fs, P.rings + (size_t)env * C.ring_words + C.ring_off[ln], v, norm_history(C, P, env, ln));
+            if (ln < F) ok = feature_update<EXTRAS>(C.c.features[ln], fs, P.rings + (size_t)env * C.ring_words + C.ring_off[ln], v, norm_history(C, P, env, ln), false, 0, 0, &fs_touched);
 #endif
             if (ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
         }
@@ -2256,9 +2263,9 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
         if (A.return_acc) A.return_acc[env] += reward;
         if (A.steps_taken) A.steps_taken[env] = entry_status ? 0 : 1;
     }
-    if (ln < F) P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln] = fs;
+    if (ln < F && fs_touched) P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln] = fs;  // (a feature on a slower clock than the step - one update a second - is written back once a second)
     if (A.info && !entry_status && !S.status) write_info(L, S, C, H, act, price, A.info + (size_t)env * LOBSIM_INFO_DIM);
-    store_env(L, S, P, env, H, !book_stored, true);
+    store_env(L, S, P, env, H, !book_stored, true, S.ladder_ver != 0 || entry_status != 0);
     if (ln == 0) {
         H.now_us = now; H.msg_cursor = cursor; H.price = price;
         H.prev_action[0] = act.v0; H.prev_action[1] = act.v1; H.prev_action[2] = act.v2; H.prev_action[3] = act.v3; H.prev_action[4] = act.v4;
