@@ -451,13 +451,13 @@ SDI void level_append(Lds& L, Scal& S, int side, int idx, int64_t id, int32_t vo
 
 // Squeezes are due when a level holds LOBSIM_TOMB tombstones, whichever step that happens in - and a launch lasts as long
 // as its slowest env, which is slow because its window is long.  So an env whose window was SHORT squeezes ahead of time:
-// the level with the most tombstones, if it has at least LOBSIM_TOMB_AHEAD of them (or its slab is nearly full).  A squeeze
+// a level that has at least LOBSIM_TOMB_AHEAD of them (or whose slab is nearly full).  A squeeze
 // only moves slots inside a slab (FIFO order kept, position caches updated), so when it happens is unobservable.
 #ifndef LOBSIM_TOMB_AHEAD
-#define LOBSIM_TOMB_AHEAD 64
+#define LOBSIM_TOMB_AHEAD 96
 #endif
 #ifndef LOBSIM_LIGHT_MSGS
-#define LOBSIM_LIGHT_MSGS 20
+#define LOBSIM_LIGHT_MSGS 24
 #endif
 SDI void squeeze_ahead(Lds& L, Scal& S) {
     const int ln = lane();
