@@ -178,7 +178,7 @@ def _short_features():
     ]  # fmt: skip
 
 
-@pytest.mark.parametrize("variant", ["plain", "ad_spread_prev", "moc"])
+@pytest.mark.parametrize("variant", ["plain", "ad_spread_prev", "moc", "wide"])
 def test_batch_against_oracle(variant):
     """256 envs with different start seconds and random Beta-policy actions, stepped 150 times and through two
     episode resets, against the oracle on the same inputs.  Integers bit-exact per env per step."""
@@ -188,6 +188,8 @@ def test_batch_against_oracle(variant):
         kw.update(enter_spread=True, inc_prev_action_in_obs=True, per_step_reward=(_capi.R_INVENTORY_ADJUSTED, 1, 0.1), terminal_reward=(_capi.R_INVENTORY_ADJUSTED, 0, 0.1))
     if variant == "moc":
         kw.update(market_order_clearing=True, market_order_fraction_of_inventory=1.0, min_quote_level=1, max_quote_level=8)
+    if variant == "wide":  # 20 quote levels per side: 40-80 live agent orders per env (agent entries beyond the first 64, free-entry
+        kw.update(max_quote_level=20)  # selection across the words of the mask), quotes far beyond the ten visible levels
     cfg = _capi.make_cfg(n, 10, _short_features(), **kw)
     stream = ol.golden_stream("synth_small")
     gpu, cpu = _lib.new_sim(cfg), ol.oracle_sim(cfg)
@@ -218,6 +220,8 @@ def test_batch_against_oracle(variant):
             starts[ids] += 11_000_000
             o1, o2 = gpu.reset(starts[ids], 0, ids), cpu.reset(starts[ids], 0, ids)
             assert np.allclose(o1, o2, rtol=RTOL, atol=ATOL)
+    if variant == "wide":
+        assert max(gpu.env_state(e)["n_agent_orders"] for e in range(0, n, 16)) > 64
     for e in (0, 17, 101, 255):
         assert np.array_equal(gpu.queues(e), cpu.queues(e)), f"env {e}: per-order book contents differ"
         sg, sc = gpu.env_state(e), cpu.env_state(e)
