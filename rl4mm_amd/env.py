@@ -579,7 +579,19 @@ class HistoricalOrderbookEnvironment:
             raise EmptyOrderbookError("Trying take liquidity from empty side of the book.")
         if status & _capi.ST_ASSERT:
             raise AssertionError("Order volume must be positive.")
-        raise RuntimeError(f"env stopped with status {status} (see include/lobsim.h: enum lobsim_status)")
+        hints = []
+        if status & _capi.ST_LEVEL_OVERFLOW:
+            hints.append("more price levels on one side than the ladder holds (the reference never drops a level that left LOBSTER's visible "
+                         "range): pass ladder_levels=128, or shorten the episode")
+        if status & _capi.ST_QUEUE_OVERFLOW:
+            hints.append("more than 512 live orders at one price")
+        if status & _capi.ST_AGENT_OVERFLOW:
+            hints.append("more than 128 live agent orders (entries freed in a step are reusable from the next one): fewer quote levels")
+        if status & _capi.ST_STREAM_END:
+            hints.append("stepped past the end of the loaded stream")
+        if status & _capi.ST_NOT_RESET:
+            hints.append("step() before reset()")
+        raise RuntimeError(f"env stopped with status {status} (include/lobsim.h: enum lobsim_status)" + ("; " + "; ".join(hints) if hints else ""))
 
     def seed(self, seed=42):
         self.np_random = np.random.RandomState(seed)
