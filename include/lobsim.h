@@ -57,7 +57,7 @@ enum lobsim_error {
 enum lobsim_status {
     LOBSIM_ST_EMPTY_BOOK = 1,      /* EmptyOrderbookError, rl4mm/orderbook/Exchange.py:180-186 */
     LOBSIM_ST_BAD_MESSAGE = 2,     /* cross_trade assert / trading_halt crash, HistoricalOrderGenerator.py:54-56 */
-    LOBSIM_ST_LEVEL_OVERFLOW = 4,  /* more price levels on one side than the build holds */
+    LOBSIM_ST_LEVEL_OVERFLOW = 4,  /* more price levels than cfg.max_levels provides slabs for */
     LOBSIM_ST_QUEUE_OVERFLOW = 8,  /* more live orders at one price than the build holds */
     LOBSIM_ST_AGENT_OVERFLOW = 16, /* more live agent orders than the build holds */
     LOBSIM_ST_STREAM_END = 32,     /* no snapshot at or before the episode's start, or a step that ends 2 s or more beyond the
@@ -127,8 +127,15 @@ typedef struct lobsim_cfg {
     int32_t inc_prev_action_in_obs;
     int32_t n_features;
     int32_t device_id; /* HIP device ordinal (ignored by the oracle) */
-    int32_t ladder_levels; /* price levels per side an env can hold: 0 = auto (64 for n_levels <= 16, else 128), 64 or 128.
-                              Exceeding it sets LOBSIM_ST_LEVEL_OVERFLOW on that env (ignored by the oracle) */
+    int32_t ladder_levels; /* price levels per side an env keeps ON CHIP (LDS): 0 = auto (64 for n_levels <= 16, else 128), 64 or
+                              128.  A performance knob only: levels beyond it live in HBM (ignored by the oracle) */
+    int32_t max_levels;    /* price levels per side an env can hold in all.  The reference's book is an unbounded SortedDict
+                              (rl4mm/orderbook/models.py:64-69) that keeps every level that left LOBSTER's visible range, so a
+                              drifting price piles up stale levels on the side it leaves (10 + one per tick of net excursion).
+                              0 = auto: 1024, halved while the slab pool (2 x 8 KiB per level and env) would take more than half
+                              of the free device memory.  Otherwise 64 .. 2048; rounded up to a multiple of 32.  Exceeding it sets
+                              LOBSIM_ST_LEVEL_OVERFLOW on that env (ignored by the oracle) */
+    int32_t reserved0;
     int64_t step_us;    /* step_size */
     int64_t episode_us; /* episode_length */
     int64_t warmup_us;  /* max feature window (whole seconds) */

@@ -63,6 +63,8 @@ class Cfg(C.Structure):
         ("n_features", C.c_int32),
         ("device_id", C.c_int32),
         ("ladder_levels", C.c_int32),
+        ("max_levels", C.c_int32),
+        ("reserved0", C.c_int32),
         ("step_us", C.c_int64),
         ("episode_us", C.c_int64),
         ("warmup_us", C.c_int64),
@@ -195,6 +197,7 @@ def make_cfg(
     terminal_reward=(R_PNL, 0, 0.0),
     device_id: int = 0,
     ladder_levels: int = 0,
+    max_levels: int = 0,
 ) -> Cfg:
     cfg = Cfg()
     cfg.n_envs, cfg.n_levels, cfg.tick_size, cfg.outer_levels = n_envs, n_levels, tick_size, outer_levels
@@ -222,6 +225,7 @@ def make_cfg(
     cfg.terminal_reward = _rw(terminal_reward)
     cfg.device_id = device_id
     cfg.ladder_levels = ladder_levels
+    cfg.max_levels = max_levels
     return cfg
 
 

@@ -69,6 +69,15 @@ namespace lobk {
 #ifndef LOBSIM_SLOT_EARLY
 #define LOBSIM_SLOT_EARLY 1   // lane-parallel cancellations: cache entries read once per batch, the slot asked for before the segment's appends
 #endif
+#ifndef LOBSIM_FAR
+#define LOBSIM_FAR 1  // 0 (diagnostic builds only): no far levels - a side that outgrows the near ladder ends its env with LOBSIM_ST_LEVEL_OVERFLOW
+#endif
+#ifndef LOBSIM_FAR_OPS
+#define LOBSIM_FAR_OPS 1   // (bisecting the cost of the far code: orders at far prices)
+#endif
+#ifndef LOBSIM_FAR_EVICT
+#define LOBSIM_FAR_EVICT 1  // (ditto: eviction / refill / slabs beyond the first mask)
+#endif
 #ifndef LOBSIM_TOMB
 #define LOBSIM_TOMB 128  // tombstones a level may hold before its slab is squeezed.  Measured 8 .. 384: with queue scans
                          // on every cancellation the optimum was 16-32; now that the position cache answers most of them, 128
@@ -116,6 +125,9 @@ struct RolloutArgs {
     double* trace;          // or null: [T][n_envs][LOBSIM_TRACE_DIM] per-step series (lobsim_set_trace_buffer)
 };
 
+typedef long long ll2_t __attribute__((ext_vector_type(2)));
+struct alignas(16) I64x2 { int64_t x, y; };
+
 // Everything below is a member of Eng<LVT>: LVT = price levels per side the LDS-resident ladder holds (64 or 128; the HBM
 // image always has room for lobk::LV = 128).  The 64-level build is the one the 10-level configurations run: 7.5 KB of
 // ladder + agent state per env leaves LDS room for the message batch and the feature state to be prefetched by LDS-DMA.
@@ -139,20 +151,24 @@ static constexpr int HALVES = LVT / 64;  // ladder entries per lane
 
 // 9.4 KB per env -> 16 envs (waves) per CU: all 4096 envs of a launch are resident at once
 struct Lds {
-    int64_t price[2][LV];
-    uint64_t meta[2][LV];  // slab | head << 16 | tail << 32 | live << 48 : one ds_read_b64 per level access
-    int32_t vol[2][LV];    // total resting volume of the level
+    // near ladder: the best LV levels of each side, sorted best first.  Entry [LV] is a staging slot: a FAR level (HBM
+    // ring, see lobsim_layout.h) that a serial routine is working on sits there for the duration of that one operation,
+    // so level_append / reduce_slot / compact_level address it like any other level (far_stage / far_commit).
+    int64_t price[2][LV + 1];
+    uint64_t meta[2][LV + 1];  // slab | head << 16 | tail << 32 | live << 48 : one ds_read_b64 per level access
+    int32_t vol[2][LV + 1];    // total resting volume of the level
     AgentOrd agent[NA];
     Op8 ops[OPS_MAX];
     int32_t cur[2][QMAX];
     double pdf[2][QMAX];
     uint16_t apos[NA];             // slot index of each live agent order inside its level's slab
-    unsigned long long freed[NA / 64];  // agent entries freed by the lane-parallel cancel pass (OR-ed by lanes)
-    // step kernel: the two ring words each feature lane will read, asked for right after the env state and parked here until
-    // the feature phase (one HBM round trip less at the end of the step)
-    int64_t rstash[LOBSIM_MAX_FEATURES][2];
+    union {
+        // step kernel: the two ring words each feature lane will read, asked for right after the env state and parked here until
+        // the feature phase (one HBM round trip less at the end of the step)
+        int64_t rstash[LOBSIM_MAX_FEATURES][2];
+        double act[LOBSIM_MAX_ACTION_DIM];  // rollout kernel: the step's action, needed again only by the trace and at the end of the launch
+    };
     int32_t info_q[4];  // SimpleInfoCalculator: first quoted level and volume-weighted level sum per side of this step's action
-    double act[LOBSIM_MAX_ACTION_DIM];  // rollout kernel: the step's action, needed again only by the trace and at the end of the launch
     // Wave-uniform state that is touched rarely (a level opens or empties, the agent trades, an execution is counted).
     // It lives here and not in scalar registers: the replay loop would otherwise carry ~35 SGPRs through every one of
     // its merge points (copies and spills on the scalar unit, which is what bounds this kernel at 16 waves per CU).
@@ -164,7 +180,9 @@ struct Lds {
     int32_t ag_cnt[2], ag_vol[2], ext_cnt[2], ext_vol[2];  // fills of the current step; agent fills by the agent's side, external
                                                           // fills by the resting order's side
     uint32_t agent_seq;
+    uint16_t far_n[2], far_front[2];  // far levels per side, ring position of the best one (EnvHdr; invariant: far_n > 0 only while the near side is full)
 };
+static_assert(sizeof(Lds) <= (LVT == 64 ? 8192 : 10240), "LDS per env: 20 (16) envs per CU with the 64 (128)-level ladder");
 
 SDI uint64_t mk_meta(int slab, int head, int tail, int live) {
     return (uint64_t)(uint32_t)slab | ((uint64_t)(uint32_t)head << 16) | ((uint64_t)(uint32_t)tail << 32) | ((uint64_t)(uint32_t)live << 48);
@@ -330,12 +348,252 @@ SDI int insert_pos(const Lds& L, const Scal& S, int side, int64_t price) {
     return r;
 }
 
-// open an empty level at sorted position pos; returns false on overflow
+// ---------------------------------------------------------------------------------------------------------------
+// far levels (HBM ring per side, lobsim_layout.h): the part of a side beyond the best LV levels.  The reference's
+// SortedDict is unbounded and LOBSTER sends no messages for orders that left its visible range, so under a price drift
+// the side the price moves away from piles up hundreds of stale levels.  Invariant: a side has far levels only while
+// its near ladder is full, so "price p belongs to the far part" = near full and p worse than the near ladder's last.
+// Everything here is rare and serial: the near ladder evicts its worst level when a better one opens (O(1), front of
+// the ring), refills from the front when a near level empties (O(1)), the resync appends at the back (O(1)); only an
+// order at a far price that has no level yet, or a far level that empties, moves ring entries (the shorter side).
+// The routines are OUT OF LINE (the step kernel's code is larger than the instruction cache as it is) and take / return
+// plain values: a reference to the wave's scalar state would pin that state in memory for the whole kernel.
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef LOBSIM_COLD_INLINE
+#define LOBSIM_COLD_INLINE 1  // measured: calls cost 3-6 % of the step (caller-saved registers around ~40 call sites); inlined behind UNLIKELY 0-2 %
+#endif
+#if LOBSIM_COLD_INLINE
+#define COLD SDI
+#else
+#define COLD static __device__ __attribute__((noinline))
+#endif
+SDI FarLevel* far_ring(Slot* slots, int side) {
+    return reinterpret_cast<FarLevel*>(reinterpret_cast<char*>(slots) - AUX_BYTES) + (size_t)side * FAR_CAP;
+}
+SDI uint64_t* hi_free_words(Slot* slots) { return reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(slots) - HI_BYTES); }
+SDI int far_count(const Lds& L, int side) { return (int)uni((int32_t)L.far_n[side]); }
+SDI int far_phys(const Lds& L, int side, int k) { return ((int)uni((int32_t)L.far_front[side]) - k) & (FAR_CAP - 1); }  // k-th best far level
+SDI bool worse(int side, int64_t a, int64_t b) { return side == LOBSIM_BUY ? a < b : a > b; }  // a is a worse price than b on this side
+// ring entries travel as two 16-byte halves (a struct copy through a conditional goes through scratch memory)
+struct FarRegs { ll2_t a, b; };  // {price, meta}, {vol, pad}
+SDI FarRegs far_ld(const FarLevel* e) { const ll2_t* q = reinterpret_cast<const ll2_t*>(e); FarRegs r = {q[0], q[1]}; return r; }
+SDI void far_st(FarLevel* e, int64_t price, uint64_t meta, int64_t vol) {
+    ll2_t* q = reinterpret_cast<ll2_t*>(e);
+    ll2_t a = {price, (long long)meta}, b = {vol, 0};
+    q[0] = a; q[1] = b;
+}
+
+#define UNLIKELY(x) __builtin_expect(!!(x), 0)  // the far branches: laid out away from the hot path, spills kept inside them
+// a free slab beyond the first NSLAB: their mask lives in HBM, one word per lane.  -1: none left
+SDI int slab_alloc_hi(Slot* slots) {
+    uint64_t* w = hi_free_words(slots);
+    const uint64_t v = w[lane()];
+    const uint64_t b = ballot(v != 0);
+    if (!b) return -1;
+    const int wl = ffs64(b);
+    const int bit = ffs64((uint64_t)rl64((int64_t)v, wl));
+    if (lane() == wl) w[wl] = v & (v - 1);
+    wsync();
+    return NSLAB + wl * 64 + bit;
+}
+SDI void slab_release(Lds& L, Slot* slots, int slab) {  // (inside the cold routines)
+    if (slab < NSLAB) { mask_set(L.slab_free, slab); return; }
+    uint64_t* w = hi_free_words(slots) + ((slab - NSLAB) >> 6);
+    if (lane() == 0) *w = *w | (1ull << ((slab - NSLAB) & 63));
+    wsync();
+}
+// The rare part of ladder_insert: a full near side evicts its worst level (index LV - 1) to the front of the far ring,
+// and / or the slab comes from the mask in HBM because the one in LDS is used up (`slab` < 0).
+// Returns the slab (or 0xffff) | status bits << 16.
+COLD int ladder_insert_cold(Lds& L, Slot* slots, int side, int evict, int slab) {
+    side = uni(side); evict = uni(evict); slab = uni(slab);
+    if (evict) {
+        const int n = far_count(L, side);
+        if (n >= FAR_CAP) return 0xffff | (LOBSIM_ST_LEVEL_OVERFLOW << 16);
+        const int fr = far_phys(L, side, -1);
+        if (lane() == 0) {
+            far_st(far_ring(slots, side) + fr, L.price[side][LV - 1], L.meta[side][LV - 1], L.vol[side][LV - 1]);
+            L.far_front[side] = (uint16_t)fr; L.far_n[side] = (uint16_t)(n + 1);
+        }
+        wsync();
+    }
+    if (slab < 0) slab = slab_alloc_hi(slots);
+    if (slab < 0) return 0xffff | (LOBSIM_ST_LEVEL_OVERFLOW << 16);
+    return slab;
+}
+// The rare part of ladder_remove: a slab beyond the first NSLAB goes back to the mask in HBM (`slab` >= 0), and / or the best
+// far level takes near entry `at` (the place that opened at the end of the full near ladder; `at` >= 0).
+COLD void ladder_remove_cold(Lds& L, Slot* slots, int side, int slab, int at) {
+    side = uni(side); slab = uni(slab); at = uni(at);
+    if (slab >= 0) slab_release(L, slots, slab);
+    if (at < 0) return;
+    const int fn = far_count(L, side), fr = far_phys(L, side, 0);
+    const FarRegs f = far_ld(far_ring(slots, side) + fr);
+    if (lane() == 0) {
+        L.price[side][at] = f.a.x; L.meta[side][at] = (uint64_t)f.a.y; L.vol[side][at] = (int32_t)f.b.x;
+        L.far_front[side] = (uint16_t)((fr - 1) & (FAR_CAP - 1)); L.far_n[side] = (uint16_t)(fn - 1);
+    }
+    wsync();
+}
+// move the ring entries of the logical range [j0, j1) by one position: dir = +1 towards the front (each physical index
+// + 1), -1 towards the back.  Chunks of 64 in the order that never overwrites an entry not yet read; inside a chunk every
+// lane's load is issued before any lane's store (a wave's vector-memory instructions execute in program order).
+SDI void far_shift(const Lds& L, Slot* slots, int side, int j0, int j1, int dir) {
+    FarLevel* ring = far_ring(slots, side);
+    const int fr = far_phys(L, side, 0), ln = lane();
+    for (int done = 0; done < j1 - j0; done += 64) {
+        const int j = dir > 0 ? j0 + done + ln : j1 - 1 - done - ln;  // towards the front: best first; towards the back: worst first
+        const bool in = j >= j0 && j < j1;
+        const FarRegs f = far_ld(ring + ((fr - (in ? j : j0)) & (FAR_CAP - 1)));  // (lanes beyond the range read a valid entry and drop it)
+        wsync();
+        if (in) { ll2_t* q = reinterpret_cast<ll2_t*>(ring + ((fr - j + dir) & (FAR_CAP - 1))); q[0] = f.a; q[1] = f.b; }
+        wsync();
+    }
+}
+// logical index of the far level at `price`, or -1; ins = far levels better than `price` (where a new level would go)
+SDI int far_find(const Lds& L, Slot* slots, int side, int64_t price, int& ins) {
+    const FarLevel* ring = far_ring(slots, side);
+    const int n = far_count(L, side), fr = far_phys(L, side, 0), ln = lane();
+    ins = 0;
+    if (n == 0) return -1;
+    {   // worse than the worst level (what the outer-level resync adds): no search
+        const int64_t pw = uni64(ring[(fr - (n - 1)) & (FAR_CAP - 1)].price);
+        if (worse(side, price, pw)) { ins = n; return -1; }
+    }
+    for (int base = 0; base < n; base += 256) {  // sorted best-first: four chunks per round trip
+        int64_t p0, p1, p2, p3;
+        { const int j = base + ln; p0 = ring[(fr - (j < n ? j : 0)) & (FAR_CAP - 1)].price; }
+        { const int j = base + 64 + ln; p1 = ring[(fr - (j < n ? j : 0)) & (FAR_CAP - 1)].price; }
+        { const int j = base + 128 + ln; p2 = ring[(fr - (j < n ? j : 0)) & (FAR_CAP - 1)].price; }
+        { const int j = base + 192 + ln; p3 = ring[(fr - (j < n ? j : 0)) & (FAR_CAP - 1)].price; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int64_t pk = k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3;
+            const int j = base + 64 * k + ln;
+            const uint64_t eq = ballot(j < n && pk == price);
+            if (eq) return base + 64 * k + ffs64(eq);
+            const int better = popc64(ballot(j < n && worse(side, price, pk)));
+            ins += better;
+            if (better < 64) return -1;
+        }
+    }
+    return -1;
+}
+// open ring entry k (0 .. n) for a new level: the shorter side makes room.  Returns status bits.
+SDI int far_insert_at(Lds& L, Slot* slots, int side, int k, int64_t price, uint64_t meta, int32_t vol) {
+    const int n = far_count(L, side);
+    if (n >= FAR_CAP) return LOBSIM_ST_LEVEL_OVERFLOW;
+    int fr = far_phys(L, side, 0);
+    if (n == 0) fr = 0;
+    else if (k <= n - k) { far_shift(L, slots, side, 0, k, +1); fr = (fr + 1) & (FAR_CAP - 1); }
+    else far_shift(L, slots, side, k, n, -1);
+    if (lane() == 0) {
+        far_st(far_ring(slots, side) + ((fr - k) & (FAR_CAP - 1)), price, meta, vol);
+        L.far_front[side] = (uint16_t)fr; L.far_n[side] = (uint16_t)(n + 1);
+    }
+    wsync();
+    return 0;
+}
+SDI void far_remove_at(Lds& L, Slot* slots, int side, int k) {
+    const int n = far_count(L, side);
+    int fr = far_phys(L, side, 0);
+    if (k < n - 1 - k) { far_shift(L, slots, side, 0, k, -1); fr = (fr - 1) & (FAR_CAP - 1); }
+    else far_shift(L, slots, side, k + 1, n, +1);
+    if (lane() == 0) { L.far_front[side] = (uint16_t)fr; L.far_n[side] = (uint16_t)(n - 1); }
+    wsync();
+}
+// does `price` belong to the far part of this side?
+SDI bool far_domain(const Lds& L, const Scal& S, int side, int64_t price) {
+    return LOBSIM_FAR && LOBSIM_FAR_OPS && S.n_lv[side] >= LV && worse(side, price, uni64(L.price[side][LV - 1]));
+}
+// find_level for a far price: the level is put into staging slot [LV] of the near arrays, where the routines that work on
+// a level address it like any other.  With `create` a level that does not exist is staged empty, with a fresh slab; it
+// enters the ring when the operation ends (far_finish).  Returns k | exists << 16 (k = the level's logical ring index, or
+// where the new level will go), -1 when there is no such level and none is to be created, -2 when no slab is left.
+COLD int far_lookup(Lds& L, Slot* slots, int side, int64_t price, int create) {
+    side = uni(side); price = uni64(price); create = uni(create);
+    int ins;
+    const int k = far_find(L, slots, side, price, ins);
+    if (k >= 0) {
+        const FarRegs f = far_ld(far_ring(slots, side) + far_phys(L, side, k));
+        if (lane() == 0) { L.price[side][LV] = f.a.x; L.meta[side][LV] = (uint64_t)f.a.y; L.vol[side][LV] = (int32_t)f.b.x; }
+        wsync();
+        return k | (1 << 16);
+    }
+    if (!create) return -1;
+    int slab = mask_take_first(L.slab_free);
+    if (slab < 0) slab = slab_alloc_hi(slots);
+    if (slab < 0) return -2;
+    if (lane() == 0) { L.price[side][LV] = price; L.meta[side][LV] = mk_meta(slab, 0, 0, 0); L.vol[side][LV] = 0; }
+    wsync();
+    return ins;
+}
+// ends an operation on the staged level: back to ring entry k, or (a level that did not exist) into the ring at k; a level
+// that has emptied (or was never filled: `dead` = the env has a status bit) leaves the ring and gives its slab back.
+// Returns status bits.
+COLD int far_finish(Lds& L, Slot* slots, int side, int k, int exists, int dead) {
+    side = uni(side); k = uni(k); exists = uni(exists); dead = uni(dead);
+    wsync();
+    const uint64_t m = (uint64_t)uni64((int64_t)L.meta[side][LV]);
+    if (m_live(m) == 0 || (dead && !exists)) {
+        if (exists) far_remove_at(L, slots, side, k);
+        slab_release(L, slots, m_slab(m));
+        return 0;
+    }
+    if (exists) {
+        if (lane() == 0) far_st(far_ring(slots, side) + far_phys(L, side, k), L.price[side][LV], m, L.vol[side][LV]);
+        wsync();
+        return 0;
+    }
+    return far_insert_at(L, slots, side, k, uni64(L.price[side][LV]), m, uni(L.vol[side][LV]));
+}
+// the worst real prices of the sides that have far levels (looked for from the back of the rings); INT64_MIN: none there
+COLD I64x2 far_worst_prices(Lds& L, Slot* slots, int sides) {
+    sides = uni(sides);
+    I64x2 r = {INT64_MIN, INT64_MIN};
+    const int ln = lane();
+    for (int side = 0; side < 2; side++) {
+        if (!((sides >> side) & 1)) continue;
+        const int fn = far_count(L, side);
+        const FarLevel* ring = far_ring(slots, side);
+        for (int base = 0; base < fn; base += 64) {
+            const int j = fn - 1 - base - ln;
+            const int64_t p = ring[far_phys(L, side, j >= 0 ? j : 0)].price;
+            const uint64_t ok = ballot(j >= 0 && (side == LOBSIM_BUY ? p > 0 : p < DUMMY_PRICE));
+            if (ok) { const int64_t w = rl64(p, ffs64(ok)); if (side == 0) r.x = w; else r.y = w; break; }
+        }
+    }
+    return r;
+}
+// inline wrappers around the staged operations
+struct FarOp { int k; bool exists; };
+// -> LV (the staging slot) or -1
+SDI int far_open(Lds& L, Scal& S, int side, int64_t price, bool create, FarOp& op, uint64_t& meta) {
+    const int r = far_lookup(L, S.slots, side, price, create ? 1 : 0);
+    if (r < 0) { if (r == -2) S.status |= LOBSIM_ST_LEVEL_OVERFLOW; op.k = -1; return -1; }
+    op.k = r & 0xffff; op.exists = (r >> 16) & 1;
+    wsync();
+    meta = (uint64_t)uni64((int64_t)L.meta[side][LV]);
+    return LV;
+}
+SDI void far_close(Lds& L, Scal& S, int side, const FarOp& op) {
+    S.status |= far_finish(L, S.slots, side, op.k, op.exists ? 1 : 0, S.status ? 1 : 0);
+}
+
+// open an empty level at sorted position pos of the NEAR ladder (the caller has ruled out far_domain); a full side
+// evicts its worst level to the far ring.  Returns false on overflow.
 SDI bool ladder_insert(Lds& L, Scal& S, int side, int pos, int64_t price) {
     int n = S.n_lv[side], ln = lane();
     EVENT(ev_ladder);
-    if (n >= LV) { S.status |= LOBSIM_ST_LEVEL_OVERFLOW; return false; }
+    if (!(LOBSIM_FAR && LOBSIM_FAR_EVICT) && n >= LV) { S.status |= LOBSIM_ST_LEVEL_OVERFLOW; return false; }
     int slab = mask_take_first(L.slab_free);
+    if (UNLIKELY(n >= LV || slab < 0)) {
+        int r = LOBSIM_ST_LEVEL_OVERFLOW << 16;
+        if (LOBSIM_FAR && LOBSIM_FAR_EVICT) r = ladder_insert_cold(L, S.slots, side, n >= LV ? 1 : 0, slab);
+        if (r >> 16) { S.status |= r >> 16; return false; }
+        slab = r & 0xffff;
+    }
+    if (n >= LV) n = LV - 1; else S.n_lv.bump(side, 1);
     int64_t p[HALVES]; uint64_t m[HALVES]; int32_t v[HALVES]; bool take[HALVES];
 #pragma unroll
     for (int r = 0; r < HALVES; r++) {
@@ -350,7 +608,6 @@ SDI bool ladder_insert(Lds& L, Scal& S, int side, int pos, int64_t price) {
         if (take[r]) { L.price[side][i] = p[r]; L.meta[side][i] = m[r]; L.vol[side][i] = v[r]; }
     }
     if (ln == 0) { L.price[side][pos] = price; L.meta[side][pos] = mk_meta(slab, 0, 0, 0); L.vol[side][pos] = 0; }
-    S.n_lv.bump(side, 1);
     S.ladder_ver++;
     wsync();
     return true;
@@ -359,7 +616,8 @@ SDI bool ladder_insert(Lds& L, Scal& S, int side, int pos, int64_t price) {
 SDI void ladder_remove(Lds& L, Scal& S, int side, int pos) {
     int n = S.n_lv[side], ln = lane();
     EVENT(ev_ladder);
-    mask_set(L.slab_free, m_slab((uint64_t)uni64((int64_t)L.meta[side][pos])));
+    const int slab = m_slab((uint64_t)uni64((int64_t)L.meta[side][pos]));
+    if (!(LOBSIM_FAR && LOBSIM_FAR_EVICT) || slab < NSLAB) mask_set(L.slab_free, slab);
     int64_t p[HALVES]; uint64_t m[HALVES]; int32_t v[HALVES]; bool take[HALVES];
 #pragma unroll
     for (int r = 0; r < HALVES; r++) {
@@ -373,9 +631,11 @@ SDI void ladder_remove(Lds& L, Scal& S, int side, int pos) {
         int i = ln + 64 * r;
         if (take[r]) { L.price[side][i] = p[r]; L.meta[side][i] = m[r]; L.vol[side][i] = v[r]; }
     }
-    S.n_lv.bump(side, -1);
     S.ladder_ver++;
     wsync();
+    const bool refill = LOBSIM_FAR && LOBSIM_FAR_EVICT && n >= LV && far_count(L, side) != 0;  // (far levels only behind a full near side)
+    if (UNLIKELY(LOBSIM_FAR && LOBSIM_FAR_EVICT && (slab >= NSLAB || refill))) ladder_remove_cold(L, S.slots, side, slab >= NSLAB ? slab : -1, refill ? n - 1 : -1);
+    if (!refill) S.n_lv.bump(side, -1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -506,7 +766,7 @@ SDI void reduce_slot(Lds& L, Scal& S, int side, int idx, uint64_t m, int pos, in
     }
     if (gone && pk == K_AGENT) mask_set(L.agent_pending, (int)pid);
     int live = m_live(m) - (gone ? 1 : 0);
-    if (gone && live == 0) { wsync(); ladder_remove(L, S, side, idx); return; }
+    if (gone && live == 0 && idx < LV) { wsync(); ladder_remove(L, S, side, idx); return; }  // (a staged far level: far_commit takes it out)
     // heads are advanced lazily: `head` is only a lower bound of the first live slot (every reader skips
     // tombstones), so removing the head order costs no dependent re-scan of the slab
     const int new_head = (gone && pos == head) ? head + 1 : head;
@@ -520,7 +780,11 @@ SDI void reduce_slot(Lds& L, Scal& S, int side, int idx, uint64_t m, int pos, in
 SDI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, int64_t id, int32_t vol) {
     uint64_t m;
     int idx = find_level_meta(L, S, side, price, m);
-    if (idx < 0) return;  // warn + KeyError -> continue
+    FarOp far = {-1, false};
+    if (idx < 0) {
+        if (UNLIKELY(far_domain(L, S, side, price))) idx = far_open(L, S, side, price, false, far, m);
+        if (idx < 0) return;  // warn + KeyError -> continue
+    }
     int ln = lane();
     int head = m_head(m), tail = m_tail(m);
     const Slot* sl = S.slots + (size_t)m_slab(m) * SLOTS;
@@ -604,12 +868,13 @@ SDI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, in
             if (lv) { int l = ffs64(lv); first_live = c * 64 + l; hk = rl32(s.kind, l); hv = rl32(s.vol, l); }
         }
 #endif
-        if (hk != K_SNAP) return;
+        if (hk != K_SNAP) return;  // (a staged far level is left as it was: nothing to write back)
         if (vol < 0) { S.status |= LOBSIM_ST_ASSERT; return; }
         pos = first_live; pv = hv; pk = K_SNAP; pid = -1;
     }
     int32_t rv = vol < 0 ? pv : (vol > pv ? pv : vol);  // CancellationVolumeExceededError -> whole remainder (:144-146)
     reduce_slot(L, S, side, idx, m, pos, rv, pv, pk, pid);
+    if (UNLIKELY(far.k >= 0)) far_close(L, S, side, far);
 }
 
 // cuts strictly inside the executed interval (from, from + ex) of one resting order (all lanes run the same trip count)
@@ -735,22 +1000,30 @@ SDI void submit_limit(Lds& L, Scal& S, int side, int64_t price, int32_t vol, boo
         vol = execute(L, S, side, is_agent, false, price, vol);
         if (S.status || vol <= 0) return;
     }
+    FarOp far = {-1, false};
     if (idx < 0) {
-        idx = insert_pos(L, S, side, price);
+        if (UNLIKELY(far_domain(L, S, side, price))) {  // beyond the near ladder: the level is worked on in the staging slot
+            idx = far_open(L, S, side, price, true, far, m);
+            if (idx < 0) return;
+        } else {
+            idx = insert_pos(L, S, side, price);
 #ifdef LOBSIM_PROFILE
-        if (!is_agent && idx == 0) S.ev_rare++;  // (diagnostic) an external limit that opens a new best level
+            if (!is_agent && idx == 0) S.ev_rare++;  // (diagnostic) an external limit that opens a new best level
 #endif
-        if (!ladder_insert(L, S, side, idx, price)) return;
-        m = (uint64_t)uni64((int64_t)L.meta[side][idx]);
+            if (!ladder_insert(L, S, side, idx, price)) return;
+            m = (uint64_t)uni64((int64_t)L.meta[side][idx]);
+        }
     }
     int64_t id = ext_id;
     if (is_agent) {
         int a = alloc_agent(L, S);
-        if (a < 0) return;
-        if (lane() == 0) { AgentOrd o; o.price = price; o.vol = vol; o.seq_side = (L.agent_seq & 0x7fffffffu) | ((uint32_t)side << 31); L.agent[a] = o; L.agent_seq++; }
-        id = a;
+        if (a >= 0) {
+            if (lane() == 0) { AgentOrd o; o.price = price; o.vol = vol; o.seq_side = (L.agent_seq & 0x7fffffffu) | ((uint32_t)side << 31); L.agent[a] = o; L.agent_seq++; }
+            id = a;
+        }
     }
-    level_append(L, S, side, idx, id, vol, is_agent ? K_AGENT : K_EXT, m);
+    if (!S.status) level_append(L, S, side, idx, id, vol, is_agent ? K_AGENT : K_EXT, m);
+    if (UNLIKELY(far.k >= 0)) far_close(L, S, side, far);
 }
 
 // process_order (Exchange.py:58-69) for one historical message
@@ -1121,11 +1394,9 @@ SDI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
         atomicAdd(&L.vol[side][li], -cv);
         if (gone) {
             atomicAdd(reinterpret_cast<unsigned long long*>(&L.meta[side][li]), (unsigned long long)(-(1ll << 48)));  // live -= 1
-            atomicOr(&L.freed[idx >> 6], 1ull << (idx & 63));
+            atomicOr(&L.agent_pending[idx >> 6], 1ull << (idx & 63));  // freed: not reused before the step ends
         }
     }
-    wsync();
-    if (ln == 0) { L.agent_pending[0] |= L.freed[0]; L.agent_pending[1] |= L.freed[1]; L.freed[0] = 0; L.freed[1] = 0; }
     wsync();
     // levels emptied by the cancellations leave the ladder (rare; sequential, looked up again by price)
     bool emptied = can_ok && gone && m_live(L.meta[side][li]) == 0;
@@ -1144,16 +1415,19 @@ SDI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
 // ---------------------------------------------------------------------------------------------------------------
 // simulator: snapshot -> book, outer-level resync, message replay
 // ---------------------------------------------------------------------------------------------------------------
-SDI void ladder_clear(Lds& L, Scal& S) {
+SDI Slot* env_slabs(const DevPtrs& P, int env) { return reinterpret_cast<Slot*>(P.pool + (size_t)env * (size_t)P.pool_stride + AUX_BYTES); }
+
+SDI void ladder_clear(Lds& L, Scal& S, int n_slab) {
     S.n_lv.v = 0;
     S.ladder_ver = 0;
+    if (lane() < 2) { L.far_n[lane()] = 0; L.far_front[lane()] = 0; }
+    hi_free_words(S.slots)[lane()] = lane() < (n_slab - NSLAB) / 64 ? ~0ull : 0ull;  // slabs beyond the first NSLAB
     if (lane() < NSLAB / 64) L.slab_free[lane()] = ~0ull;
     if (lane() < NA / 64) { L.agent_free[lane()] = ~0ull; L.agent_pending[lane()] = 0; }
     L.agent[lane()].vol = 0;
     L.agent[lane() + 64].vol = 0;
     L.apos[lane()] = 0;
     L.apos[lane() + 64] = 0;
-    if (lane() < NA / 64) L.freed[lane()] = 0;
     if (lane() == 0) L.agent_seq = 0;
     wsync();
 }
@@ -1161,9 +1435,16 @@ SDI void ladder_clear(Lds& L, Scal& S) {
 // book[direction][price] = deque([LimitOrder(internal_id=-1)]) (Exchange.py:172-178, OrderbookSimulator.py:130)
 SDI void set_level_to_snapshot(Lds& L, Scal& S, int side, int64_t price, int32_t vol) {
     int idx = find_level(L, S, side, price);
+    FarOp far = {-1, false};
     if (idx < 0) {
-        idx = insert_pos(L, S, side, price);
-        if (!ladder_insert(L, S, side, idx, price)) return;
+        if (UNLIKELY(far_domain(L, S, side, price))) {
+            uint64_t m;
+            idx = far_open(L, S, side, price, true, far, m);
+            if (idx < 0) return;
+        } else {
+            idx = insert_pos(L, S, side, price);
+            if (!ladder_insert(L, S, side, idx, price)) return;
+        }
     }
     if (lane() == 0) {
         int slab = m_slab(L.meta[side][idx]);
@@ -1172,6 +1453,7 @@ SDI void set_level_to_snapshot(Lds& L, Scal& S, int side, int64_t price, int32_t
         L.meta[side][idx] = mk_meta(slab, 0, 1, 1); L.vol[side][idx] = vol;
     }
     wsync();
+    if (UNLIKELY(far.k >= 0)) far_close(L, S, side, far);
 }
 
 // orderbook_price_range (Exchange.py:158-169): lowest buy price > 0 and highest sell price < 9999999999
@@ -1188,13 +1470,18 @@ SDI bool price_range(const Lds& L, const Scal& S, int64_t& worst_buy, int64_t& w
     if (ib < 0 || is < 0) return false;  // StopIteration
     worst_buy = uni64(L.price[0][ib]);
     worst_sell = uni64(L.price[1][is]);
+    // a side with far levels: its worst real price is in the far ring
+    const int fsides = (LOBSIM_FAR && nb >= LV && far_count(L, 0) ? 1 : 0) | (LOBSIM_FAR && ns >= LV && far_count(L, 1) ? 2 : 0);
+    if (UNLIKELY(fsides)) {
+        const I64x2 w = far_worst_prices(const_cast<Lds&>(L), S.slots, fsides);
+        if (w.x != INT64_MIN) worst_buy = w.x;
+        if (w.y != INT64_MIN) worst_sell = w.y;
+    }
     return true;
 }
 
 SDI double best_buy_d(const Lds& L, const Scal& S) { return S.n_lv[0] ? (double)uni64(L.price[0][0]) : 0.0; }
 SDI double best_sell_d(const Lds& L, const Scal& S) { return S.n_lv[1] ? (double)uni64(L.price[1][0]) : (double)INFINITY; }
-
-struct alignas(16) I64x2 { int64_t x, y; };
 
 struct Ranges { double min_buy, max_sell, init_buy, init_sell; };
 
@@ -1260,7 +1547,6 @@ SDI void resync_outer_levels(Lds& L, Scal& S, const DevCfg& C, const StreamDev& 
 
 // One batch of the message stream: lane ln holds message cursor + ln (t = INT64_MAX past the end of the stream).
 struct MsgBatch { int64_t t, eid, price, meta; };
-typedef long long ll2_t __attribute__((ext_vector_type(2)));
 typedef const ll2_t __attribute__((address_space(1)))* GlobalI64x2;  // global (not flat) loads of the packed stream
 
 // No bounds test: the host appends 64 sentinel rows (t = INT64_MAX) to every stream (lobsim_add_stream), and a load inside
@@ -1906,12 +2192,15 @@ struct HdrRegs {
     int64_t inventory, cash;
     uint32_t agent_seq;
     int32_t status, n_lv0, n_lv1;
+    uint32_t far_n, far_front;  // two 16-bit halves each (buy | sell << 16)
 };
 static_assert(NSLAB == 256 && NA == 128, "HdrRegs holds the free masks as scalars");
 
 SDI HdrRegs read_hdr(const EnvHdr& H) {
+    const uint64_t farw = *reinterpret_cast<const uint64_t*>(&H.far_n[0]);  // far_n[2], far_front[2]: one 8-byte word
     HdrRegs h = {H.slab_free[0], H.slab_free[1], H.slab_free[2], H.slab_free[3], H.agent_free[0], H.agent_free[1],
-                 H.inventory, H.cash, H.agent_seq, H.status, H.n_lv[0], H.n_lv[1]};
+                 H.inventory, H.cash, H.agent_seq, H.status, H.n_lv[0], H.n_lv[1],
+                 (uint32_t)farw, (uint32_t)(farw >> 32)};
     return h;
 }
 
@@ -1953,15 +2242,15 @@ SDI void load_env_commit(Lds& L, Scal& S, const DevPtrs& P, int env, const HdrRe
         for (int i = ln + 64; i < S.n_lv[s]; i += 64) {
             L.price[s][i] = G.price[s][i]; L.meta[s][i] = G.meta[s][i]; L.vol[s][i] = G.vol[s][i];
         }
-    if (ln < NA / 64) L.freed[ln] = 0;
     S.status = H.status; S.n_ops = 0; S.ladder_ver = 0; S.msgs_step = 0;
     if (ln < NSLAB / 64) L.slab_free[ln] = ln == 0 ? H.sf0 : ln == 1 ? H.sf1 : ln == 2 ? H.sf2 : H.sf3;
     if (ln < NA / 64) { L.agent_free[ln] = ln == 0 ? H.af0 : H.af1; L.agent_pending[ln] = 0; }
+    if (ln < 2) { L.far_n[ln] = (uint16_t)(H.far_n >> (16 * ln)); L.far_front[ln] = (uint16_t)(H.far_front >> (16 * ln)); }
     if (ln == 0) {
         L.inv = H.inventory; L.cash = H.cash; L.agent_seq = H.agent_seq;
         L.ag_cnt[0] = L.ag_cnt[1] = 0; L.ag_vol[0] = L.ag_vol[1] = 0; L.ext_cnt[0] = L.ext_cnt[1] = 0; L.ext_vol[0] = L.ext_vol[1] = 0;
     }
-    S.slots = P.slots + (size_t)env * NSLAB * SLOTS;
+    S.slots = env_slabs(P, env);
     S.idc = P.idc + (size_t)env * IDC_N;
     wsync();
 }
@@ -1995,6 +2284,7 @@ SDI void store_env(const Lds& L, const Scal& S, const DevPtrs& P, int env, EnvHd
     if (ln < NSLAB / 64) H.slab_free[ln] = L.slab_free[ln];
     if (ln < NA / 64) H.agent_free[ln] = L.agent_free[ln] | L.agent_pending[ln];
     if (ln == 0) { H.n_lv[0] = S.n_lv[0]; H.n_lv[1] = S.n_lv[1]; H.agent_seq = L.agent_seq; }
+    if (ln < 2) { H.far_n[ln] = L.far_n[ln]; H.far_front[ln] = L.far_front[ln]; }
     }
     if (!rest) return;
     if (ln == 0) {
@@ -2432,11 +2722,11 @@ SDI void reset_body(const DevCfg& C, const DevPtrs& P, const ResetArgs& A) {
     EnvHdr& H = P.hdr[env];
     const int F = C.c.n_features, D = C.obs_dim, Lv = C.c.n_levels;
     Scal S;
-    S.slots = P.slots + (size_t)env * NSLAB * SLOTS;
+    S.slots = env_slabs(P, env);
     S.idc = P.idc + (size_t)env * IDC_N;
     S.status = 0; S.n_ops = 0;
     if (ln == 0) { L.inv = H.inventory; L.cash = H.cash; }  // the portfolio is NOT reset (Q7)
-    ladder_clear(L, S);
+    ladder_clear(L, S, P.n_slab);
     clear_step_fills(L);
     const int stream_id = A.stream_ids[k];
     const StreamDev& st = P.streams[stream_id];
@@ -2499,11 +2789,11 @@ SDI void set_book_body(const DevCfg& C, const DevPtrs& P, int env, const int64_t
     __shared__ Lds L;
     EnvHdr& H = P.hdr[env];
     Scal S;
-    S.slots = P.slots + (size_t)env * NSLAB * SLOTS;
+    S.slots = env_slabs(P, env);
     S.idc = P.idc + (size_t)env * IDC_N;
     S.status = 0; S.n_ops = 0;
     if (lane() == 0) { L.inv = H.inventory; L.cash = H.cash; }
-    ladder_clear(L, S);
+    ladder_clear(L, S, P.n_slab);
     clear_step_fills(L);
     if (row) load_snapshot_book(L, S, row, C.c.n_levels, true);
     store_env(L, S, P, env, H);

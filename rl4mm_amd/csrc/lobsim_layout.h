@@ -6,9 +6,12 @@
 // Per env in HBM (sized for 288 GB: we spend capacity to make every access O(1) and coalesced):
 //   EnvHdr                      scalars (clock, portfolio, resync bookkeeping, fill aggregates, free masks)
 //   Ladder                      per side LV price levels, sorted best-first (SoA: price, packed slab/head/tail/live, volume)
-//   Slot slabs[2*LV][SLOTS]     one fixed slab per price level = that level's FIFO queue; slot index = time
-//                               priority; removed orders leave tombstones, squeezed out once a chunk's worth
-//                               (64) has piled up, so a scan touches ceil(live/64)+1 chunks
+//   FarLevel far[2][FAR_CAP]    price levels beyond the best LVT of a side (the reference's SortedDict is unbounded and keeps
+//                               every level that left LOBSTER's visible range): a ring per side, best-first from its front
+//   hi_free[64]                 free mask of the slabs beyond the first NSLAB_LO
+//   Slot slabs[n_slab][SLOTS]   one fixed slab per price level = that level's FIFO queue; slot index = time
+//                               priority; removed orders leave tombstones, squeezed out once LOBSIM_TOMB of them
+//                               have piled up, so a scan touches ceil((live+tombstones)/64) chunks
 //   AgentOrd agent[NA]          the agent's own live orders (the reference's "internal orderbook")
 //   feature scalars + rings     rolling windows of the observation features
 // During a launch the ladder, the agent orders and the op list live in LDS; slabs stay in HBM/L2 and are read
@@ -22,9 +25,21 @@
 namespace lobk {
 
 constexpr int WAVE = 64;
-constexpr int LV = 128;          // price levels per side (2 per lane)
+constexpr int LV = 128;          // price levels per side of the NEAR ladder (the part of a side an env keeps in LDS; 2 per lane)
 constexpr int SLOTS = 512;       // order slots per price level (8 chunks of one wave-load each; 8 KiB slab)
-constexpr int NSLAB = 2 * LV;    // slabs per env
+constexpr int NSLAB = 2 * LV;    // slabs whose free mask lives in the header / in LDS (the first ones handed out)
+// Levels beyond the near ladder ("far" levels: the worse end of a side) live in HBM, one ring per side that is ordered
+// best-first from its front: the level next to the near ladder's worst is at `front`, the k-th best far level at
+// (front - k) mod FAR_CAP.  Both ends are O(1): the near ladder evicts to / refills from the front, the once-a-second
+// outer-level resync appends at the back.  The ring's capacity is fixed; how many levels an env can really hold is set
+// by its slab pool (cfg.max_levels -> DevPtrs.n_slab).
+constexpr int FAR_CAP = 2048;
+constexpr int NSLAB_MAX = NSLAB + 64 * 64;  // the free mask of the slabs beyond NSLAB is one 64-bit word per lane
+struct alignas(16) FarLevel { int64_t price; uint64_t meta; int64_t vol; int64_t pad; };  // meta as in Ladder
+static_assert(sizeof(FarLevel) == 32, "");
+constexpr size_t FAR_BYTES = 2 * (size_t)FAR_CAP * sizeof(FarLevel);
+constexpr size_t HI_BYTES = 1024;                  // hi_free[64] u64 + padding (slabs stay 1 KiB-aligned)
+constexpr size_t AUX_BYTES = FAR_BYTES + HI_BYTES;  // per env, in front of its slabs: far rings, then hi_free
 constexpr int NA = 128;          // live agent orders per env (2 per lane)
 #ifndef LOBSIM_IDC_N
 #define LOBSIM_IDC_N 32768
@@ -74,6 +89,7 @@ struct alignas(16) EnvHdr {
     // fills of the last step
     int64_t agent_fill_count, agent_vol[2], ext_count[2], ext_vol[2];
     int64_t cash_delta;
+    uint16_t far_n[2], far_front[2];  // far levels per side and the ring position of the best one (one 8-byte word)
     int64_t info_moc_count;    // SimpleInfoCalculator.market_order_count / market_order_total_volume (InfoCalculators.py:26-27, 85-87):
     double info_moc_volume;    // live as long as the env object, never reset
     double prev_action[LOBSIM_MAX_ACTION_DIM];
@@ -119,7 +135,10 @@ struct DevCfg {
 struct DevPtrs {
     EnvHdr* hdr;
     Ladder* ladder;
-    Slot* slots;       // [env][NSLAB][SLOTS]
+    uint8_t* pool;     // [env]{FarLevel far[2][FAR_CAP]; u64 hi_free[64] (+pad); Slot slabs[n_slab][SLOTS]}
+    int64_t pool_stride;  // bytes per env
+    int32_t n_slab;    // slabs per env (NSLAB .. NSLAB_MAX, a multiple of 64)
+    int32_t pad0;
     AgentOrd* agent;   // [env][NA]
     uint16_t* apos;    // [env][NA] slot index of each live agent order inside its level's slab
     uint64_t* idc;     // [env][IDC_N] position cache of external orders: tag(id) << 32 | slab << 16 | slot, direct-mapped by id

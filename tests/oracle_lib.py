@@ -19,9 +19,7 @@ def oracle_binding() -> _capi.Binding:
     global _binding
     if _binding is None:
         so = ROOT / "oracle" / "liblobsim_oracle.so"
-        src = ROOT / "oracle" / "lobsim_oracle.c"
-        if not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
-            subprocess.check_call(["make", "-C", str(ROOT / "oracle"), "-s"])
+        subprocess.check_call(["make", "-C", str(ROOT / "oracle"), "-s"])  # (a no-op when the library is newer than its source and the header)
         b = _capi.Binding(so, prefix="oracle_", skip=_capi.ORACLE_SKIP)
         P64, PD = C.POINTER(C.c_int64), C.POINTER(C.c_double)
         b.lib.oracle_beta_volumes.restype = None
@@ -41,8 +39,25 @@ def oracle_binding() -> _capi.Binding:
         PI32, PU8 = C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
         b.lib.oracle_rollout.restype = C.c_int
         b.lib.oracle_rollout.argtypes = [C.c_void_p, C.c_int32, PD, C.c_int32, PD, PU8, PD, PD, PU8, PD, PI32, PD]
+        b.lib.oracle_set_threads.restype = None
+        b.lib.oracle_set_threads.argtypes = [C.c_int]
+        b.lib.oracle_set_threads(usable_cpus())  # (a GPU box shows 256 CPUs and grants 16: 256 OpenMP threads per small step call crawl)
         _binding = b
     return _binding
+
+
+def usable_cpus() -> int:
+    """CPUs this process can keep busy: the affinity mask capped by the cgroup's CPU quota."""
+    import os
+
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def oracle_sim(cfg) -> _capi.Sim:

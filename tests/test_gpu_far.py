@@ -1,0 +1,247 @@
+"""GPU parity of the UNBOUNDED price ladder (`-m gpu`): books that outgrow the on-chip near ladder.
+
+The reference keeps every price level ever opened (rl4mm/orderbook/models.py:64-69 SortedDict; Exchange.py:71-83 inserts,
+only _clear_empty_orders_and_prices :238-247 removes) and LOBSTER sends no messages for orders that left its visible range,
+so under a price drift one side piles up a stale level per tick of excursion: 10 + 360 levels after 30 minutes at one tick
+per 5 s.  The HIP path keeps the best 64 / 128 levels of a side in LDS and the rest in an HBM ring per side (DESIGN.md
+section 2); these tests drive it far beyond the near ladder against the oracle, whose book is the reference's structure.
+"""
+import numpy as np
+import pytest
+
+import drift_stream as ds
+import oracle_lib as ol
+from rl4mm_amd import _capi, _lib
+
+pytestmark = pytest.mark.gpu
+
+TICK, MID = 100, 1_000_000
+
+
+def _feats():
+    F = _capi.make_feature
+    return [F(_capi.F_SPREAD, 0, 100_000, 0, 1e9), F(_capi.F_INVENTORY, 0, 100_000, -1e9, 1e9)]
+
+
+def _engine_pair(ladder_levels, max_levels):
+    cfg = _capi.make_cfg(1, 10, _feats(), ladder_levels=ladder_levels, max_levels=max_levels)
+    gpu, cpu = _lib.new_sim(cfg), ol.oracle_sim(cfg)
+    levels = [(0, MID - TICK * (200 + 3 * i), 500 + i) for i in range(10)] + [(1, MID + TICK * (200 + 3 * i), 400 + i) for i in range(10)]
+    row = ol.snapshot_row_from_levels(levels, 10)
+    for sim in (gpu, cpu):
+        sim.debug_set_book(0, row, 0)
+        sim.set_portfolio(0, 0)
+    return gpu, cpu
+
+
+def _random_ops(rng, cpu, n_ops, span):
+    """Generator of single engine ops [type, side, price, volume, id, is_external]; looks at the ORACLE's book to address
+    agent orders by FIFO rank and to keep market orders inside the resting volume."""
+    live = {}  # external id -> (side, price)
+    next_id = 1000
+    for _ in range(n_ops):
+        u = rng.random()
+        side = int(rng.integers(0, 2))
+        sgn = -1 if side == 0 else 1
+        bb, bs = cpu.best_prices()
+        bb, bs = int(bb[0]), int(bs[0])
+        ref = bb if side == 0 else bs
+        if ref == 0 or ref > 10**12:
+            ref = MID + sgn * TICK
+        k = int(rng.integers(0, span)) if rng.random() < 0.6 else min(int(rng.geometric(0.15)) - 1, span - 1)
+        price = MID + sgn * TICK * (1 + k) if rng.random() < 0.7 else ref + sgn * TICK * int(rng.integers(0, 12))
+        if u < 0.40:
+            if rng.random() < 0.04:  # crossing limit: a few ticks through the opposite best
+                price = (bs if side == 0 else bb) - sgn * TICK * int(rng.integers(0, 4))
+                if price <= 0 or price > 10**12:
+                    continue
+            next_id += 1
+            live[next_id] = (side, price)
+            yield [1, side, price, int(rng.integers(1, 60)) * 10, next_id, 1]
+        elif u < 0.62 and live:
+            oid = list(live)[int(rng.integers(0, len(live)))]
+            s, p = live[oid]
+            if rng.random() < 0.5:
+                yield [2, s, p, int(rng.integers(1, 30)) * 10, oid, 1]  # partial cancellation (clamped when it over-asks)
+            else:
+                live.pop(oid)
+                yield [3, s, p, int(rng.integers(1, 80)) * 10, oid, 1]  # (LOBSTER deletions carry the remaining volume)
+        elif u < 0.67:
+            prices, _, _ = cpu.book(0, side, 4096)
+            if len(prices):
+                p = int(prices[int(rng.integers(0, len(prices)))])
+                yield [3, side, p, int(rng.integers(1, 20)) * 10, 77_000_000 + int(rng.integers(0, 1000)), 1]  # unknown id
+        elif u < 0.77:
+            yield [1, side, price, int(rng.integers(1, 40)) * 10, 0, 0]  # agent limit order
+        elif u < 0.85:
+            prices, _, _ = cpu.book(0, side, 4096)
+            cands = []
+            for p in prices[rng.permutation(len(prices))[:40]]:
+                n_agent = int((cpu.level_orders(0, side, int(p))["kind"] == 1).sum())
+                if n_agent:
+                    cands.append((int(p), n_agent))
+            if cands:
+                p, n_agent = cands[int(rng.integers(0, len(cands)))]
+                typ, rank = (2 if rng.random() < 0.5 else 3), int(rng.integers(0, n_agent + 1))  # (rank n_agent addresses no order)
+                whole = typ == 3 and rank < n_agent and rng.random() < 0.4  # Deletion without a volume: the whole order
+                yield [typ, side, p, -1 if whole else int(rng.integers(1, 50)) * 10, rank, 0]
+        elif u < 0.93:
+            _, vols, _ = cpu.book(0, side ^ 1, 4096)
+            if len(vols) < 3:
+                continue
+            big = rng.random() < 0.12
+            depth = int(rng.integers(3, 40)) if big else int(rng.integers(1, 3))
+            v = int(vols[: min(depth, len(vols) - 2)].sum() * rng.uniform(0.3, 1.0)) + 1
+            yield [4, side, 0, v, 0, 0 if rng.random() < 0.25 else 1]
+        else:
+            next_id += 1
+            live[next_id] = (side, price)
+            yield [1, side, price, int(rng.integers(1, 60)) * 10, next_id, 1]
+
+
+@pytest.mark.parametrize("ladder_levels", [64, 128])
+def test_engine_random_ops_far_levels(ladder_levels):
+    """6000 random engine ops over +-700 ticks (external / agent limits, cancellations, deletions of known and unknown ids,
+    market orders that sweep up to 40 levels) on one env: the book (prices, volumes, order counts) after EVERY op, the fills
+    of every op, and the per-order queues every 400 ops, against the oracle.  Both sides hold several hundred levels."""
+    gpu, cpu = _engine_pair(ladder_levels, 2048)
+    rng = np.random.Generator(np.random.PCG64(100 + ladder_levels))
+    most = [0, 0]
+    for i, op in enumerate(_random_ops(rng, cpu, 6000, 700)):
+        fc = cpu.debug_process_orders(0, [op])
+        fg = gpu.debug_process_orders(0, [op])
+        sg, sc = gpu.env_state(0), cpu.env_state(0)
+        assert sg["status"] == sc["status"] == 0, (i, op, sg["status"], sc["status"])
+        assert list(fg) == list(fc), (i, op, list(fg), list(fc))
+        for side in (0, 1):
+            bg, bc = gpu.book(0, side, 4096), cpu.book(0, side, 4096)
+            for a, b, what in zip(bg, bc, ("prices", "volumes", "order counts")):
+                assert np.array_equal(a, b), f"op {i} {op}: {what} of side {side} differ at level {np.nonzero(a[:min(len(a), len(b))] != b[:min(len(a), len(b))])[0][:4]} ({len(a)} vs {len(b)} levels)"
+            most[side] = max(most[side], len(bg[0]))
+        assert (sg["n_buy_levels"], sg["n_sell_levels"], sg["inventory"], sg["cash"], sg["n_agent_orders"]) == (sc["n_buy_levels"], sc["n_sell_levels"], sc["inventory"], sc["cash"], sc["n_agent_orders"]), (i, op)
+        if i % 400 == 399:
+            assert np.array_equal(gpu.queues(0), cpu.queues(0)), f"per-order queues differ after op {i}"
+    assert np.array_equal(gpu.queues(0), cpu.queues(0))
+    assert min(most) > ladder_levels + 60, most
+    gpu.close()
+
+
+def test_level_capacity_is_a_status_bit_not_a_corruption():
+    """max_levels = 128 (256 slabs per env): the op that needs the 257th level sets LOBSIM_ST_LEVEL_OVERFLOW; until then the book
+    equals the oracle's."""
+    gpu, cpu = _engine_pair(64, 128)
+    rng = np.random.Generator(np.random.PCG64(5))
+    flagged = False
+    for i, op in enumerate(_random_ops(rng, cpu, 3000, 450)):
+        cpu.debug_process_orders(0, [op])
+        gpu.debug_process_orders(0, [op])
+        sg, sc = gpu.env_state(0), cpu.env_state(0)
+        if sg["status"]:
+            assert sg["status"] == _capi.ST_LEVEL_OVERFLOW and sc["n_buy_levels"] + sc["n_sell_levels"] > 256, (i, op, sg["status"], sc["n_buy_levels"], sc["n_sell_levels"])
+            flagged = True
+            break
+        assert sc["n_buy_levels"] + sc["n_sell_levels"] <= 256
+        for side in (0, 1):
+            assert np.array_equal(gpu.book(0, side, 4096)[0], cpu.book(0, side, 4096)[0]), (i, op)
+    assert flagged
+    gpu.close()
+
+
+def _step_compare(gpu, cpu, act, t, sample=None):
+    og, rg, dg = gpu.step(act)
+    oc, rc, dc = cpu.step(act)
+    assert np.array_equal(dg, dc), f"step {t}: done differs in envs {np.nonzero(dg != dc)[0][:8]}"
+    for a, b, what in zip(gpu.portfolios(), cpu.portfolios(), ("inventory", "cash", "price")):
+        assert np.array_equal(a, b), f"step {t}: {what} differs in envs {np.nonzero(a != b)[0][:8]}"
+    assert np.allclose(og, oc, rtol=1e-12, atol=1e-9) and np.allclose(rg, rc, rtol=0, atol=1e-9), f"step {t}: obs / reward differ"
+    return dg
+
+
+def _assert_same_books(gpu, cpu, envs):
+    for e in envs:
+        sg, sc = gpu.env_state(int(e)), cpu.env_state(int(e))
+        for k in ("status", "n_buy_levels", "n_sell_levels", "n_agent_orders", "n_resyncs", "min_buy_price", "max_sell_price", "agent_fill_count", "ext_buy_count", "ext_sell_count"):
+            assert sg[k] == sc[k], (e, k, sg[k], sc[k])
+        assert np.array_equal(gpu.queues(int(e)), cpu.queues(int(e))), f"env {e}: per-order book contents differ"
+
+
+@pytest.mark.parametrize("seconds_per_tick", [5.0, 2.0])
+def test_drifting_stream_without_agent(seconds_per_tick):
+    """The probe of the round-2 review: 10-level book, the price stepping up one tick every 5 s (2 s), a 30-minute replay
+    with no agent orders (the replay is the warm-up of a reset whose start lies 30 minutes after the snapshot it loads).
+    The oracle ends with ~350 (~860) buy levels; every env of the batch must hold exactly its book, order by order."""
+    n = 64
+    ps = ds.drift_stream(11, ds.ramp_path(seconds_per_tick), duration_s=1_900.0)
+    cfg = _capi.make_cfg(n, 10, _feats(), step_us=100_000, episode_us=10_000_000, warmup_us=1_800_000_000)
+    gpu, cpu = _lib.new_sim(cfg), ol.oracle_sim(cfg)
+    for sim in (gpu, cpu):
+        sim.add_stream(ps)
+    starts = (34_202 + 1_800 + np.arange(n) % 60) * 1_000_000
+    og, oc = gpu.reset(starts, 0), cpu.reset(starts, 0)
+    assert np.array_equal(og, oc)
+    _assert_same_books(gpu, cpu, range(0, n, 7))
+    st = gpu.env_state(0)
+    assert st["status"] == 0 and st["n_buy_levels"] >= (340 if seconds_per_tick == 5.0 else 850), st["n_buy_levels"]
+    assert not any(gpu.env_state(e)["status"] for e in range(n))
+    # a few agent steps on top of the drifted book
+    rng = np.random.Generator(np.random.PCG64(3))
+    for t in range(20):
+        _step_compare(gpu, cpu, rng.uniform(0, 10, size=(n, 4)), t)
+    _assert_same_books(gpu, cpu, (0, 13, n - 1))
+    gpu.close()
+
+
+def _dev(arr):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(arr)).to("cuda:0")
+
+
+@pytest.mark.parametrize("path", ["ramp_up", "ramp_down", "triangle"])
+def test_drifting_stream_with_agent_whole_batch(path):
+    """256 envs x a full 30-minute episode (18 000 steps, random Beta-policy actions, the agent trading all the way) on a
+    stream that drifts one tick every 4 s, or oscillates +-150 ticks at one tick per 3 s.  The first 400 steps one
+    env.step() at a time: inventory, cash, price, done, observation and reward of EVERY env at every step.  The rest as
+    400-step launches (lobsim_rollout_device against oracle_rollout on the same pre-drawn actions): portfolio, done, last
+    observation / reward and episode return of every env after every launch.  Per-order books of a sample at the end; no
+    status bit; the drifting side ends with more than 400 levels (the oscillating path peaks near 300)."""
+    import torch
+
+    n, steps, single, chunk = 256, 18_000, 400, 400
+    p = {"ramp_up": ds.ramp_path(4.0), "ramp_down": ds.ramp_path(4.0, -1), "triangle": ds.triangle_path(150, 3.0)}[path]
+    ps = ds.drift_stream(21 + len(path), p, duration_s=1_900.0)
+    cfg = _capi.make_cfg(n, 10, _feats(), step_us=100_000, episode_us=1_800_000_000, warmup_us=10_000_000)
+    gpu, cpu = _lib.new_sim(cfg), ol.oracle_sim(cfg)
+    rng = np.random.Generator(np.random.PCG64(8))
+    starts = (34_212 + rng.integers(0, 40, size=n)) * 1_000_000
+    for sim in (gpu, cpu):
+        sim.add_stream(ps)
+        sim.set_portfolio(0, 10**12)
+    assert np.array_equal(gpu.reset(starts, 0), cpu.reset(starts, 0))
+    peak = 0
+    for t in range(single):
+        _step_compare(gpu, cpu, rng.uniform(0, 10, size=(n, 4)), t)
+    obs = torch.zeros((n, gpu.obs_dim), dtype=torch.float64, device="cuda:0")
+    reward = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    done = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+    ret = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    taken = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    for t in range(single, steps, chunk):
+        T = min(chunk, steps - t)
+        acts = rng.uniform(0, 10, size=(T, n, 4))
+        ret.zero_()
+        gpu.rollout_device(_capi.POLICY_GIVEN, [], T, _dev(acts).data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr(), ret.data_ptr(), taken.data_ptr())
+        gpu.sync()
+        oc = ol.oracle_rollout(cpu, _capi.POLICY_GIVEN, [], T, acts, want_actions=False)
+        assert np.array_equal(taken.cpu().numpy(), oc["steps"]) and np.array_equal(done.cpu().numpy(), oc["done"]), f"steps {t}..{t + T}"
+        for a, b, what in zip(gpu.portfolios(), cpu.portfolios(), ("inventory", "cash", "price")):
+            assert np.array_equal(a, b), f"steps {t}..{t + T}: {what} differs in envs {np.nonzero(a != b)[0][:8]}"
+        assert np.allclose(obs.cpu().numpy(), oc["obs"], rtol=1e-12, atol=1e-9) and np.allclose(reward.cpu().numpy(), oc["reward"], rtol=0, atol=1e-9)
+        assert np.allclose(ret.cpu().numpy(), oc["ret"], rtol=1e-12, atol=1e-6), f"steps {t}..{t + T}: episode returns"
+        st = gpu.env_state(int(rng.integers(0, n)))
+        peak = max(peak, st["n_buy_levels"], st["n_sell_levels"])
+    assert not any(gpu.env_state(e)["status"] for e in range(n))
+    assert done.cpu().numpy().all()
+    assert peak >= (250 if path == "triangle" else 400), peak
+    _assert_same_books(gpu, cpu, (0, 37, 128, n - 1))
+    gpu.close()
