@@ -36,7 +36,8 @@ HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md
 ENVS_PER_GPU = 4096
 STEP_US = 100_000
 EPISODE_US = 1_800_000_000  # 30 min, the reference default
-PROFILE_ROUND = "r2"
+PROFILE_ROUND = "r3"
+REPEATS = 5  # timed regions of --steps steps per invocation; `value` is the median region
 
 WORKLOADS = {
     "random": "4096 vectorised envs per GPU, synthetic 10-level SPY-shaped LOBSTER stream @1s snapshots, random Beta-policy actions (BASELINE.json configs[1])",
@@ -83,9 +84,78 @@ def build_stream(sim_seconds):
     return build_streams("random", sim_seconds)[0]
 
 
-def build_stream(sim_seconds):
-    """The configs[1] stream alone (tools/)."""
-    return build_streams("random", sim_seconds)[0]
+def shared_streams(workload, sim_seconds, rank, dist):
+    """The streams of a multi-rank job: local rank 0 generates them once and parks them as .npz, the others load them
+    (eight generators next to eight ranks on a box that grants 16 CPUs made every rank's set-up - and its first timed
+    steps - jittery).  One rank: just build."""
+    if dist is None:
+        return build_streams(workload, sim_seconds)
+    import tempfile
+
+    from rl4mm_amd.stream import PackedStream
+
+    n = len(DEEP50_RATES) if workload == "deep50" else 1
+    d = Path(tempfile.gettempdir()) / f"lobsim_bench_{os.environ.get('MASTER_PORT', '0')}_{workload}_{sim_seconds}"
+    if rank == 0:
+        d.mkdir(parents=True, exist_ok=True)
+        for i, s in enumerate(build_streams(workload, sim_seconds)):
+            s.save(d / f"stream{i}.npz")
+    dist.barrier()
+    streams = [PackedStream.load(d / f"stream{i}.npz") for i in range(n)]
+    dist.barrier()
+    if rank == 0:
+        import shutil
+
+        shutil.rmtree(d, ignore_errors=True)
+    return streams
+
+
+def timed_regions(step, K, repeats, first_step, dist, sync, make_events=None):
+    """`repeats` regions of exactly K steps, each bracketed by a barrier + device synchronise on both sides.  Per region the
+    job's time is the MAX over ranks of the rank's own clock around its K steps (all ranks released together by the opening
+    barrier; the closing barrier's own 50-100 us of RCCL launch is outside every rank's clock).  Returns (per-region job
+    times [R] in seconds, this rank's times [R], per-region event times in ms or None)."""
+    import torch
+
+    local, ev_ms = [], []
+    gc.collect()
+    gc.disable()  # (a cyclic collection inside a 0.7 ms region would be a third of it)
+    for r in range(repeats):
+        evs = make_events() if make_events else None
+        if dist:
+            dist.barrier()
+        sync()
+        if evs:
+            evs[0].record()  # on the idle stream, just ahead of the clock: instrumentation, not steps
+        t0 = time.perf_counter()
+        for t in range(K):
+            step(first_step + r * K + t)
+        if evs:
+            evs[1].record()
+        sync()
+        local.append(time.perf_counter() - t0)
+        if dist:
+            dist.barrier()  # the closing side of the bracket: every rank is done before anything else happens
+        sync()
+        if evs:
+            ev_ms.append(evs[0].elapsed_time(evs[1]))
+    gc.enable()
+    mine = torch.tensor(local, dtype=torch.float64)
+    job = mine.clone()
+    if dist:
+        dev = None if dist.get_backend() == "gloo" else torch.device("cuda", torch.cuda.current_device())
+        job = job.to(dev) if dev else job
+        dist.all_reduce(job, op=dist.ReduceOp.MAX)
+        job = job.cpu()
+    return job.tolist(), local, (ev_ms if make_events else None)
+
+
+def region_summary(job_times, K):
+    """median / min / max region of a run, as ms per step"""
+    srt = sorted(job_times)
+    med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+    return med, {"repeats": len(srt), "ms_per_step_min": srt[0] / K * 1e3, "ms_per_step_max": srt[-1] / K * 1e3,
+                 "ms_per_step_regions": [round(x / K * 1e3, 5) for x in job_times]}  # fmt: skip
 
 
 def workload_cfg(capi, workload, n_envs, device_id=0):
@@ -211,6 +281,48 @@ def cpu_baseline(workload, budget_s=10.0):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# the Python boundary (reported beside `value`, never as it)
+# ---------------------------------------------------------------------------------------------------------------------
+def facade_leg(sim, stream, n_envs, device_id, steps=60):
+    """env-steps/s through the API the reference's callers hold: HistoricalOrderbookVectorEnv.vector_step_arrays (numpy in,
+    numpy out: actions cross PCIe to the device, observations / rewards / dones back, every step), the same through RLlib's
+    list-shaped vector_step, and the C-ABI's host-pointer lobsim_step underneath them; plus vector_reset (start draws on
+    the host + 3000 warm-up steps per env on the device)."""
+    from datetime import datetime, timedelta
+
+    from rl4mm_amd import env as E
+
+    rng = np.random.Generator(np.random.PCG64(7))
+    acts = rng.uniform(0, 10, size=(steps + 5, n_envs, 4))
+    out = {"unit": "env-steps/s", "steps": steps, "envs": n_envs, "note": "host numpy arrays in and out every step (PCIe inclusive); `value` is the device-pointer entry"}
+
+    def rate(fn):
+        for t in range(5):
+            fn(acts[t])
+        t0 = time.perf_counter()
+        for t in range(steps):
+            fn(acts[5 + t])
+        return n_envs * steps / (time.perf_counter() - t0)
+
+    out["lobsim_step_host_pointers"] = rate(lambda a: sim.step(a))
+    day = datetime.strptime(stream.trading_date, "%Y-%m-%d")
+    venv = E.HistoricalOrderbookVectorEnv(
+        n_envs, E.StreamCatalog().add(stream), ticker=stream.ticker, n_levels=stream.n_levels, min_date=day, max_date=day,
+        min_start_timedelta=timedelta(hours=10), max_end_timedelta=timedelta(hours=10, minutes=31), episode_length=timedelta(minutes=30),
+        initial_portfolio=E.Portfolio(inventory=0, cash=10**12), per_step_reward_function=E.PnL(), terminal_reward_function=E.PnL(), device_id=device_id, max_levels=128,
+    )  # fmt: skip
+    np.random.seed(11)
+    venv.vector_reset_arrays()
+    t0 = time.perf_counter()
+    venv.vector_reset_arrays()
+    out["vector_reset_ms"] = (time.perf_counter() - t0) * 1e3
+    out["vector_step_arrays"] = rate(lambda a: venv.vector_step_arrays(a))
+    out["vector_step_lists"] = rate(lambda a: venv.vector_step(a))
+    venv.close()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # multi-GPU launcher
 # ---------------------------------------------------------------------------------------------------------------------
 def _free_port():
@@ -228,30 +340,33 @@ def launch_ranks(n, argv):
 
 
 def stub_rank(args, rank, world):
-    """CPU stand-in of one rank (tests/test_host_logic.py): same launcher, same barrier / max-over-ranks timing, same
-    episode-return gather - over gloo, with a step that only fills the return vector."""
+    """CPU stand-in of one rank (tests/test_host_logic.py): same launcher, same timed_regions harness (barriers, max over
+    ranks per region, median region), same stream hand-over and episode-return gather - over gloo, with a step that only
+    fills the return vector."""
     import torch
     import torch.distributed as dist
 
     from rl4mm_amd.dist import gather_episode_returns, shard_range
 
     dist.init_process_group("gloo")
+    streams = shared_streams("random", 1, rank, dist)
     lo, hi = shard_range(world * args.envs, rank, world)
     returns = torch.zeros(hi - lo, dtype=torch.float64)
-    dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        returns += torch.arange(lo, hi, dtype=torch.float64)
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)  # this rank's own clock; the job's time is the MAX over ranks
-    dist.barrier()
-    per_rank = [torch.zeros_like(el) for _ in range(world)]
-    dist.all_gather(per_rank, el)
-    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+
+    def step(t):
+        returns.add_(torch.arange(lo, hi, dtype=torch.float64))
+
+    job, local, _ = timed_regions(step, args.steps, args.repeats, 0, dist, lambda: None)
+    med, summary = region_summary(job, args.steps)
+    mine = torch.tensor([sorted(local)[len(local) // 2] / args.steps * 1e3], dtype=torch.float64)
+    per_rank = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(per_rank, mine)
     allr = gather_episode_returns(returns)
     if rank == 0:
-        ok = bool(torch.equal(allr, args.steps * torch.arange(world * args.envs, dtype=torch.float64)))
-        print(json.dumps({"metric": "stub", "n_gpus": world, "steps": args.steps, "gathered_returns": int(allr.numel()), "gather_in_env_order": ok,
-                          "ms_per_step_per_rank": [float(x.item()) / args.steps * 1e3 for x in per_rank]}))  # fmt: skip
+        ok = bool(torch.equal(allr, args.steps * args.repeats * torch.arange(world * args.envs, dtype=torch.float64)))
+        print(json.dumps({"metric": "stub", "n_gpus": world, "steps": args.steps, "ms_per_step": med / args.steps * 1e3, **summary,
+                          "gathered_returns": int(allr.numel()), "gather_in_env_order": ok, "stream_msgs": int(streams[0].n_msgs),
+                          "ms_per_step_per_rank": [float(x.item()) for x in per_rank]}))  # fmt: skip
     dist.barrier()
     dist.destroy_process_group()
 
@@ -268,6 +383,8 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of all-core CPU work in the cpu_baseline sample")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # CPU test of the launcher (gloo, no lobsim)
+    ap.add_argument("--repeats", type=int, default=REPEATS, help="timed regions of --steps steps; `value` is the median region")
+    ap.add_argument("--no-facade", action="store_true", help="skip the Python-boundary leg (VectorEnv.vector_step_arrays, host-pointer lobsim_step)")
     args = ap.parse_args()
     if args.envs is None:
         args.envs = 8192 if args.workload == "deep50" else ENVS_PER_GPU
@@ -297,10 +414,12 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    K, W, N, wl = args.steps, args.warmup, args.envs, args.workload
+    K, W, N, wl, R = args.steps, args.warmup, args.envs, args.workload, max(1, args.repeats)
+    if os.environ.get("LOBSIM_LIB") and rank == 0:
+        print(f"bench.py: LOBSIM_LIB override active, running {os.environ['LOBSIM_LIB']} (no staleness check)", file=sys.stderr)
 
-    sim_seconds = (2 * K + W) * STEP_US // 1_000_000 + 1  # the timed steps, then the open-loop rollout leg's K more
-    streams = build_streams(wl, sim_seconds)
+    sim_seconds = ((R + 1) * K + W) * STEP_US // 1_000_000 + 8  # the timed regions, the open-loop rollout leg's K more, the facade leg
+    streams = shared_streams(wl, sim_seconds, rank, dist)
     cfg = workload_cfg(_capi, wl, N, device_id=local_rank)
     sim = _lib.new_sim(cfg)
     # kernels run on a torch-owned (non-default) stream so the torch.cuda.Event pairs below time exactly them
@@ -327,10 +446,10 @@ def main():
         def step(t):  # one env.step() per env per launch, the rule-based agent's action computed in the kernel prologue
             sim.rollout_device(_capi.POLICY_TERADACTYL, TERADACTYL_PARAMS, 1, 0, 0, *out_ptrs, 0)
     else:
-        acts = torch.from_numpy(np.random.Generator(np.random.PCG64(42 + rank)).uniform(0, 10, size=(K + W, N, 4))).to(dev)
+        acts = torch.from_numpy(np.random.Generator(np.random.PCG64(42 + rank)).uniform(0, 10, size=(R * K + W, N, 4))).to(dev)
         # device addresses worked out ahead of the timed region (a short region - the driver times 20 steps - would otherwise
         # charge the tensor indexing of its first step as GPU idle time)
-        act_ptrs = [acts[t].data_ptr() for t in range(K + W)]
+        act_ptrs = [acts[t].data_ptr() for t in range(R * K + W)]
         out_ptrs = (obs.data_ptr(), obs32.data_ptr(), reward.data_ptr(), done.data_ptr(), returns.data_ptr())
 
         def step(t):  # one launch of lob_step_kernel over the rank's envs; the episode return is accumulated in its epilogue
@@ -339,34 +458,19 @@ def main():
     for t in range(W):
         step(t)
     returns.zero_()
-    # HIP events on the launch stream: one pair around the whole timed region (back-to-back launches of the one kernel)
-    ev_all = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-    for ev in ev_all:
+    # HIP events on the launch stream: one pair around each timed region (back-to-back launches of the one kernel)
+    warm_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    for ev in warm_ev:
         ev.record()  # a dry run: the very first timed event record of a process takes ~50 us on the host (lazy set-up of the
                      # profiling signals) - as much as 1.5 steps of a 20-step region - and none afterwards
     torch.cuda.synchronize()
-    gc.collect()
-    gc.disable()  # (a cyclic collection inside a 0.7 ms region would be a third of it)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev_all[0].record()  # on the idle stream, just ahead of the clock: instrumentation, not steps (recorded after t0 it held the
-                        # first launch back: 38.2 instead of 36.0 us per step over a 20-step region)
-    t0 = time.perf_counter()
-    for t in range(K):
-        step(W + t)
-    ev_all[1].record()
-    torch.cuda.synchronize()
-    local_elapsed = time.perf_counter() - t0
-    gc.enable()
-    if dist:
-        dist.barrier()  # the closing side of the bracket: every rank is done before anything else happens
-    torch.cuda.synchronize()
-    # The job's time is the MAX over ranks of each rank's own clock around its K steps (both ends behind a device synchronise,
-    # all ranks released together by the opening barrier).  The closing barrier's own latency - 50-100 us of RCCL launch on a
-    # 0.7 ms region of the driver's 20-step run - is not part of any rank's K steps.
-    elapsed = local_elapsed
-    kernel_ms = ev_all[0].elapsed_time(ev_all[1]) / K  # average launch duration over the timed region (back-to-back launches)
+    job_times, local_times, ev_ms = timed_regions(step, K, R, W, dist, torch.cuda.synchronize,
+                                                  lambda: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+    # `value` = the MEDIAN region (each region is K steps inside its own barrier + synchronise bracket, its time the MAX over
+    # ranks): one host hiccup inside a 0.7 ms region - the driver's 20-step form - no longer decides the number
+    elapsed, region_stats = region_summary(job_times, K)
+    local_elapsed = sorted(local_times)[len(local_times) // 2]
+    kernel_ms = sorted(ev_ms)[len(ev_ms) // 2] / K  # average launch duration over the median region (back-to-back launches)
 
     # extra (not `value`): K more steps as ONE launch (lobsim_rollout_device) - the mode the reference's rule-based
     # baseline sweeps can use; no per-step launch tail, state stays on chip
@@ -389,9 +493,6 @@ def main():
     if dist:
         from rl4mm_amd.dist import gather_episode_returns
 
-        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        elapsed = float(el.item())
         mine = torch.tensor([local_elapsed / K * 1e3], dtype=torch.float64, device=dev)
         allms = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allms, mine)
@@ -418,7 +519,7 @@ def main():
         kernel = "lob_step_kernel"  # (Teradactyl: lobsim_rollout_device with T = 1 runs the step kernel, the policy in its prologue)
         out = {
             "metric": "env-steps/sec (batched LOB sims)", "value": world * N * K / elapsed, "unit": "env-steps/s",
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, **region_stats, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int64+f64", "data": "synthetic",
             "config": {
                 "workload": WORKLOADS[wl], "envs_per_gpu": N, "global_envs": world * N, "features": "full_state (10 default features, 5 min warm-up)",
@@ -437,6 +538,10 @@ def main():
                 "value": rollout[1] / (rollout[0] * 1e-3), "unit": "env-steps/s (rank 0)", "steps_per_launch": K, "launch_ms": rollout[0],
                 "note": "lob_rollout_kernel: K steps per env in one launch; reported beside, never as, `value`",
             }
+        if os.environ.get("LOBSIM_LIB"):
+            out["config"]["lobsim_lib_override"] = os.environ["LOBSIM_LIB"]
+        if world == 1 and wl == "random" and not args.no_facade:
+            out["facade"] = facade_leg(sim, streams[0], N, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_budget)
         print(json.dumps(out))

@@ -248,8 +248,10 @@ enum lobsim_info_col {
  * info_calculator=None).  Rows of envs that did not step keep their previous contents. */
 int lobsim_set_info_buffer(lobsim_t* h, double* d_info);
 /* Per-step series of a multi-step launch, the columns get_episode_summary_dict reads (rl4mm/gym/utils.py:145-198):
- * d_trace: DEVICE buffer [t_capacity][n_envs][LOBSIM_TRACE_DIM] f64; lobsim_rollout_device (T <= t_capacity) writes row t of
- * every env that took step t.  NULL: off. */
+ * d_trace: DEVICE buffer [t_capacity][n_envs][LOBSIM_TRACE_DIM] f64; lobsim_rollout_device (1 <= T <= t_capacity) writes row t of
+ * every env that took step t.  A step that ends with a status bit (the reference would have raised there) counts in
+ * d_steps_taken - the env did step, into its error state - but writes NO row: pre-fill the buffer with NaN and the failed
+ * step shows as a NaN row.  NULL: off. */
 enum lobsim_trace_col {
     LOBSIM_TRACE_REWARD = 0,
     LOBSIM_TRACE_AUM = 1,

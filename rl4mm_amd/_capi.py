@@ -289,9 +289,9 @@ class Sim:
     def step(self, actions, active=None):
         actions = np.ascontiguousarray(actions, dtype=np.float64).reshape(self.n_envs, self.action_dim)
         act = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
-        obs = np.zeros((self.n_envs, self.obs_dim), dtype=np.float64)
-        reward = np.zeros(self.n_envs, dtype=np.float64)
-        done = np.zeros(self.n_envs, dtype=np.uint8)
+        obs = np.empty((self.n_envs, self.obs_dim), dtype=np.float64)  # (the call writes all three in full)
+        reward = np.empty(self.n_envs, dtype=np.float64)
+        done = np.empty(self.n_envs, dtype=np.uint8)
         self._check(self.b.fn["step"](self.h, _ptr(actions, _PD), _ptr(act, _PU8), _ptr(obs, _PD), _ptr(reward, _PD), _ptr(done, _PU8)), "step")
         return obs, reward, done
 

@@ -213,7 +213,7 @@ struct Scal {
     int32_t status;
     int32_t n_ops;
     uint32_t ladder_ver;    // bumped whenever a level is opened or removed (indices into the ladder shift)
-    int32_t msgs_step;      // messages replayed in this step so far (is this a light step? see squeeze_ahead) ...
+    int32_t msgs_step = 0;  // messages replayed in this step so far (is this a light step? see squeeze_ahead) ...
     bool ahead = false;     // ... and does this kernel squeeze ahead of time at all (the per-step kernel does: it is the one whose
                             // launches end with their slowest env; a multi-step launch only pays for the extra squeezes)
     int64_t q_buy, q_sell;  // best prices the current op list was built against (_get_best_prices)

@@ -12,8 +12,11 @@ Same names, constructor arguments and return shapes as the reference so it drops
 * ``StreamCatalog``                       replaces ``HistoricalDatabase`` as the data source: packed (ticker, day)
   streams (rl4mm_amd/stream.py)
 
-`gym` and `ray` are optional: spaces fall back to a minimal Box with the attributes RLlib and the reference's
-agents read (low, high, shape, dtype, sample, seed).
+`gym` and `ray` are optional.  When they import, ``HistoricalOrderbookEnvironment`` IS a ``gym.Env`` and
+``HistoricalOrderbookVectorEnv`` IS a ``ray.rllib.env.VectorEnv`` (RLlib's env check accepts nothing else), spaces are
+``gym.spaces.Box`` and ``env_creator`` sets ``env.spec = EnvSpec(id, max_episode_steps)`` like the reference
+(rl4mm/gym/utils.py:83-86).  Without them the bases are plain classes and spaces fall back to a minimal Box with the
+attributes RLlib and the reference's agents read (low, high, shape, dtype, sample, seed).
 """
 from __future__ import annotations
 
@@ -50,6 +53,41 @@ except Exception:  # noqa: BLE001
 
         def contains(self, x):
             return bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+
+try:  # the bases RLlib checks for (ray.rllib.env.base_env convert_to_base_env / check_env accept gym.Env and VectorEnv only)
+    import gym as _gym  # type: ignore
+
+    _GymEnv = _gym.Env
+except Exception:  # noqa: BLE001
+    _gym = None
+    _GymEnv = object
+try:
+    from ray.rllib.env.vector_env import VectorEnv as _RayVectorEnv  # type: ignore
+except Exception:  # noqa: BLE001
+    _RayVectorEnv = object
+
+
+class _EnvSpec:
+    """gym.envs.registration.EnvSpec's two fields the reference sets (rl4mm/gym/utils.py:83-86); used when gym is absent."""
+
+    def __init__(self, id, max_episode_steps=None):  # noqa: A002 - gym's own argument name
+        self.id, self.max_episode_steps = id, max_episode_steps
+
+    def __repr__(self):
+        return f"EnvSpec({self.id})"
+
+
+def make_env_spec(episode_length: timedelta, step_size: timedelta):
+    steps = episode_length / step_size  # a float, like the reference's `episode_length / timedelta(seconds=step_size)`
+    if _gym is not None:
+        try:
+            from gym.envs.registration import EnvSpec  # type: ignore
+
+            return EnvSpec(id="HistoricalOrderbookEnvironment-v0", max_episode_steps=steps)
+        except Exception:  # noqa: BLE001
+            pass
+    return _EnvSpec(id="HistoricalOrderbookEnvironment-v0", max_episode_steps=steps)
 
 
 US = timedelta(microseconds=1)
@@ -300,6 +338,17 @@ class SimpleInfoCalculator:
         costs one device-to-host copy instead of bulk getters plus a host-side Beta evaluation."""
         import torch
 
+        # The kernel works the info out from the ENV's configuration (its quote levels, enter_spread, concentration, clearing
+        # fraction); the reference's calculator carries its own copies of those (InfoCalculators.py:17-29).  Only when they
+        # say the same do the device rows equal what this object would compute on the host: otherwise stay on the host path.
+        c = sim.cfg
+        same = (self.quote_levels == c.max_quote_level - c.min_quote_level and c.min_quote_level == 0 and self.active_volume == 100
+                and bool(self.enter_spread) == bool(c.enter_spread)
+                and (self.concentration is None) == (not c.use_concentration) and (self.concentration is None or float(self.concentration) == c.concentration)
+                and (not c.market_order_clearing or float(self.market_order_fraction_of_inventory) == c.market_order_fraction_of_inventory))
+        if not same:
+            self._device_rows = None
+            return self
         self._device_rows = torch.zeros((sim.n_envs, _capi.INFO_DIM), dtype=torch.float64, device=torch.device("cuda", sim.cfg.device_id))
         torch.cuda.synchronize()
         sim.set_info_buffer(self._device_rows.data_ptr())
@@ -397,8 +446,13 @@ class StreamCatalog:
 # ---------------------------------------------------------------------------------------------------------------
 # environments
 # ---------------------------------------------------------------------------------------------------------------
-class HistoricalOrderbookVectorEnv:
-    """N independent copies of the reference env stepped by one kernel launch (RLlib VectorEnv shape)."""
+class HistoricalOrderbookVectorEnv(_RayVectorEnv):
+    """N independent copies of the reference env stepped by one kernel launch: a ``ray.rllib.env.VectorEnv`` when ray imports.
+
+    ``vector_reset / reset_at / vector_step`` have RLlib's list-of-per-env-values shape.  A caller that wants the batch
+    as it comes off the device uses the ARRAY path: ``vector_reset_arrays() -> obs[N, D]``,
+    ``vector_step_arrays(actions[N, A]) -> (obs[N, D], reward[N], done[N] bool, infos or None)`` - no per-env Python objects
+    (building 4 x 4096 list entries costs 35 x the kernel)."""
 
     def __init__(
         self,
@@ -429,6 +483,7 @@ class HistoricalOrderbookVectorEnv:
         outer_levels: int = 20,
         device_id: int = 0,
         ladder_levels: int = 0,
+        max_levels: int = 0,
     ):
         # action space, HistoricalOrderbookEnvironment.py:85-94
         if concentration is not None:
@@ -466,10 +521,13 @@ class HistoricalOrderbookVectorEnv:
             concentration=concentration, market_order_clearing=market_order_clearing, market_order_fraction_of_inventory=market_order_fraction_of_inventory,
             enter_spread=enter_spread, inc_prev_action_in_obs=inc_prev_action_in_obs, per_step_reward=self.per_step_reward_function.desc(),
             terminal_reward=self.terminal_reward_function.desc(), device_id=device_id,
-            ladder_levels=ladder_levels,  # price levels per side an env can hold (0 = 64 for books of <= 16 visible levels, else 128): the
-                                          # reference keeps stale levels that left LOBSTER's visible range for the rest of the episode, so a
-                                          # strongly trending day wants 128; beyond the capacity an env stops with LOBSIM_ST_LEVEL_OVERFLOW
+            ladder_levels=ladder_levels,  # price levels per side kept ON CHIP (0 = 64 for books of <= 16 visible levels, else 128): a performance knob
+            max_levels=max_levels,  # price levels per side an env can hold in all (0 = 1024 if memory allows): the reference keeps stale levels that left
+                                    # LOBSTER's visible range for the rest of the episode - one per tick of price drift; beyond it an env stops with
+                                    # LOBSIM_ST_LEVEL_OVERFLOW
         )  # fmt: skip
+        if _RayVectorEnv is not object:
+            super().__init__(self.observation_space, self.action_space, num_envs)
         self.sim = _lib.new_sim(cfg)  # raises if the HIP library or the GPU is missing: there is no CPU path
         self._stream_ids: Dict[Tuple[str, str], int] = {}
         for key, stream in catalog.items():
@@ -479,6 +537,8 @@ class HistoricalOrderbookVectorEnv:
         assert float(cash) == int(cash), "cash must be integer valued (it is kept exact as int64)"
         self.sim.set_portfolio(int(self.initial_portfolio.inventory), int(cash))
         self._dones = np.zeros(num_envs, dtype=bool)
+        self._any_done = False
+        self._day_table = None
 
     # ---- start-time draw: same np.random calls, in the same order, as the reference (:196, :333-351) -------------
     def _random_offset_timestamp(self) -> timedelta:
@@ -500,7 +560,8 @@ class HistoricalOrderbookVectorEnv:
     def _get_random_start_time(self) -> datetime:
         return self._get_random_trading_day() + self._random_offset_timestamp()
 
-    def _draw(self, n: int):
+    def _draw_slow(self, n: int):
+        """One env at a time through the reference's own call sequence (the definition the batched draw is tested against)."""
         sids, starts = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int64)
         for i in range(n):
             t = self._get_random_start_time()
@@ -511,12 +572,114 @@ class HistoricalOrderbookVectorEnv:
             starts[i] = _us(t - datetime.combine(t.date(), datetime.min.time()))
         return sids, starts
 
-    # ---- VectorEnv API ------------------------------------------------------------------------------------------
-    def vector_reset(self) -> List[np.ndarray]:
+    def _day_lookup(self):
+        """Per candidate business day (pd.bdate_range(min_date, max_date), what np.random.choice draws from): the stream of
+        the NASDAQ session it maps to (-1: not loaded)."""
+        if self._day_table is None:
+            from .trading_calendar import get_next_trading_dt
+
+            days = pd.bdate_range(self.min_date, self.max_date)
+            sid = np.full(len(days), -1, dtype=np.int32)
+            keys = []
+            for i, d in enumerate(days):
+                key = (self.ticker, get_next_trading_dt(pd.to_datetime(d).to_pydatetime()).strftime("%Y-%m-%d"))
+                keys.append(key)
+                sid[i] = self._stream_ids.get(key, -1)
+            self._day_table = (sid, keys)
+        return self._day_table
+
+    def _draw(self, n: int):
+        """Start day and start second of n episodes with the global ``np.random`` state advanced exactly as n calls of the
+        reference's ``_get_random_start_time`` advance it (HistoricalOrderbookEnvironment.py:196,333-351): per env one
+        ``np.random.choice`` over the business days, then one ``np.random.randint`` over the start offsets.  Legacy
+        ``RandomState.randint(0, m)`` draws 32-bit words, masks them to the next power of two and rejects values >= m (no
+        word at all when m == 1): the words of all n envs are pulled in one call and the accept / reject walk is replayed
+        here, then the generator is wound to the word the last env stopped at.  ~4 ms for 4096 envs instead of 0.5 s."""
+        day_sid, day_keys = self._day_lookup()
+        n_days = len(day_sid)
+        max_offset_steps = int((self.max_end_timedelta - self.episode_length - self.min_start_timedelta) / self.step_size)
+        if n_days == 0:
+            raise ValueError("'a' cannot be empty unless no samples are taken")  # np.random.choice of an empty range
+        if n == 0:
+            return np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int64)
+        if max(n_days, max_offset_steps) > 0xFFFFFFFF:
+            return self._draw_slow(n)
+
+        def mask_of(m):  # smallest 2^k - 1 >= m - 1
+            r, k = m - 1, 0
+            while (1 << k) - 1 < r:
+                k += 1
+            return (1 << k) - 1
+
+        need_day, need_off = n_days > 1, max_offset_steps > 1  # (m <= 1: the value is 0 and no word is drawn; m <= 0 raises -> 0)
+        rs = np.random.mtrand._rand  # the global legacy generator the reference uses
+        state0 = rs.get_state()
+        day = np.zeros(n, dtype=np.int64)
+        off = np.zeros(n, dtype=np.int64)
+        if need_day or need_off:
+            md, mo = mask_of(n_days) if need_day else 0, mask_of(max_offset_steps) if need_off else 0
+            # expected words per env, with head-room; more are pulled if the walk runs out
+            per_env = (need_day * (md + 1) / max(n_days, 1)) + (need_off * (mo + 1) / max(max_offset_steps, 1))
+            k_words = int(n * per_env * 1.25) + 64
+            while True:
+                rs.set_state(state0)
+                words = np.frombuffer(rs.bytes(4 * k_words), dtype="<u4")
+                vd = (words & md).tolist() if need_day else None
+                vo = (words & mo).tolist() if need_off else None
+                p, ok = 0, True
+                dl, ol = [0] * n, [0] * n
+                try:
+                    for i in range(n):
+                        if need_day:
+                            while vd[p] >= n_days:
+                                p += 1
+                            dl[i] = vd[p]
+                            p += 1
+                        if need_off:
+                            while vo[p] >= max_offset_steps:
+                                p += 1
+                            ol[i] = vo[p]
+                            p += 1
+                except IndexError:
+                    ok = False
+                if ok:
+                    break
+                k_words *= 2
+            rs.set_state(state0)
+            if p:
+                rs.bytes(4 * p)  # exactly the words the n envs consumed
+            day[:] = dl
+            off[:] = ol
+        sids = day_sid[day]
+        if (sids < 0).any():
+            raise KeyError(f"no packed stream loaded for {day_keys[int(day[np.nonzero(sids < 0)[0][0]])]}")
+        start_us = _us(self.min_start_timedelta) + off * _us(self.step_size)
+        return sids.astype(np.int32), (start_us // 1_000_000) * 1_000_000  # "start episode on sec" (:341)
+
+    # ---- array path ------------------------------------------------------------------------------------------------
+    def vector_reset_arrays(self) -> np.ndarray:
         sids, starts = self._draw(self.num_envs)
         obs = self.sim.reset(starts, sids)
         self._dones[:] = False
-        return list(obs)
+        self._any_done = False
+        return obs
+
+    def vector_step_arrays(self, actions, want_infos: bool = True):
+        """-> (obs f64[N, D], reward f64[N], done bool[N], infos).  infos is None when there is no info calculator (the
+        reference's default) or when not asked for."""
+        actions = np.asarray(actions, dtype=np.float64)
+        active = (~self._dones).view(np.uint8) if self._any_done else None  # (nothing to mask until an env has finished)
+        obs, reward, done = self.sim.step(actions, active=active)
+        done = done.view(np.bool_)
+        if done.any():
+            self._dones |= done
+            self._any_done = True
+        infos = self.info_calculator.calculate_dicts(self.sim, actions) if (want_infos and self.info_calculator is not None) else None
+        return obs, reward, done, infos
+
+    # ---- VectorEnv API ------------------------------------------------------------------------------------------
+    def vector_reset(self) -> List[np.ndarray]:
+        return list(self.vector_reset_arrays())
 
     def reset_at(self, index: Optional[int] = None) -> np.ndarray:
         index = 0 if index is None else index
@@ -527,13 +690,14 @@ class HistoricalOrderbookVectorEnv:
         sids, starts = self._draw(len(ids))
         obs = self.sim.reset(starts, sids, ids)
         self._dones[ids] = False
+        self._any_done = bool(self._dones.any())
         return obs
 
     def vector_step(self, actions):
-        obs, reward, done = self.sim.step(np.asarray(actions, dtype=np.float64), active=(~self._dones).astype(np.uint8))
-        self._dones |= done.astype(bool)
-        infos = [{} for _ in range(self.num_envs)] if self.info_calculator is None else self.info_calculator.calculate_dicts(self.sim, actions)
-        return list(obs), list(reward), list(done.astype(bool)), infos
+        obs, reward, done, infos = self.vector_step_arrays(actions)
+        if infos is None:
+            infos = [{} for _ in range(self.num_envs)]
+        return list(obs), reward.tolist(), done.tolist(), infos
 
     def get_sub_environments(self):
         return []
@@ -546,8 +710,9 @@ class HistoricalOrderbookVectorEnv:
         self.sim.close()
 
 
-class HistoricalOrderbookEnvironment:
-    """Single-env facade with the reference's gym.Env surface (reset / step / seed / render / spaces)."""
+class HistoricalOrderbookEnvironment(_GymEnv):
+    """Single-env facade with the reference's gym.Env surface (reset / step / seed / render / spaces); a ``gym.Env`` when gym
+    imports (rl4mm/gym/HistoricalOrderbookEnvironment.py:51)."""
 
     metadata = {"render.modes": ["human"]}
 
@@ -581,8 +746,8 @@ class HistoricalOrderbookEnvironment:
             raise AssertionError("Order volume must be positive.")
         hints = []
         if status & _capi.ST_LEVEL_OVERFLOW:
-            hints.append("more price levels on one side than the ladder holds (the reference never drops a level that left LOBSTER's visible "
-                         "range): pass ladder_levels=128, or shorten the episode")
+            hints.append("more price levels than cfg.max_levels provides slabs for (the reference never drops a level that left LOBSTER's "
+                         "visible range: one stale level per tick of price drift): pass a larger max_levels (up to 2048), or shorten the episode")
         if status & _capi.ST_QUEUE_OVERFLOW:
             hints.append("more than 512 live orders at one price")
         if status & _capi.ST_AGENT_OVERFLOW:
@@ -635,9 +800,9 @@ def env_creator(env_config: dict, catalog: StreamCatalog = None, num_envs: Optio
         enter_spread=env_config["enter_spread"], info_calculator=env_config.get("info_calculator"), n_levels=env_config["n_levels"],
     )  # fmt: skip
     n = num_envs or env_config.get("num_envs", 1)
-    if n > 1:
-        return HistoricalOrderbookVectorEnv(n, catalog, **kw)
-    return HistoricalOrderbookEnvironment(catalog=catalog, **kw)
+    env = HistoricalOrderbookVectorEnv(n, catalog, **kw) if n > 1 else HistoricalOrderbookEnvironment(catalog=catalog, **kw)
+    env.spec = make_env_spec(episode_length, step_size)  # rl4mm/gym/utils.py:83-86
+    return env
 
 
 def generate_trajectory(agent, env):

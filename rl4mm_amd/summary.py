@@ -34,7 +34,8 @@ def policy_of(agent, action_dim: int, n_envs: int, n_steps: int):
 
 def generate_trajectories(agent, venv, n_steps: Optional[int] = None) -> Dict[str, np.ndarray]:
     """One episode of every env of ``venv`` (HistoricalOrderbookVectorEnv) under ``agent``, in one launch.
-    -> dict(steps [N], trace [T, N, TRACE_DIM] (rows beyond an env's steps are NaN), final observation / reward / done)."""
+    -> dict(steps [N], trace [T, N, TRACE_DIM], final observation / reward / done).  Trace rows beyond an env's steps are NaN; so
+    is the row of a step that ended with a status bit (counted in `steps`, where the reference would have raised)."""
     import torch
 
     sim, n = venv.sim, venv.num_envs
@@ -55,6 +56,7 @@ def generate_trajectories(agent, venv, n_steps: Optional[int] = None) -> Dict[st
     finally:
         sim.set_trace_buffer(0, 0)
     venv._dones[:] = done.cpu().numpy().astype(bool)
+    venv._any_done = bool(venv._dones.any())
     return dict(steps=steps.cpu().numpy(), trace=trace.cpu().numpy(), observations=obs.cpu().numpy(), rewards=reward.cpu().numpy(), dones=done.cpu().numpy().astype(bool))
 
 

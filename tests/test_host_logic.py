@@ -124,10 +124,12 @@ def test_episode_return_gather_world_size_2_gloo():
         assert np.array_equal(res[r], np.arange(n_total) * 0.5)
 
 
-def test_bench_gpus_flag_launches_ranks_gloo_stub():
-    """`python bench.py --gpus 2` (no torchrun around it) must itself start 2 ranks: the launcher path of bench.py with
-    the CPU stand-in step (gloo) - rank 0 prints one JSON line with n_gpus = 2 and the gathered return vector of both
-    ranks in env order."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_gpus_flag_launches_ranks_gloo_stub(world):
+    """`python bench.py --gpus N` (no torchrun around it) must itself start N ranks: the launcher path of bench.py with
+    the CPU stand-in step (gloo) through the SAME harness as the GPU run - the stream generated once by rank 0 and handed to
+    the others, five timed regions each inside its own barrier pair, the region time the MAX over ranks, the reported time
+    the median region.  Rank 0 prints one JSON line with n_gpus = N and the gathered return vector of all ranks in env order."""
     import json
     import subprocess
     import sys
@@ -135,13 +137,16 @@ def test_bench_gpus_flag_launches_ranks_gloo_stub():
 
     root = Path(__file__).resolve().parent.parent
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--stub", "--steps", "3", "--envs", "37"], env=env,
-                       capture_output=True, text=True, timeout=300)  # fmt: skip
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", str(world), "--stub", "--steps", "3", "--envs", "37", "--repeats", "5"], env=env,
+                       capture_output=True, text=True, timeout=600)  # fmt: skip
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["gathered_returns"] == 74 and out["gather_in_env_order"] and len(out["ms_per_step_per_rank"]) == 2
+    assert out["n_gpus"] == world and out["gathered_returns"] == 37 * world and out["gather_in_env_order"] and len(out["ms_per_step_per_rank"]) == world
+    assert out["repeats"] == 5 and len(out["ms_per_step_regions"]) == 5 and out["stream_msgs"] > 0
+    assert out["ms_per_step_min"] <= out["ms_per_step"] <= out["ms_per_step_max"]
+    assert out["ms_per_step"] == pytest.approx(sorted(out["ms_per_step_regions"])[2], abs=1e-4)
 
 
 def test_nasdaq_trading_calendar():
@@ -221,3 +226,177 @@ def test_id_suffix_order_equals_string_sort():
         ids = np.arange(n) + (np.arange(n) // batch) * batch
         ref = np.lexsort((np.array([str(int(i)) for i in ids]), t))
         assert np.array_equal(_id_suffix_order(t, ids), ref)
+
+
+def _bare_vector_env(min_date, max_date, episode_minutes, step_seconds):
+    """A HistoricalOrderbookVectorEnv without a device handle: enough of it for the start-time draw."""
+    import pandas as pd
+
+    from rl4mm_amd.env import HistoricalOrderbookVectorEnv as V
+    from rl4mm_amd.trading_calendar import get_next_trading_dt
+
+    env = V.__new__(V)
+    env.ticker, env._day_table = "SYN", None
+    env.min_date, env.max_date = min_date, max_date
+    env.min_start_timedelta, env.max_end_timedelta = timedelta(hours=10), timedelta(hours=15, minutes=30)
+    env.episode_length, env.step_size = timedelta(minutes=episode_minutes), timedelta(seconds=step_seconds)
+    env._stream_ids = {}
+    for d in pd.bdate_range(min_date, max_date):
+        env._stream_ids.setdefault(("SYN", get_next_trading_dt(pd.to_datetime(d).to_pydatetime()).strftime("%Y-%m-%d")), len(env._stream_ids))
+    return env
+
+
+@pytest.mark.parametrize("case", [(datetime(2018, 2, 21), datetime(2018, 2, 21), 30, 0.1), (datetime(2018, 2, 1), datetime(2018, 3, 15), 30, 0.1),
+                                  (datetime(2018, 2, 1), datetime(2018, 2, 2), 330, 0.1), (datetime(2018, 2, 1), datetime(2018, 2, 9), 329, 60.0),
+                                  (datetime(2018, 3, 26), datetime(2018, 4, 3), 30, 1.0)])  # fmt: skip
+def test_batched_start_draw_equals_per_env_reference_calls(case):
+    """vector_reset draws every env's (day, start second) in one pass; values AND the global np.random state afterwards must be
+    what n calls of the reference's _get_random_start_time (HistoricalOrderbookEnvironment.py:196,333-351) leave behind - one
+    day (no word drawn), many days (rejection sampling on both draws), an episode that fills the window (randint raises ->
+    0), a window of exactly one step, a range with a holiday (Good Friday 2018 maps to the Monday after)."""
+    env = _bare_vector_env(*case)
+    for seed in (1, 7, 123):
+        np.random.seed(seed)
+        slow = env._draw_slow(257)
+        after_slow = np.random.randint(0, 1 << 30)
+        np.random.seed(seed)
+        fast = env._draw(257)
+        assert np.array_equal(slow[0], fast[0]) and np.array_equal(slow[1], fast[1])
+        assert np.random.randint(0, 1 << 30) == after_slow
+    assert (fast[1] % 1_000_000 == 0).all()
+
+
+def test_env_classes_are_gym_env_and_rllib_vector_env_when_those_import(monkeypatch):
+    """RLlib's env check accepts gym.Env / VectorEnv instances only (the reference's class is a gym.Env,
+    HistoricalOrderbookEnvironment.py:51; its env_creator sets env.spec, rl4mm/gym/utils.py:83-86).  gym and ray are not in
+    this image: stub modules with the surface the package touches are injected, the package re-imported."""
+    import importlib
+    import sys
+    import types
+
+    gym = types.ModuleType("gym")
+    gym.Env = type("Env", (), {"spec": None, "metadata": {}})
+    spaces = types.ModuleType("gym.spaces")
+
+    class Box:
+        def __init__(self, low, high, shape=None, dtype=np.float32):
+            shape = np.shape(low) if shape is None else shape
+            self.low, self.high = np.broadcast_to(np.asarray(low, dtype=dtype), shape).copy(), np.broadcast_to(np.asarray(high, dtype=dtype), shape).copy()
+            self.shape, self.dtype = tuple(shape), np.dtype(dtype)
+
+    spaces.Box = Box
+    gym.spaces = spaces
+    envs, reg = types.ModuleType("gym.envs"), types.ModuleType("gym.envs.registration")
+
+    class EnvSpec:
+        def __init__(self, id, max_episode_steps=None):  # noqa: A002
+            self.id, self.max_episode_steps = id, max_episode_steps
+
+    reg.EnvSpec = EnvSpec
+    envs.registration = reg
+    gym.envs = envs
+    ray, rllib, renv, vec = (types.ModuleType(n) for n in ("ray", "ray.rllib", "ray.rllib.env", "ray.rllib.env.vector_env"))
+
+    class VectorEnv:
+        def __init__(self, observation_space, action_space, num_envs):
+            self.observation_space, self.action_space, self.num_envs = observation_space, action_space, num_envs
+
+    vec.VectorEnv = VectorEnv
+    for name, mod in (("gym", gym), ("gym.spaces", spaces), ("gym.envs", envs), ("gym.envs.registration", reg), ("ray", ray), ("ray.rllib", rllib),
+                      ("ray.rllib.env", renv), ("ray.rllib.env.vector_env", vec)):  # fmt: skip
+        monkeypatch.setitem(sys.modules, name, mod)
+    import rl4mm_amd.env as E
+
+    E = importlib.reload(E)
+    try:
+        assert issubclass(E.HistoricalOrderbookEnvironment, gym.Env) and issubclass(E.HistoricalOrderbookVectorEnv, VectorEnv)
+        assert E.Box is Box
+        made = {}
+
+        def fake_sim(cfg):  # no GPU here: the handle is not what this test is about
+            made["cfg"] = cfg
+            return types.SimpleNamespace(add_stream=lambda s: 0, set_portfolio=lambda *a: None, close=lambda: None, n_envs=cfg.n_envs)
+
+        monkeypatch.setattr(E._lib, "new_sim", fake_sim)
+        cat = E.StreamCatalog().add(synthetic_stream(3, 10, 50.0, 9.5 * 3600, 9.5 * 3600 + 5, ticker="SYN", trading_date="2018-02-21"))
+        env_config = dict(ticker="SYN", min_date="2018-02-21", max_date="2018-02-21", step_size=0.1, episode_length=30, n_levels=10, features="full_state", max_inventory=1000,
+                          normalisation_on=False, initial_cash=10**6, initial_inventory=0, per_step_reward_function="PnL", terminal_reward_function="PnL", market_order_clearing=False,
+                          market_order_fraction_of_inventory=0.0, min_quote_level=0, max_quote_level=10, enter_spread=False, concentration=None, info_calculator=None)  # fmt: skip
+        env = E.env_creator(env_config, catalog=cat)
+        assert isinstance(env, gym.Env) and isinstance(env.spec, EnvSpec)
+        assert env.spec.id == "HistoricalOrderbookEnvironment-v0" and env.spec.max_episode_steps == 18000
+        assert isinstance(env.observation_space, Box) and env.observation_space.shape == (10,) and env.action_space.shape == (4,)
+        venv = E.env_creator(env_config, catalog=cat, num_envs=8)
+        assert isinstance(venv, VectorEnv) and venv.num_envs == 8 and venv.spec.max_episode_steps == 18000 and made["cfg"].n_envs == 8
+    finally:
+        monkeypatch.undo()
+        importlib.reload(E)
+    assert not issubclass(E.HistoricalOrderbookEnvironment, gym.Env)
+
+
+def test_info_dicts_feed_the_reference_metrics_callback():
+    """rl4mm/utils/rllib/custom_metrics_callback.py:14-47 copies every key of `episode._agent_to_last_info["agent0"]` into
+    `episode.custom_metrics`, which RLlib then averages per key: the info dict of a step must be a flat dict whose keys are the
+    reference calculator's (InfoCalculators.py:31-89) and whose values survive np.mean.  The callback's loop is restated on
+    a stub episode (ray is not installed); the dict comes from SimpleInfoCalculator.calculate_dicts on a stub handle."""
+    import types
+
+    from rl4mm_amd.env import SimpleInfoCalculator
+
+    n = 3
+    sim = types.SimpleNamespace(
+        portfolios=lambda: (np.array([5, -7, 0]), np.array([10**6, 2 * 10**6, 1000]), np.array([2_700_050.0, 2_700_010.5, 2_699_990.0])),
+        best_prices=lambda: (np.array([2_700_000] * n), np.array([2_700_100] * n)),
+    )
+    actions = np.array([[1.0, 2.0, 1.0, 2.0, 6.0], [0.5, 0.5, 3.0, 3.0, 6.0], [2.0, 1.0, 2.0, 1.0, 0.0]])
+    calc = SimpleInfoCalculator(market_order_fraction_of_inventory=0.5)
+    infos = calc.calculate_dicts(sim, actions)
+    reference_keys = ["asset_price", "inventory", "cash", "aum", "market_spread", "agent_spread", "agent_weighted_spread", "midprice_offset", "weighted_midprice_offset",
+                      "bid_action", "ask_action", "market_order_action", "market_order_count", "market_order_total_volume"]  # fmt: skip
+    for info in infos:
+        assert list(info) == reference_keys
+        episode = types.SimpleNamespace(length=1, custom_metrics={}, _agent_to_last_info={"agent0": info})
+        assert episode.length > 0
+        for key in episode._agent_to_last_info["agent0"]:  # on_episode_step / on_episode_end, :26-27 and :46-47
+            episode.custom_metrics[key] = episode._agent_to_last_info["agent0"][key]
+        assert set(episode.custom_metrics) == set(reference_keys)
+        for key, value in episode.custom_metrics.items():  # what RLlib's metrics summary does with a custom metric
+            assert np.isfinite(np.mean(value)), key
+    assert [i["market_order_count"] for i in infos] == [0, 1, 0] and infos[1]["market_order_total_volume"] == 4.0  # |inventory| 7 > 6: round(3.5) = 4
+    assert infos[0]["aum"] == 10**6 + 2_700_050.0 * 5 and infos[0]["market_spread"] == 100
+
+
+def test_7z_archives_go_through_the_7z_executable(tmp_path, monkeypatch):
+    """run_populate_database_from_zipped.py:100 shells out to `7z x`; so does ingest._extract for `.7z` archives.  There is no
+    7z in this image: a stand-in executable on PATH (it unpacks a zip that was given the .7z name) shows the branch passes the
+    right command line, extracts next to the archive, and the day ends up in the catalog."""
+    import stat
+    import zipfile
+
+    from rl4mm_amd import ingest
+    from rl4mm_amd.env import StreamCatalog
+    from rl4mm_amd.synth import generate_lobster, write_lobster_csv
+
+    data = tmp_path / "data"
+    data.mkdir()
+    g = generate_lobster(5, 10, 150.0, 9.5 * 3600, 9.5 * 3600 + 20)
+    mp_, bp_ = write_lobster_csv(g, tmp_path / "raw", "SYN", "2018-02-21", 10)
+    arc = data / "_data_dwn_9_391__SYN_2018-02-21_2018-02-21_10.7z"
+    with zipfile.ZipFile(arc, "w") as z:
+        z.write(mp_, mp_.name); z.write(bp_, bp_.name)
+    bindir = tmp_path / "bin"
+    bindir.mkdir()
+    fake = bindir / "7z"
+    fake.write_text('#!/usr/bin/env python3\nimport sys, zipfile\nopen(sys.argv[0] + ".log", "a").write(" ".join(sys.argv[1:]) + "\\n")\n'
+                    'assert sys.argv[1] == "x" and sys.argv[2] == "-y", sys.argv\nout = [a[2:] for a in sys.argv if a.startswith("-o")][0]\n'
+                    'zipfile.ZipFile(sys.argv[3]).extractall(out)\n')
+    fake.chmod(fake.stat().st_mode | stat.S_IXUSR)
+    monkeypatch.setenv("PATH", f"{bindir}{os.pathsep}{os.environ['PATH']}")
+    cat = ingest.populate_catalog_from_archives(StreamCatalog(), data, "S")
+    assert [k for k, _ in cat.items()] == [("SYN", "2018-02-21")]
+    ref = pack_lobster(mp_, bp_, "SYN", "2018-02-21", 10, "S")
+    assert np.array_equal(cat.get("SYN", "2018-02-21").msgs, ref.msgs) and np.array_equal(cat.get("SYN", "2018-02-21").snaps, ref.snaps)
+    assert (bindir / "7z.log").read_text().split()[:3] == ["x", "-y", str(arc)] and not list(data.glob("*.csv"))
+    monkeypatch.setenv("PATH", str(tmp_path / "nowhere"))
+    with pytest.raises(RuntimeError, match="no 7z executable"):
+        ingest._extract(arc, data)
