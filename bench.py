@@ -281,53 +281,6 @@ def cpu_baseline(workload, budget_s=10.0):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# experiment: resident env waves (lobsim_set_persistent) against one launch per step
-# ---------------------------------------------------------------------------------------------------------------------
-def persistent_leg(sim, n_envs, K, dev, repeats=3):
-    """env-steps/s of lobsim_step_device with one launch per call and with the resident kernel, (a) fed pre-drawn actions,
-    (b) in a closed loop with a small torch policy network between steps on the same stream (obs f32 [N, 10] -> 256 -> 4,
-    its output is the next step's action): the resident waves hold 4 of 5 wave slots per SIMD, the policy kernels run on
-    what is left."""
-    import torch
-
-    obs = torch.zeros((n_envs, sim.obs_dim), dtype=torch.float64, device=dev)
-    obs32 = torch.zeros((n_envs, sim.obs_dim), dtype=torch.float32, device=dev)
-    reward = torch.zeros(n_envs, dtype=torch.float64, device=dev)
-    done = torch.zeros(n_envs, dtype=torch.uint8, device=dev)
-    g = torch.Generator(device=dev).manual_seed(5)
-    w1 = torch.randn((sim.obs_dim, 256), device=dev, generator=g) * 0.1
-    w2 = torch.randn((256, 4), device=dev, generator=g) * 0.1
-    acts = torch.rand((K, n_envs, 4), dtype=torch.float64, device=dev, generator=g) * 10.0
-    act = acts[0].clone()
-    ptrs = [acts[t].data_ptr() for t in range(K)]
-    res = {"unit": "env-steps/s", "steps": K, "repeats": repeats}
-
-    def given(t):
-        sim.step_device(ptrs[t % K], 0, obs.data_ptr(), obs32.data_ptr(), reward.data_ptr(), done.data_ptr(), 0)
-
-    def closed_loop(t):
-        # (element-wise / reduction kernels on purpose: next to 16 resident env waves a CU has ~96 VGPRs per lane and 37 KB of LDS
-        # left, and a kernel that needs more than that - a tuned GEMM - would wait for ever: see DESIGN.md section 5)
-        x = torch.nan_to_num(obs32).clamp(-10, 10)
-        h = torch.relu((x[:, :, None] * w1[None, :, :]).sum(1))
-        act.copy_(torch.sigmoid((h[:, :, None] * w2[None, :, :]).sum(1)) * 10.0)
-        sim.step_device(act.data_ptr(), 0, obs.data_ptr(), obs32.data_ptr(), reward.data_ptr(), done.data_ptr(), 0)
-
-    for mode in ("launch_per_step", "persistent"):
-        sim.set_persistent(mode == "persistent")
-        for name, fn in (("given_actions", given), ("policy_network_between_steps", closed_loop)):
-            for t in range(5):
-                fn(t)
-            # (stream-level synchronisation: a device-wide one waits for the resident kernel itself)
-            job, _, _ = timed_regions(fn, K, repeats, 0, None, torch.cuda.current_stream().synchronize)
-            res[f"{mode}.{name}"] = n_envs * K / region_summary(job, K)[0]
-    sim.set_persistent(False)
-    st_bad = sum(sim.env_state(int(e))["status"] != 0 for e in range(0, n_envs, max(1, n_envs // 64)))
-    res["envs_in_error_state_sampled"] = int(st_bad)
-    return res
-
-
-# ---------------------------------------------------------------------------------------------------------------------
 # the Python boundary (reported beside `value`, never as it)
 # ---------------------------------------------------------------------------------------------------------------------
 def facade_leg(sim, stream, n_envs, device_id, steps=60):
@@ -431,7 +384,6 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of all-core CPU work in the cpu_baseline sample")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # CPU test of the launcher (gloo, no lobsim)
     ap.add_argument("--repeats", type=int, default=REPEATS, help="timed regions of --steps steps; `value` is the median region")
-    ap.add_argument("--persistent-experiment", action="store_true", help="extra leg: per-call launches vs lobsim_set_persistent, each with and without a torch policy network between steps")
     ap.add_argument("--no-facade", action="store_true", help="skip the Python-boundary leg (VectorEnv.vector_step_arrays, host-pointer lobsim_step)")
     args = ap.parse_args()
     if args.envs is None:
@@ -467,8 +419,6 @@ def main():
         print(f"bench.py: LOBSIM_LIB override active, running {os.environ['LOBSIM_LIB']} (no staleness check)", file=sys.stderr)
 
     sim_seconds = ((R + 1) * K + W) * STEP_US // 1_000_000 + 8  # the timed regions, the open-loop rollout leg's K more, the facade leg
-    if args.persistent_experiment:
-        sim_seconds += 4 * 3 * min(K, 100) * STEP_US // 1_000_000 + 8
     streams = shared_streams(wl, sim_seconds, rank, dist)
     cfg = workload_cfg(_capi, wl, N, device_id=local_rank)
     sim = _lib.new_sim(cfg)
@@ -590,8 +540,6 @@ def main():
             }
         if os.environ.get("LOBSIM_LIB"):
             out["config"]["lobsim_lib_override"] = os.environ["LOBSIM_LIB"]
-        if world == 1 and wl == "random" and args.persistent_experiment:
-            out["persistent_experiment"] = persistent_leg(sim, N, min(K, 100), dev)
         if world == 1 and wl == "random" and not args.no_facade:
             out["facade"] = facade_leg(sim, streams[0], N, local_rank)
         if world == 1 and not args.no_cpu_baseline:

@@ -208,17 +208,6 @@ int lobsim_step_device(lobsim_t* h, const double* d_actions, const uint8_t* d_ac
                        double* d_reward, uint8_t* d_done, double* d_return_acc);
 int lobsim_sync(lobsim_t* h);
 
-/* Persistent stepping (on != 0): lobsim_step_device / lobsim_step no longer launch one kernel per call; the env waves stay
- * resident on the device between calls with each env's ladder and agent orders on chip (what lobsim_rollout_device keeps
- * there for one multi-step launch), and a call hands them its arguments and waits - on the caller's stream - until every env
- * has stepped.  Same results, same stream-ordering contract as the per-call launch.  Needs every env wave resident at once
- * (LOBSIM_ERR_STATE otherwise: 5120 envs per MI355X with the 64-level ladder, 4096 with the 128-level one).  Any other entry
- * point that needs the env state (reset, rollout, the inspection calls ...) first makes the resident kernel write it back
- * and exit; the next step call starts it again (~50 us), as does a pause of more than ~15 s between steps.  The resident
- * waves occupy 4 of the 5 (4) wave slots per SIMD: other kernels (a policy network between steps) run beside them on what
- * is left.  Off by default (an experiment). */
-int lobsim_set_persistent(lobsim_t* h, int32_t on);
-
 /* Open-loop / rule-based rollouts: up to T consecutive env.step()s per env in ONE launch, the action of every step
  * produced on the device (the reference's rule-based baselines, rl4mm/agents/baseline_agents.py, and its
  * generate_trajectory loop, rl4mm/gym/utils.py:100-117).  An env stops early when it reports done.

@@ -132,7 +132,6 @@ PROTOTYPES = {
     "step": (C.c_int, [C.c_void_p, _PD, _PU8, _PD, _PD, _PU8]),
     "step_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sync": (C.c_int, [C.c_void_p]),
-    "set_persistent": (C.c_int, [C.c_void_p, C.c_int32]),
     "rollout_device": (C.c_int, [C.c_void_p, C.c_int32, _PD, C.c_int32] + [C.c_void_p] * 8),
     "set_info_buffer": (C.c_int, [C.c_void_p, C.c_void_p]),
     "set_trace_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
@@ -146,7 +145,7 @@ PROTOTYPES = {
     "debug_process_orders": (C.c_int, [C.c_void_p, C.c_int32, _P64, C.c_int32, _P64]),
 }
 # the oracle has no device entry points
-ORACLE_SKIP = {"set_stream", "step_device", "sync", "rollout_device", "set_info_buffer", "set_trace_buffer", "set_persistent"}
+ORACLE_SKIP = {"set_stream", "step_device", "sync", "rollout_device", "set_info_buffer", "set_trace_buffer"}
 
 
 def _ptr(a: Optional[np.ndarray], typ):
@@ -307,9 +306,6 @@ class Sim:
 
     def sync(self):
         self._check(self.b.fn["sync"](self.h), "sync")
-
-    def set_persistent(self, on: bool = True):
-        self._check(self.b.fn["set_persistent"](self.h, int(bool(on))), "set_persistent")
 
     def set_info_buffer(self, d_info: int):
         self._check(self.b.fn["set_info_buffer"](self.h, d_info), "set_info_buffer")

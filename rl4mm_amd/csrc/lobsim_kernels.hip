@@ -103,25 +103,6 @@ struct StepArgs {
     double* info;           // or null: [n_envs][LOBSIM_INFO_DIM] info arrays (lobsim_set_info_buffer)
 };
 
-// Persistent stepping (lobsim_set_persistent): the env waves stay resident between env.step() calls with ladder / agent state
-// in LDS; a step arrives as an epoch bump.  One control block per handle in device memory.
-constexpr int PERSIST_REPLICAS = 64;  // epoch word and completion counter are replicated (env & 63 picks one, 64 B apart): 4096
-                                      // waves polling / bumping ONE L2 line would serialise on its channel
-enum PersistCmd : uint32_t { PERSIST_RUN = 0, PERSIST_STOP = 1 };
-struct alignas(64) PersistSlot { uint32_t v; uint32_t pad[15]; };
-struct PersistCtl {
-    PersistSlot epoch[PERSIST_REPLICAS];  // written by the post kernel (release), polled by the env waves
-    PersistSlot done[PERSIST_REPLICAS];   // bumped by every env wave once per epoch (release), summed by the post kernel
-    uint32_t cmd;                         // PersistCmd of the current epoch
-    uint32_t error;                       // the waiter gave up waiting (the env waves are gone)
-    uint32_t epoch0;                      // epoch at which the running persistent kernel started (its counters started at zero)
-    uint32_t pad[13];
-    StepArgs args;                        // arguments of the current epoch's step
-};
-#ifndef LOBSIM_PERSIST_SPINS
-#define LOBSIM_PERSIST_SPINS (1u << 26)   // polls (~0.5 us each) before an idle env wave writes its state back and exits: ~30 s
-#endif
-
 struct ResetArgs {
     const int32_t* env_ids;  // [n]
     const int32_t* stream_ids;
@@ -2731,148 +2712,6 @@ SDI void rollout_body(const DevCfg& C, const DevPtrs& P, const RolloutArgs& A) {
     }
 }
 
-// Data another kernel writes / reads WHILE this one runs (the mailbox, the step's actions and outputs).  The device is eight
-// XCDs with an L2 each; agent-scope acquire / release fences would keep them coherent by invalidating / writing back a whole
-// L2 per fence - measured: 0.19 us per env wave per step, 790 us for 4096 envs.  Instead every such access is a relaxed
-// SYSTEM-scope atomic (sc0 sc1: it goes past L1 and L2 to memory, nothing else is touched) and ordering is by waiting for
-// the stores' acknowledgement (s_waitcnt vmcnt(0)) before the word that publishes them is written.
-SDI uint32_t ld_u32(const uint32_t* p) { return (uint32_t)uni((int32_t)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)); }
-SDI uint64_t ld_u64(const void* p) { return (uint64_t)uni64((int64_t)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)); }
-SDI double ld_f64_sys(const double* p) { return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)); }
-template <typename T>
-SDI void st_sys(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-SDI void stores_done() { __builtin_amdgcn_s_waitcnt(0x0070); __builtin_amdgcn_sched_barrier(0); }  // vmcnt(0): every earlier store is acknowledged
-template <typename T>
-SDI T* ld_ptr(T* const* p) { return reinterpret_cast<T*>(ld_u64(p)); }
-
-// Persistent stepping: one wave per env stays resident, ladder / agent orders / scalars on chip between steps (what the
-// multi-step launch keeps there, but with one env.step() per CALL: the action of a step arrives with an epoch bump, its
-// outputs are written and the completion counter bumped before the wave waits for the next one).  While it waits the wave
-// has the next window's first message batch in flight.  A STOP epoch (any entry point that needs the env state in HBM) or
-// ~30 s without a step makes it write the state back and exit.
-template <bool EXTRAS>
-SDI void persist_body(const DevCfg& C, const DevPtrs& P, PersistCtl* ctl, uint32_t start_epoch) {
-    __shared__ Lds L;
-    const int env = blockIdx.x, ln = lane();
-    EnvHdr& H = P.hdr[env];
-    const int F = C.c.n_features, AD = C.c.action_dim, D = C.obs_dim;
-    Scal S;
-    load_env(L, S, P, env, H);
-    S.ahead = true;  // (a launch of this kind ends every step with its slowest env too)
-    double fval = 0.0;
-    if (ln < F) fval = P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln].current_value;
-    int64_t now = H.now_us, cursor = H.msg_cursor;
-    const int stream_id = H.stream_id;
-    const StreamDev& st0 = P.streams[stream_id >= 0 ? stream_id : 0];
-    const int64_t n_msgs_all = st0.n_msgs;
-    const int64_t* msgs_all = st0.msgs;
-    const int64_t terminal_us = H.terminal_us;
-    Ranges R = {0.0, 0.0, 0.0, 0.0};
-    int n_resyncs = 0;
-    double price = H.price;
-    if (ln < LOBSIM_MAX_ACTION_DIM) L.act[ln] = H.prev_action[ln];
-    wsync();
-    uint32_t seen = start_epoch;
-    const uint32_t* ep = &ctl->epoch[env & (PERSIST_REPLICAS - 1)].v;
-    uint32_t* dn = &ctl->done[env & (PERSIST_REPLICAS - 1)].v;
-    for (;;) {
-        MsgBatch first = fetch_messages(msgs_all, stream_id >= 0 ? cursor : 0);  // the next window's first batch travels while we wait
-        if (stream_id < 0) first.t = INT64_MAX;
-        uint32_t e = seen, spins = 0;
-        while ((e = ld_u32(ep)) == seen) {
-            __builtin_amdgcn_s_sleep(16);
-            if (++spins > LOBSIM_PERSIST_SPINS) break;
-        }
-        if (e == seen) break;  // idle for too long: state back to HBM, exit (the host restarts the kernel with the next step)
-        seen = e;
-        if (ld_u32(&ctl->cmd) == PERSIST_STOP) break;
-        const StepArgs& A = ctl->args;
-        const uint8_t* active = ld_ptr(&A.active);
-        bool stepped = false;
-        double reward = 0.0;
-        int done = 1;
-        const int entry_status = S.status;
-        if (!active || __hip_atomic_load(active + env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
-            stepped = true;
-            Act5 act;
-            const int policy = (int)ld_u32(reinterpret_cast<const uint32_t*>(&A.policy));
-            if (policy == LOBSIM_POLICY_GIVEN) {
-                const double* ap = ld_ptr(&A.actions) + (size_t)env * AD;  // (written by a kernel that ran since this wave last read the buffer)
-                act.v0 = ld_f64_sys(ap); act.v1 = ld_f64_sys(ap + 1);
-                act.v2 = AD > 2 ? ld_f64_sys(ap + 2) : 0.0; act.v3 = AD > 3 ? ld_f64_sys(ap + 3) : 0.0; act.v4 = AD > 4 ? ld_f64_sys(ap + 4) : 0.0;
-                act.v0 = rld(act.v0, 0); act.v1 = rld(act.v1, 0); act.v2 = rld(act.v2, 0); act.v3 = rld(act.v3, 0); act.v4 = rld(act.v4, 0);
-            } else {
-                double prm[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) prm[k] = __longlong_as_double((long long)ld_u64(&A.params[k]));
-                if (policy == LOBSIM_POLICY_FIXED) { act.v0 = prm[0]; act.v1 = prm[1]; act.v2 = prm[2]; act.v3 = prm[3]; act.v4 = prm[4]; }
-                else act = teradactyl_action(prm, rld(fval, (int)prm[5]));
-            }
-            if (!S.status) {
-                clear_step_fills(L);
-                const int64_t inv0 = cur_inv(L), cash0 = cur_cash(L);
-                const double p0 = price;
-                double* info = ld_ptr(&A.info);
-                build_agent_ops(L, S, C, act, info != nullptr);
-                if (ln == 0) { L.act[0] = act.v0; L.act[1] = act.v1; L.act[2] = act.v2; L.act[3] = act.v3; L.act[4] = act.v4; }
-                if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true, first, n_msgs_all, 0, false, &H);
-                if (!S.status) {
-                    StepView v = make_view(L, S, price, now);
-                    bool ok = true;
-                    if (ln < F) {
-                        FeatState fs = P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln];
-                        ok = feature_update<EXTRAS>(C.c.features[ln], fs, P.rings + (size_t)env * C.ring_words + C.ring_off[ln], v, norm_history(C, P, env, ln));
-                        P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln] = fs;
-                        fval = fs.current_value;
-                    }
-                    if (ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
-                }
-                if (!S.status) {
-                    done = 0;
-                    reward = step_reward<EXTRAS>(L, S, C, P, env, false, inv0, cash0, p0, price);
-                    if (2 * (terminal_us - now) < C.c.step_us) {
-                        reward = step_reward<EXTRAS>(L, S, C, P, env, true, inv0, cash0, p0, price);
-                        done = 1;
-                    }
-                }
-                if (S.status) { done = 1; reward = 0.0; }
-                if (info && !S.status) {
-                    Act5 a5; a5.v0 = L.act[0]; a5.v1 = L.act[1]; a5.v2 = L.act[2]; a5.v3 = L.act[3]; a5.v4 = L.act[4];
-                    write_info(L, S, C, H, a5, price, info + (size_t)env * LOBSIM_INFO_DIM);
-                }
-            } else if (ln == 0) { L.act[0] = act.v0; L.act[1] = act.v1; L.act[2] = act.v2; L.act[3] = act.v3; L.act[4] = act.v4; }
-            wsync();
-            // outputs of this step
-            double val = 0.0;
-            if (ln < F) val = fval;
-            else if (ln < D) val = L.act[ln - F];
-            double* obs = ld_ptr(&A.obs);
-            float* obs32 = ld_ptr(&A.obs_f32);
-            if (ln < D) {
-                if (obs) st_sys(obs + (size_t)env * D + ln, val);
-                if (obs32) st_sys(obs32 + (size_t)env * D + ln, (float)val);
-            }
-            if (ln == 0) {
-                st_sys(ld_ptr(&A.reward) + env, reward);
-                st_sys(ld_ptr(&A.done) + env, (uint8_t)done);
-                double* racc = ld_ptr(&A.return_acc);
-                if (racc) st_sys(racc + env, ld_f64_sys(racc + env) + reward);
-                int32_t* taken = ld_ptr(&A.steps_taken);
-                if (taken) st_sys(taken + env, (int32_t)(entry_status ? 0 : 1));
-            }
-        }
-        (void)stepped;
-        // this env's part of the epoch is done: the outputs are in memory, then the counter
-        stores_done();
-        if (ln == 0) __hip_atomic_fetch_add(dn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    store_env(L, S, P, env, H);
-    if (ln == 0) {
-        H.now_us = now; H.msg_cursor = cursor; H.price = price;
-        H.prev_action[0] = L.act[0]; H.prev_action[1] = L.act[1]; H.prev_action[2] = L.act[2]; H.prev_action[3] = L.act[3]; H.prev_action[4] = L.act[4];
-    }
-}
-
 // env.reset(): snapshot book at (episode_start - warmup), features reset, warm-up replay without agent orders
 // (HistoricalOrderbookEnvironment.py:147-161)
 template <bool EXTRAS>
@@ -3034,49 +2873,10 @@ SDI void process_orders_body(const DevCfg& C, const DevPtrs& P, int env, const i
 #ifndef LOBSIM_ROLLOUT_WAVES
 #define LOBSIM_ROLLOUT_WAVES 4
 #endif
-#ifndef LOBSIM_PERSIST_WAVES
-#define LOBSIM_PERSIST_WAVES 5
-#endif
 template <bool EXTRAS, int LVT, bool SPEC = false>
 __global__ __launch_bounds__(64, LVT == 64 ? LOBSIM_STEP_WAVES : LOBSIM_STEP_WAVES_DEEP) void lob_step_kernel(DevCfg C, DevPtrs P, StepArgs A) { Eng<LVT, SPEC>::template step_body<EXTRAS>(C, P, A); }
 template <bool EXTRAS, int LVT, bool SPEC = false>
 __global__ __launch_bounds__(64, LOBSIM_ROLLOUT_WAVES) void lob_rollout_kernel(DevCfg C, DevPtrs P, RolloutArgs A) { Eng<LVT, SPEC>::template rollout_body<EXTRAS>(C, P, A); }
-// (register budget of FIVE waves per SIMD although at most four are resident: the fifth slot's registers are what the post
-// kernel - and any kernel the caller runs between steps - gets; with a four-wave budget the resident waves own every VGPR of
-// the SIMD and nothing else can ever start: the post kernel waits for a slot, the env waves wait for the post kernel)
-template <bool EXTRAS, int LVT, bool SPEC = false>
-__global__ __launch_bounds__(64, LOBSIM_PERSIST_WAVES) void lob_persist_kernel(DevCfg C, DevPtrs P, PersistCtl* ctl, uint32_t start_epoch) {
-    Eng<LVT, SPEC>::template persist_body<EXTRAS>(C, P, ctl, start_epoch);
-}
-// One per lobsim_step_device call in persistent mode, on the caller's stream: publishes the step's arguments and the new epoch,
-// then waits until every env wave has bumped the completion counter - work queued behind it on that stream sees the step's
-// outputs, exactly as after the per-step launch.  (One wave: lane r owns replica r.)
-__global__ __launch_bounds__(64) void lob_persist_post_kernel(PersistCtl* ctl, StepArgs a, uint32_t epoch, uint32_t n_envs, uint32_t cmd) {
-    const uint32_t r = threadIdx.x;
-    {   // the arguments, word by word past the caches (see ld_u32); acknowledged before the epoch is published
-        static_assert(sizeof(StepArgs) % 8 == 0, "");
-        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&a);
-        unsigned long long* dst = reinterpret_cast<unsigned long long*>(&ctl->args);
-        for (uint32_t w = r; w < sizeof(StepArgs) / 8; w += 64) __hip_atomic_store(dst + w, src[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (r == 0) __hip_atomic_store(&ctl->cmd, cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    __builtin_amdgcn_s_waitcnt(0x0070);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_wave_barrier();
-    __hip_atomic_store(&ctl->epoch[r].v, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (cmd == PERSIST_STOP) return;
-    // envs r, r + 64, ... bump replica r once per epoch; the counters were zeroed when the persistent kernel started at epoch0
-    const uint32_t mine = n_envs / PERSIST_REPLICAS + (r < n_envs % PERSIST_REPLICAS ? 1u : 0u);
-    const uint32_t epoch0 = __hip_atomic_load(&ctl->epoch0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    const uint32_t target = mine * (epoch - epoch0);
-    uint32_t spins = 0;
-    for (;;) {
-        const uint32_t v = __hip_atomic_load(&ctl->done[r].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (__builtin_amdgcn_ballot_w64(v != target) == 0) break;
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1u << 24)) { if (r == 0) __hip_atomic_store(&ctl->error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }  // (~5 s: the env waves are gone)
-    }
-}
 template <bool EXTRAS, int LVT>
 __global__ __launch_bounds__(64, 4) void lob_reset_kernel(DevCfg C, DevPtrs P, ResetArgs A) { Eng<LVT>::template reset_body<EXTRAS>(C, P, A); }
 template <int LVT>

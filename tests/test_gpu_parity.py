@@ -924,58 +924,3 @@ def test_specialised_default_config_kernels_equal_generic_ones():
             assert np.array_equal(sims[0].queues(e), other.queues(e))
     for s in sims:
         s.close()
-
-
-def test_persistent_stepping_equals_one_launch_per_step():
-    """lobsim_set_persistent (env waves resident between calls, state on chip) against the per-call launch on a second handle
-    and against the oracle: 1024 envs, 120 device-pointer steps with pre-drawn actions - observation, reward, done of every env
-    at every step - then an inspection call (which takes the resident kernel down), a reset of half the envs, 40 more steps
-    through the HOST-pointer entry in persistent mode; portfolios, fill counters and sampled books at the end."""
-    import torch
-
-    import bench
-
-    n, steps = 1024, 120
-    stream = synthetic_stream(78, 10, 200.0, 9.5 * 3600 + 1490, 9.5 * 3600 + 1800 + 90)
-    cfg = _capi.make_cfg(n, 10, bench.default_features(_capi), step_us=100_000, episode_us=1_800_000_000, max_levels=128)
-    a, b, cpu = _lib.new_sim(cfg), _lib.new_sim(cfg), ol.oracle_sim(cfg)
-    rng = np.random.Generator(np.random.PCG64(17))
-    starts = (36_000 + rng.integers(0, 50, size=n)) * 1_000_000
-    for sim in (a, b, cpu):
-        sim.add_stream(stream)
-        sim.set_portfolio(0, 10**12)
-        sim.reset(starts, 0)
-    a.set_persistent(True)
-    acts = rng.uniform(0, 10, size=(steps + 40, n, 4))
-    d_acts = torch.from_numpy(acts).cuda()
-    D = a.obs_dim
-    outs = [(torch.zeros((n, D), dtype=torch.float64).cuda(), torch.zeros(n, dtype=torch.float64).cuda(), torch.zeros(n, dtype=torch.uint8).cuda()) for _ in range(2)]
-    for t in range(steps):
-        for sim, (o, r, d) in zip((a, b), outs):
-            sim.step_device(d_acts[t].data_ptr(), 0, o.data_ptr(), 0, r.data_ptr(), d.data_ptr(), 0)
-            sim.sync()
-        oc, rc, dc = cpu.step(acts[t])
-        for k in range(3):
-            assert torch.equal(outs[0][k], outs[1][k]), f"step {t}: persistent and per-call launches differ in output {k}"
-        assert np.allclose(outs[0][0].cpu().numpy(), oc, rtol=RTOL, atol=ATOL) and np.array_equal(outs[0][2].cpu().numpy(), dc), t
-    for x, y, z in zip(a.portfolios(), b.portfolios(), cpu.portfolios()):  # (stops the resident kernel: the state is read from HBM)
-        assert np.array_equal(x, y) and np.array_equal(x, z)
-    ids = np.arange(0, n, 2, dtype=np.int32)
-    new_starts = starts[ids] + 20_000_000
-    for sim in (a, b, cpu):
-        sim.reset(new_starts, 0, ids)
-    for t in range(steps, steps + 40):  # host pointers, still persistent on handle a (the kernel restarts with the first call)
-        oa, ra, da = a.step(acts[t])
-        ob, rb, db = b.step(acts[t])
-        oc, rc, dc = cpu.step(acts[t])
-        assert np.array_equal(oa, ob) and np.array_equal(ra, rb) and np.array_equal(da, db), t
-        assert np.allclose(oa, oc, rtol=RTOL, atol=ATOL) and np.array_equal(da, dc), t
-    a.set_persistent(False)
-    for x, y, z in zip(a.portfolios(), b.portfolios(), cpu.portfolios()):
-        assert np.array_equal(x, y) and np.array_equal(x, z)
-    for e in (0, 511, n - 1):
-        assert np.array_equal(a.queues(e), cpu.queues(e))
-        sa, sc = a.env_state(e), cpu.env_state(e)
-        for k in ("status", "now_us", "n_agent_orders", "n_resyncs", "agent_fill_count", "ext_buy_count", "ext_sell_volume"):
-            assert sa[k] == sc[k], (e, k, sa[k], sc[k])
-    a.close(); b.close()
