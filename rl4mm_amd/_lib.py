@@ -69,6 +69,9 @@ def binding() -> _capi.Binding:
     if _binding is None:
         alt = os.environ.get("LOBSIM_LIB")  # diagnostics: a prebuilt variant of the same library (tools/build_variant.sh)
         if alt:
+            import sys
+
+            print(f"rl4mm_amd: LOBSIM_LIB is set - loading {alt} instead of {LIB_PATH} (no staleness check)", file=sys.stderr)
             _binding = _capi.Binding(alt, prefix="lobsim_")
             return _binding
         if _stale():
