@@ -197,7 +197,7 @@ def _dev(arr):
     return torch.from_numpy(np.ascontiguousarray(arr)).to("cuda:0")
 
 
-@pytest.mark.parametrize("path", ["ramp_up", "ramp_down", "triangle"])
+@pytest.mark.parametrize("path", ["ramp_up", "ramp_down", "triangle", "ramp_up_default_config", "ramp_down_wide_ladder"])
 def test_drifting_stream_with_agent_whole_batch(path):
     """256 envs x a full 30-minute episode (18 000 steps, random Beta-policy actions, the agent trading all the way) on a
     stream that drifts one tick every 4 s, or oscillates +-150 ticks at one tick per 3 s.  The first 400 steps one
@@ -208,12 +208,22 @@ def test_drifting_stream_with_agent_whole_batch(path):
     import torch
 
     n, steps, single, chunk = 256, 18_000, 400, 400
-    p = {"ramp_up": ds.ramp_path(4.0), "ramp_down": ds.ramp_path(4.0, -1), "triangle": ds.triangle_path(150, 3.0)}[path]
-    ps = ds.drift_stream(21 + len(path), p, duration_s=1_900.0)
-    cfg = _capi.make_cfg(n, 10, _feats(), step_us=100_000, episode_us=1_800_000_000, warmup_us=10_000_000)
-    gpu, cpu = _lib.new_sim(cfg), ol.oracle_sim(cfg)
+    p = {"ramp_up": ds.ramp_path(4.0), "ramp_down": ds.ramp_path(4.0, -1), "triangle": ds.triangle_path(150, 3.0),
+         "ramp_up_default_config": ds.ramp_path(4.0), "ramp_down_wide_ladder": ds.ramp_path(4.0, -1)}[path]
+    ps = ds.drift_stream(21 + len(path), p, duration_s=1_900.0 if path != "ramp_up_default_config" else 2_200.0)
     rng = np.random.Generator(np.random.PCG64(8))
-    starts = (34_212 + rng.integers(0, 40, size=n)) * 1_000_000
+    if path == "ramp_up_default_config":
+        # the reference's default configuration (10 default features, 5-minute warm-up): the kernels with its constants folded
+        # (Eng<64, true>), the ones the bench times
+        import bench
+
+        cfg = _capi.make_cfg(n, 10, bench.default_features(_capi), step_us=100_000, episode_us=1_800_000_000)
+        starts = (34_200 + 310 + rng.integers(0, 40, size=n)) * 1_000_000
+    else:
+        # (the wide-ladder case keeps 128 levels per side on chip: the far ring starts later, the same book must come out)
+        cfg = _capi.make_cfg(n, 10, _feats(), step_us=100_000, episode_us=1_800_000_000, warmup_us=10_000_000, ladder_levels=128 if path == "ramp_down_wide_ladder" else 0)
+        starts = (34_212 + rng.integers(0, 40, size=n)) * 1_000_000
+    gpu, cpu = _lib.new_sim(cfg), ol.oracle_sim(cfg)
     for sim in (gpu, cpu):
         sim.add_stream(ps)
         sim.set_portfolio(0, 10**12)
