@@ -2874,7 +2874,7 @@ SDI void process_orders_body(const DevCfg& C, const DevPtrs& P, int env, const i
 #define LOBSIM_ROLLOUT_WAVES 4
 #endif
 template <bool EXTRAS, int LVT, bool SPEC = false>
-__global__ __launch_bounds__(64, LVT == 64 ? LOBSIM_STEP_WAVES : LOBSIM_STEP_WAVES_DEEP) void lob_step_kernel(DevCfg C, DevPtrs P, StepArgs A) { Eng<LVT, SPEC>::template step_body<EXTRAS>(C, P, A); }
+__global__ __launch_bounds__(64, (LVT == 64 && !EXTRAS) ? LOBSIM_STEP_WAVES : LOBSIM_STEP_WAVES_DEEP) void lob_step_kernel(DevCfg C, DevPtrs P, StepArgs A) { Eng<LVT, SPEC>::template step_body<EXTRAS>(C, P, A); }
 template <bool EXTRAS, int LVT, bool SPEC = false>
 __global__ __launch_bounds__(64, LOBSIM_ROLLOUT_WAVES) void lob_rollout_kernel(DevCfg C, DevPtrs P, RolloutArgs A) { Eng<LVT, SPEC>::template rollout_body<EXTRAS>(C, P, A); }
 template <bool EXTRAS, int LVT>

@@ -18,7 +18,8 @@ acts = torch.from_numpy(np.random.default_rng(2).uniform(0, 10, size=(K + 20, N,
 sims, res = {}, {}
 for arg in sys.argv[1:]:
     name, path = arg.split("=")
-    cfg = _capi.make_cfg(N, 10, bench.default_features(_capi), step_us=100_000, episode_us=1_800_000_000)
+    kw = dict(per_step_reward=(_capi.R_ROLLING_SHARPE, 0, 0.0, 120, 60)) if os.environ.get("AB_REWARD") == "RS" else {}  # (RS: the EXTRAS kernel variants)
+    cfg = _capi.make_cfg(N, 10, bench.default_features(_capi), step_us=100_000, episode_us=1_800_000_000, **kw)
     import subprocess
     missing = [n for n in _capi.PROTOTYPES if ("lobsim_" + n).encode() not in subprocess.run(["nm", "-D", str(ROOT / path)], capture_output=True).stdout]
     sim = _capi.Sim(_capi.Binding(ROOT / path, skip=missing), cfg)  # (older builds lack the newest entry points)
