@@ -19,6 +19,7 @@ sims, res = {}, {}
 for arg in sys.argv[1:]:
     name, path = arg.split("=")
     kw = dict(per_step_reward=(_capi.R_ROLLING_SHARPE, 0, 0.0, 120, 60)) if os.environ.get("AB_REWARD") == "RS" else {}  # (RS: the EXTRAS kernel variants)
+    if os.environ.get("AB_MAX_LEVELS"): kw["max_levels"] = int(os.environ["AB_MAX_LEVELS"])  # (slab pool size: 2 x 8 KiB per level and env)
     cfg = _capi.make_cfg(N, 10, bench.default_features(_capi), step_us=100_000, episode_us=1_800_000_000, **kw)
     import subprocess
     missing = [n for n in _capi.PROTOTYPES if ("lobsim_" + n).encode() not in subprocess.run(["nm", "-D", str(ROOT / path)], capture_output=True).stdout]
