@@ -370,6 +370,47 @@ def test_msft_50_level_replay_against_oracle():
     gpu.close()
 
 
+def test_real_lobster_slice_4096_envs_against_oracle():
+    """The only real LOBSTER data in reach - the reference's own MSFT 2012-06-21 test slice, 50 levels, ~350 messages per
+    second - at BASELINE's batch size: 4096 envs with their own random Beta-policy action sequences (half of them quoting inside
+    the spread, so that the agent is hit), started at 10:00:01 or 10:00:02, stepped to the end of the slice.  Every env
+    against the oracle at every step: inventory, cash, price, done, observation, reward; fill counters of every env and
+    per-order books of a sample at the end.  (BASELINE configs[2] names SPY 2018-02-21, which is neither in the image nor in
+    the reference: this is its bit-exact-fill check on the real data there is.)"""
+    n = 4096
+    F = _capi.make_feature
+    feats = [F(_capi.F_INVENTORY, 0, 100_000, -1e6, 1e6), F(_capi.F_SPREAD, 0, 100_000, 0, 5000), F(_capi.F_PRICE_MOVE, 5, 100_000, -1e4, 1e4),
+             F(_capi.F_TRADE_VOLUME_IMBALANCE, 5, 100_000, -1, 1), F(_capi.F_BOOK_IMBALANCE, 0, 100_000, -1, 1)]  # fmt: skip
+    rng = np.random.Generator(np.random.PCG64(2012))
+    starts = np.where(rng.random(n) < 0.7, 36_001, 36_002) * 1_000_000
+    for spread in (False, True):
+        cfg = _capi.make_cfg(n, 50, feats, step_us=100_000, episode_us=1_500_000, warmup_us=1_000_000, outer_levels=48, enter_spread=spread)
+        gpu, cpu = _lib.new_sim(cfg), ol.oracle_sim(cfg)
+        for sim in (gpu, cpu):
+            sim.add_stream(ol.golden_stream("msft"))
+            sim.set_portfolio(0, 10**9)
+        assert np.array_equal(gpu.reset(starts, 0), cpu.reset(starts, 0))
+        fills = 0
+        for t in range(15):
+            act = rng.uniform(0, 10, size=(n, 4))
+            og, rg, dg = gpu.step(act)
+            oc, rc, dc = cpu.step(act)
+            assert np.array_equal(dg, dc), t
+            for a, b, what in zip(gpu.portfolios(), cpu.portfolios(), ("inventory", "cash", "price")):
+                assert np.array_equal(a, b), f"enter_spread={spread} step {t}: {what} differs in envs {np.nonzero(a != b)[0][:8]}"
+            assert np.allclose(og, oc, rtol=RTOL, atol=ATOL) and np.allclose(rg, rc, rtol=0, atol=ATOL), t
+        keys = ("status", "now_us", "n_agent_orders", "n_resyncs", "n_buy_levels", "n_sell_levels", "agent_fill_count", "agent_buy_volume", "agent_sell_volume",
+                "ext_buy_count", "ext_sell_count", "ext_buy_volume", "ext_sell_volume")  # fmt: skip
+        for e in range(n):
+            sg, sc = gpu.env_state(e), cpu.env_state(e)
+            assert all(sg[k] == sc[k] for k in keys), (e, {k: (sg[k], sc[k]) for k in keys if sg[k] != sc[k]})
+            fills += sg["agent_fill_count"]
+        assert np.abs(gpu.portfolios()[0]).max() > 0, "the agent must have traded"
+        for e in (0, 2047, n - 1):
+            assert np.array_equal(gpu.queues(e), cpu.queues(e)), e
+        gpu.close()
+
+
 def test_full_size_properties():
     """BASELINE configs[1] at full size (4096 envs, synthetic 10-level stream, default full_state features, 300 steps):
     (a) EVERY env against the oracle on the same inputs - inventory, cash, price and done at every step (bit-exact),
