@@ -1328,7 +1328,25 @@ SDI int nth_set_bit32(uint32_t x, int r) {
     return base;
 }
 
+#ifndef LOBSIM_LEVEL_GUESS
+#define LOBSIM_LEVEL_GUESS 1
+#endif
 SDI int lane_find_level(const Lds& L, int side, int n, int64_t price) {
+#if LOBSIM_LEVEL_GUESS
+    if constexpr (SPEC) {
+        // Near the touch the ladder has a level at every tick, and that is where the messages and the agent's quotes are: level
+        // index = distance from the best price in ticks, checked with one LDS read - two dependent reads instead of the binary
+        // search's six.  Any lane that misses sends the (active part of the) wave through the search.
+        const int64_t best = L.price[side][0];
+        const int64_t d = side == LOBSIM_BUY ? best - price : price - best;
+        int g = -1;
+        if (n > 0 && d >= 0 && d < (int64_t)LV * 100) {
+            const uint32_t q = __umulhi((uint32_t)d, 42949673u);  // d / 100, exact in this range
+            if (q * 100u == (uint32_t)d && (int)q < n && L.price[side][q] == price) g = (int)q;
+        }
+        if (ballot(g < 0) == 0) return g;
+    }
+#endif
     int lo = 0, hi = n;
     while (lo < hi) {
         int mid = (lo + hi) >> 1;
