@@ -158,8 +158,8 @@ def region_summary(job_times, K):
                  "ms_per_step_regions": [round(x / K * 1e3, 5) for x in job_times]}  # fmt: skip
 
 
-def workload_cfg(capi, workload, n_envs, device_id=0):
-    kw = dict(step_us=STEP_US, episode_us=EPISODE_US, device_id=device_id)
+def workload_cfg(capi, workload, n_envs, device_id=0, ladder_levels=0):
+    kw = dict(step_us=STEP_US, episode_us=EPISODE_US, device_id=device_id, ladder_levels=ladder_levels)
     if workload == "ad":  # get_reward_function("AD"), rl4mm/gym/utils.py:29-39
         kw.update(per_step_reward=(capi.R_INVENTORY_ADJUSTED, 1, 0.1), terminal_reward=(capi.R_INVENTORY_ADJUSTED, 1, 0.1))
     return capi.make_cfg(n_envs, 50 if workload == "deep50" else 10, default_features(capi), **kw)
@@ -384,6 +384,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of all-core CPU work in the cpu_baseline sample")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # CPU test of the launcher (gloo, no lobsim)
     ap.add_argument("--repeats", type=int, default=REPEATS, help="timed regions of --steps steps; `value` is the median region")
+    ap.add_argument("--ladder-levels", type=int, default=0, help="price levels per side kept on chip (0 = the library's choice: 64 for books of <= 16 visible levels, else 128)")
     ap.add_argument("--no-facade", action="store_true", help="skip the Python-boundary leg (VectorEnv.vector_step_arrays, host-pointer lobsim_step)")
     args = ap.parse_args()
     if args.envs is None:
@@ -420,7 +421,7 @@ def main():
 
     sim_seconds = ((R + 1) * K + W) * STEP_US // 1_000_000 + 8  # the timed regions, the open-loop rollout leg's K more, the facade leg
     streams = shared_streams(wl, sim_seconds, rank, dist)
-    cfg = workload_cfg(_capi, wl, N, device_id=local_rank)
+    cfg = workload_cfg(_capi, wl, N, device_id=local_rank, ladder_levels=args.ladder_levels)
     sim = _lib.new_sim(cfg)
     # kernels run on a torch-owned (non-default) stream so the torch.cuda.Event pairs below time exactly them
     torch.cuda.set_stream(torch.cuda.Stream(device=dev))

@@ -127,7 +127,7 @@ typedef struct lobsim_cfg {
     int32_t inc_prev_action_in_obs;
     int32_t n_features;
     int32_t device_id; /* HIP device ordinal (ignored by the oracle) */
-    int32_t ladder_levels; /* price levels per side an env keeps ON CHIP (LDS): 0 = auto (64 for n_levels <= 16, else 128), 64 or
+    int32_t ladder_levels; /* price levels per side an env keeps ON CHIP (LDS): 0 = auto (64 for n_levels <= 56, else 128), 64 or
                               128.  A performance knob only: levels beyond it live in HBM (ignored by the oracle) */
     int32_t max_levels;    /* price levels per side an env can hold in all.  The reference's book is an unbounded SortedDict
                               (rl4mm/orderbook/models.py:64-69) that keeps every level that left LOBSTER's visible range, so a

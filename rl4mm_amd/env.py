@@ -521,7 +521,7 @@ class HistoricalOrderbookVectorEnv(_RayVectorEnv):
             concentration=concentration, market_order_clearing=market_order_clearing, market_order_fraction_of_inventory=market_order_fraction_of_inventory,
             enter_spread=enter_spread, inc_prev_action_in_obs=inc_prev_action_in_obs, per_step_reward=self.per_step_reward_function.desc(),
             terminal_reward=self.terminal_reward_function.desc(), device_id=device_id,
-            ladder_levels=ladder_levels,  # price levels per side kept ON CHIP (0 = 64 for books of <= 16 visible levels, else 128): a performance knob
+            ladder_levels=ladder_levels,  # price levels per side kept ON CHIP (0 = 64 for books of <= 56 visible levels, else 128): a performance knob
             max_levels=max_levels,  # price levels per side an env can hold in all (0 = 1024 if memory allows): the reference keeps stale levels that left
                                     # LOBSTER's visible range for the rest of the episode - one per tick of price drift; beyond it an env stops with
                                     # LOBSIM_ST_LEVEL_OVERFLOW
