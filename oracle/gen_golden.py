@@ -621,6 +621,23 @@ def main():
                            TradeVolumeImbalance(name="tvi", update_frequency=timedelta(seconds=0.2), lookback_periods=10, track_internal=True)]
         run_trajectory("synth_track_internal", db_s, "SYN", sdate, 10, tracked(), random_agent(44), 2, [35940, 35965], 20.0, step_reward="PnL", terminal_reward="PnL",
                        enter_spread=True, initial=(0, 10**9), stream_file="synth_small")  # fmt: skip
+        # step_size other than 0.1 s (an env_config key: rl4mm/helpers/main_helper.py:75, rl4mm/gym/utils.py:46-48).  0.05 s with the
+        # default features (HistoricalOrderbookEnvironment.py:395-398 allows any step <= 0.1 s: Spread / Inventory / EpisodeProportion
+        # tick with the step, the 0.1 s and 1 s features are gated on every second / twentieth step, Features.py:80-81,102-105);
+        # 1 s and 5 s with features whose update_frequency is the step (a 5 s window holds ~1000 messages, every step ends on a
+        # whole second, i.e. with the outer-level check of OrderbookSimulator.py:86-87)
+        run_trajectory("synth_step50ms_default", db_s, "SYN", sdate, 10, HistoricalOrderbookEnvironment.get_default_features(timedelta(seconds=0.05), timedelta(seconds=12)),
+                       random_agent(51), 1, [36000], 12.0, step_s=0.05, stream_file="synth_small")  # fmt: skip
+        per_second = lambda s, ep_s: [Spread(update_frequency=timedelta(seconds=s)), PriceMove(name="pm", update_frequency=timedelta(seconds=s), lookback_periods=4),  # noqa: E731
+                                      Volatility(name="v", update_frequency=timedelta(seconds=s), lookback_periods=6), Inventory(update_frequency=timedelta(seconds=s)),
+                                      EpisodeProportion(update_frequency=timedelta(seconds=s), episode_length=timedelta(seconds=ep_s)), TimeOfDay(),
+                                      TradeDirectionImbalance(update_frequency=timedelta(seconds=s), lookback_periods=5),
+                                      TradeVolumeImbalance(update_frequency=timedelta(seconds=s), lookback_periods=5, track_internal=True),
+                                      PriceRange(update_frequency=timedelta(seconds=s), lookback_periods=3), BookImbalance(update_frequency=timedelta(seconds=s))]  # fmt: skip
+        run_trajectory("synth_step1s", db_s, "SYN", sdate, 10, per_second(1.0, 60), random_agent(52), 2, [35960, 36030], 60.0, step_s=1.0, step_reward="SD", terminal_reward="PnL",
+                       inc_prev=True, stream_file="synth_small")  # fmt: skip
+        run_trajectory("synth_step5s", db_s, "SYN", sdate, 10, per_second(5.0, 60), random_agent(53), 2, [35975, 36040], 60.0, step_s=5.0, enter_spread=True,
+                       initial=(0, 10**9), stream_file="synth_small")  # fmt: skip
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

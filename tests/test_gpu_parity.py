@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 
 RTOL, ATOL = 1e-12, 1e-9
 TRAJ = ["msft_fixed", "msft_teradactyl_ad", "msft_random_allfeat", "synth_default_random", "synth_teradactyl_ad_spread", "synth_amihud", "synth_info_moc", "synth_info_spread",
-        "synth_moc_conc", "synth_moc_crash", "synth_q5_fixed", "synth_norm", "synth_track_internal"]  # fmt: skip
+        "synth_moc_conc", "synth_moc_crash", "synth_q5_fixed", "synth_norm", "synth_track_internal",
+        "synth_step50ms_default", "synth_step1s", "synth_step5s"]  # fmt: skip  (the last three: step_size 0.05 s / 1 s / 5 s)
 
 
 def _small_cfg(n_envs=1, n_levels=8, **kw):
@@ -227,6 +228,77 @@ def test_batch_against_oracle(variant):
         sg, sc = gpu.env_state(e), cpu.env_state(e)
         for k in ("now_us", "n_agent_orders", "n_resyncs", "min_buy_price", "max_sell_price", "status", "agent_fill_count", "ext_buy_count", "ext_sell_volume"):
             assert sg[k] == sc[k], (e, k, sg[k], sc[k])
+    gpu.close()
+
+
+def _features_on_clock(step_us, episode_us):
+    """Feature set whose update_frequency is the step (the reference gates a feature on `now % update_frequency == 0`,
+    Features.py:80-81,102-105), plus one slower (TimeOfDay, a minute) and - for sub-100-ms steps - 0.1 s / 1 s features that a
+    step between their ticks must leave untouched, like the default set under step_size 0.05 s."""
+    F, s = _capi.make_feature, step_us
+    fs = [
+        F(_capi.F_SPREAD, 0, s, 0, 5000), F(_capi.F_PRICE_MOVE, 4, s, -1e4, 1e4), F(_capi.F_VOLATILITY, 8, s, 0, 1.0), F(_capi.F_INVENTORY, 0, s, -1e6, 1e6),  # (the longest window - the warm-up - is whole seconds for every step used below)
+        F(_capi.F_EPISODE_PROPORTION, 0, s, 0, 1.0, dparam=s / episode_us), F(_capi.F_TIME_OF_DAY, 0, 60_000_000, 0, 9, iparam=1_980_000_000),
+        F(_capi.F_TRADE_DIRECTION_IMBALANCE, 5, s, -1, 1), F(_capi.F_TRADE_VOLUME_IMBALANCE, 5, s, -1, 1, iparam=1), F(_capi.F_PRICE_RANGE, 3, s, 0, 1e4),
+        F(_capi.F_BOOK_IMBALANCE, 0, s, -1, 1),
+    ]  # fmt: skip
+    if step_us < 100_000:
+        fs += [F(_capi.F_PRICE_MOVE, 1, 100_000, -1e4, 1e4), F(_capi.F_VOLATILITY, 30, 100_000, 0, 1.0), F(_capi.F_PRICE_MOVE, 3, 1_000_000, -1e4, 1e4),
+               F(_capi.F_TRADE_VOLUME_IMBALANCE, 20, 100_000, -1, 1)]  # fmt: skip
+    return fs
+
+
+@pytest.mark.parametrize("step_us,ladder_levels", [(1_000_000, 64), (1_000_000, 128), (5_000_000, 64), (5_000_000, 128), (50_000, 64), (250_000, 128)])
+def test_batch_step_sizes_against_oracle(step_us, ladder_levels):
+    """step_size other than 0.1 s (env_config key, rl4mm/helpers/main_helper.py:75; HistoricalOrderbookEnvironment.py:98-100): 256
+    envs with random actions against the oracle, every env at every step, through an episode end and a reset, with both
+    on-chip ladder widths.  Nothing but 0.1 s runs the kernels specialised for the default configuration, so these are the
+    generic ones: a 1 s window holds ~200 messages (3-4 batches of 64 in the replay loop), a 5 s window ~1000, every 1 s / 5 s
+    step ends on a whole second (the outer-level check of OrderbookSimulator.py:86-87 runs every step), a 50 ms step on every
+    twentieth; 250 ms steps meet the second on every fourth."""
+    n = 256
+    steps, ep_steps = {1_000_000: (60, 40), 5_000_000: (20, 12), 50_000: (150, 100), 250_000: (100, 60)}[step_us]
+    episode_us = ep_steps * step_us
+    feats = _features_on_clock(step_us, episode_us)
+    cfg = _capi.make_cfg(n, 10, feats, step_us=step_us, episode_us=episode_us, outer_levels=20, ladder_levels=ladder_levels,
+                         per_step_reward=(_capi.R_INVENTORY_ADJUSTED, 1, 0.1), terminal_reward=(_capi.R_PNL, 0, 0.0))  # fmt: skip
+    stream = ol.golden_stream("synth_small")  # 09:54:50 .. 10:01:50
+    gpu, cpu = _lib.new_sim(cfg), ol.oracle_sim(cfg)
+    rng = np.random.Generator(np.random.PCG64(1000 + step_us // 1000))
+    starts = (35_730 + rng.integers(0, 120, size=n)) * 1_000_000
+    for sim in (gpu, cpu):
+        sim.add_stream(stream)
+        sim.set_portfolio(0, 10**9)
+    og, oc = gpu.reset(starts, 0), cpu.reset(starts, 0)
+    assert np.allclose(og, oc, rtol=RTOL, atol=ATOL)
+    n_done = 0
+    for t in range(steps):
+        act = rng.uniform(0, 10, size=(n, 4))
+        og, rg, dg = gpu.step(act)
+        oc, rc, dc = cpu.step(act)
+        ig, cg, pg = gpu.portfolios()
+        ic, cc, pc = cpu.portfolios()
+        assert np.array_equal(ig, ic), f"step {t}: inventory differs in envs {np.nonzero(ig != ic)[0][:8]}"
+        assert np.array_equal(cg, cc), f"step {t}: cash differs in envs {np.nonzero(cg != cc)[0][:8]}"
+        assert np.array_equal(dg, dc), f"step {t}: done differs"
+        assert np.array_equal(pg, pc), f"step {t}: microprice differs"
+        assert np.allclose(og, oc, rtol=RTOL, atol=ATOL), f"step {t}: obs differ by {np.abs(og - oc).max()}"
+        assert np.allclose(rg, rc, rtol=0, atol=ATOL), f"step {t}: reward differs by {np.abs(rg - rc).max()}"
+        if dg.any():
+            ids = np.nonzero(dg)[0].astype(np.int32)
+            n_done += len(ids)
+            starts[ids] += (episode_us // 1_000_000 + 1) * 1_000_000
+            o1, o2 = gpu.reset(starts[ids], 0, ids), cpu.reset(starts[ids], 0, ids)
+            assert np.allclose(o1, o2, rtol=RTOL, atol=ATOL)
+    assert n_done == n  # every env went through its terminal step and a reset
+    assert np.abs(ig).max() > 0
+    for e in range(n):
+        sg, sc = gpu.env_state(e), cpu.env_state(e)
+        for k in ("now_us", "n_agent_orders", "n_resyncs", "min_buy_price", "max_sell_price", "status", "agent_fill_count", "agent_buy_volume", "agent_sell_volume",
+                  "ext_buy_count", "ext_sell_count", "ext_buy_volume", "ext_sell_volume", "n_buy_levels", "n_sell_levels", "best_buy", "best_sell"):  # fmt: skip
+            assert sg[k] == sc[k], (e, k, sg[k], sc[k])
+    for e in (0, 17, 101, 255):
+        assert np.array_equal(gpu.queues(e), cpu.queues(e)), f"env {e}: per-order book contents differ"
     gpu.close()
 
 

@@ -10,7 +10,8 @@ from rl4mm_amd import _capi
 from traj_util import replay_and_check, run_engine_case
 
 TRAJ = ["msft_fixed", "msft_teradactyl_ad", "msft_random_allfeat", "synth_default_random", "synth_teradactyl_ad_spread", "synth_amihud", "synth_info_moc", "synth_info_spread",
-        "synth_moc_conc", "synth_moc_crash", "synth_q5_fixed", "synth_norm", "synth_track_internal"]  # fmt: skip
+        "synth_moc_conc", "synth_moc_crash", "synth_q5_fixed", "synth_norm", "synth_track_internal",
+        "synth_step50ms_default", "synth_step1s", "synth_step5s"]  # fmt: skip  (the last three: step_size 0.05 s / 1 s / 5 s)
 
 
 def _small_cfg(n_levels=8, **kw):
