@@ -129,12 +129,14 @@ typedef struct lobsim_cfg {
     int32_t device_id; /* HIP device ordinal (ignored by the oracle) */
     int32_t ladder_levels; /* price levels per side an env keeps ON CHIP (LDS): 0 = auto (64 for n_levels <= 56, else 128), 64 or
                               128.  A performance knob only: levels beyond it live in HBM (ignored by the oracle) */
-    int32_t max_levels;    /* price levels per side an env can hold in all.  The reference's book is an unbounded SortedDict
-                              (rl4mm/orderbook/models.py:64-69) that keeps every level that left LOBSTER's visible range, so a
-                              drifting price piles up stale levels on the side it leaves (10 + one per tick of net excursion).
-                              0 = auto: 1024, halved while the slab pool (2 x 8 KiB per level and env) would take more than half
-                              of the free device memory.  Otherwise 64 .. 2048; rounded up to a multiple of 32.  Exceeding it sets
-                              LOBSIM_ST_LEVEL_OVERFLOW on that env (ignored by the oracle) */
+    int32_t max_levels;    /* the env's budget of price levels: its slab pool holds 2 x max_levels levels in all, shared by the two
+                              sides (a side can take nearly all of it, up to ladder_levels + 2048).  The reference's book is an
+                              unbounded SortedDict (rl4mm/orderbook/models.py:64-69) that keeps every level that left LOBSTER's visible
+                              range, so a drifting price piles up stale levels on the side it leaves (10 + one per tick of net excursion).
+                              0 = the default, 512 (8 MiB of slabs per env, whatever else is on the GPU); otherwise 64 .. 2048, raised
+                              to 128 at least and rounded up to a multiple of 32.  If the pool cannot be allocated, lobsim_create
+                              retries with half (down to 128): lobsim_get_limits reports what the handle really has.  The operation
+                              that needs one level more sets LOBSIM_ST_LEVEL_OVERFLOW on that env (ignored by the oracle) */
     int32_t reserved0;
     int64_t step_us;    /* step_size */
     int64_t episode_us; /* episode_length */
@@ -175,6 +177,12 @@ typedef struct lobsim_order_view {
 } lobsim_order_view;
 
 typedef struct lobsim lobsim_t;
+
+/* Bumped whenever a struct of this header changes layout or an entry point changes meaning: a binding compares it with the
+ * LOBSIM_ABI_VERSION it was written against before it passes a config struct: a stale prebuilt library would otherwise
+ * read the struct at the wrong offsets and still produce plausible numbers. */
+#define LOBSIM_ABI_VERSION 4
+int lobsim_abi_version(void);
 
 int lobsim_create(const lobsim_cfg* cfg, lobsim_t** out);
 void lobsim_destroy(lobsim_t* h);
@@ -266,6 +274,50 @@ int lobsim_set_trace_buffer(lobsim_t* h, double* d_trace, int32_t t_capacity);
 
 int lobsim_obs_dim(const lobsim_t* h);
 
+/* What this handle can hold per env (the reference's containers are unbounded; each of these is a status bit when exceeded). */
+typedef struct lobsim_limits {
+    int32_t level_slabs;     /* price levels an env can hold in all, both sides together (= 2 x the effective max_levels) */
+    int32_t ladder_levels;   /* levels per side kept on chip (64 / 128); a performance property, bounds nothing */
+    int32_t far_levels;      /* levels per side beyond the on-chip ladder (2048) */
+    int32_t queue_slots;     /* live orders + tombstones at one price (512) */
+    int32_t agent_orders;    /* live agent orders (128) */
+    int32_t fill_log_rows;   /* rows per list of the fill log of lobsim_forward */
+    int64_t bytes_per_env;   /* device memory per env */
+} lobsim_limits;
+int lobsim_get_limits(const lobsim_t* h, lobsim_limits* out);
+
+/* Status bits (enum lobsim_status) of every env into a host array [n_envs]: which envs stopped, and why.  The batched env asks
+ * when a step reported done, to tell an episode's end from an error (the reference raises there: Exchange.py:32-37,180-186). */
+int lobsim_get_status(lobsim_t* h, int32_t* status);
+
+/* --- host-mapped step I/O ------------------------------------------------------------------------------------------------- */
+/* The host-pointer lobsim_step without its copies: pinned host buffers the GPU reads the actions from and writes observations,
+ * rewards and done flags to directly (no hipMemcpy in the step).  The caller fills io.actions [n_envs][action_dim] (and
+ * io.active [n_envs] when it passes use_active), calls lobsim_step_host_io, and reads io.obs [n_envs][obs_dim] / io.obs_f32 /
+ * io.reward / io.done in place once it returns (it synchronises).  The buffers belong to the handle and live as long as it does.
+ * want_obs: bit 0 = f64 observations, bit 1 = f32 (the dtype of observation_space, HistoricalOrderbookEnvironment.py:131-135). */
+typedef struct lobsim_host_io {
+    double* actions;
+    uint8_t* active;
+    double* obs;
+    float* obs_f32;
+    double* reward;
+    uint8_t* done;
+} lobsim_host_io;
+int lobsim_host_io_buffers(lobsim_t* h, lobsim_host_io* out);
+int lobsim_step_host_io(lobsim_t* h, int32_t use_active, int32_t want_obs);
+
+/* lobsim_step_device where the mask says which envs NOT to step: d_skip [n_envs] (device, may be NULL), envs with d_skip[i] != 0
+ * are left alone.  d_skip may be the very array the done flags are written to: an env that reported done then stays as it is -
+ * outputs included - until the caller resets it and clears its flag (a closed loop on the device with no host round trip per step). */
+int lobsim_step_device_skip(lobsim_t* h, const double* d_actions, const uint8_t* d_skip, double* d_obs, float* d_obs_f32,
+                            double* d_reward, uint8_t* d_done, double* d_return_acc);
+/* env.reset() with device outputs: like lobsim_reset, the first observation of env e = env_ids[i] written to ROW e of the caller's
+ * d_obs [n_envs][obs_dim] f64 and / or d_obs_f32 (device pointers, either may be NULL: the buffers it also hands to
+ * lobsim_step_device), and d_done[e] cleared when d_done is given.  Synchronises (the arguments are host arrays). */
+int lobsim_reset_device(lobsim_t* h, const int32_t* env_ids, int32_t n, const int32_t* stream_ids, const int64_t* episode_start_us,
+                        double* d_obs, float* d_obs_f32, uint8_t* d_done);
+
 /* --- inspection (parity tests, info dicts) ---------------------------------------------------------------- */
 int lobsim_get_env_state(lobsim_t* h, int32_t env, lobsim_env_state* out);
 /* Device-side bulk read of (inventory, cash, price) for all envs into host arrays (any may be NULL). */
@@ -290,6 +342,32 @@ int lobsim_debug_set_book(lobsim_t* h, int32_t env, const int64_t* snapshot_row,
  * NULL) receives the aggregate fills {agent_fill_count, agent_buy_vol, agent_sell_vol, ext_buy_count,
  * ext_sell_count, ext_buy_vol, ext_sell_vol, cash_delta}. */
 int lobsim_debug_process_orders(lobsim_t* h, int32_t env, const int64_t* orders, int32_t n, int64_t* fills_out);
+
+/* --- simulator-level entry (rl4mm/simulation/OrderbookSimulator.py:55-88 on its own: no env, no features, no warm-up) -------- */
+/* OrderbookSimulator.reset_episode(start) (:55-68) for n envs: central book <- the last snapshot at or before start_us
+ * (get_historical_start_book, :90-97), internal book emptied, initial price ranges (:185-188), clock = start_us (whole seconds,
+ * :61).  No snapshot there: LOBSIM_ST_STREAM_END on that env. */
+int lobsim_reset_episode(lobsim_t* h, const int32_t* env_ids, int32_t n, const int32_t* stream_ids, const int64_t* start_us);
+enum lobsim_forward_flags {
+    LOBSIM_FWD_UPDATE_FEATURES = 1 /* after the step: state.price = microprice, Feature.update(state) for every feature of the
+                                      cfg on the step's fills (Features.py:80-86), values to obs - the reference's feature tests */
+};
+/* OrderbookSimulator.forward_step(until, internal_orders) (:70-88) for n envs: env i first processes its n_orders[i] internal
+ * orders - rows orders[i][0 .. n_orders[i]) of [max_orders][6], the row format of lobsim_debug_process_orders - then the
+ * messages of (now, until_us[i]], sets its clock to until_us[i] and, on a whole second and near the edge of its initial price
+ * range, runs update_outer_levels (:99-135).  until <= now is the reference's assert: LOBSIM_ST_ASSERT.  Every fill of the call
+ * goes to the env's fill log (lobsim_get_fills).  orders / n_orders may be NULL (no internal orders); obs (host, [n][obs_dim])
+ * may be NULL. */
+int lobsim_forward(lobsim_t* h, const int32_t* env_ids, int32_t n, const int64_t* until_us, const int64_t* orders,
+                   const int32_t* n_orders, int32_t max_orders, int32_t flags, double* obs);
+/* FilledOrders of the env's last lobsim_forward (rl4mm/orderbook/models.py:104-107): rows {list, side, price, volume} with
+ * list 0 = .internal (the agent's resting orders that were hit, by their side; the agent's aggressing fills, one MarketOrder copy
+ * at the fill price per resting order), then list 1 = .external (resting external orders, by their side), each in fill order.
+ * *n_out = rows of the step; at most max_rows are written.  LOBSIM_ERR_NOMEM if the step made more fills per list than the log
+ * holds (lobsim_limits.fill_log_rows; the rows that fit are still returned). */
+int lobsim_get_fills(lobsim_t* h, int32_t env, int64_t* out, int32_t max_rows, int32_t* n_out);
+/* Feature.reset(state) on the simulator's current state for every feature of the cfg (Features.py:88-96), first usage = now. */
+int lobsim_features_reset(lobsim_t* h, const int32_t* env_ids, int32_t n);
 
 #ifdef __cplusplus
 }

@@ -543,9 +543,9 @@ static Order order_from_message(const int64_t* m) {
 }
 
 /* forward_step, :70-88: agent orders first, then the window (now, until] of historical messages */
-static void forward_step(oracle_t* h, Env* e, int64_t until, Order* internal, int n_internal) {
+static void forward_step_impl(oracle_t* h, Env* e, int64_t until, Order* internal, int n_internal, int keep_fills) {
     Ctx c = {e, &e->fin, &e->fex};
-    e->fin.n = e->fex.n = 0;
+    if (!keep_fills) e->fin.n = e->fex.n = 0;
     for (int i = 0; i < n_internal && !e->status; i++) process_order(&c, &internal[i]);
     if (e->stream_id >= 0) {
         const Stream* st = &h->streams[e->stream_id];
@@ -562,6 +562,11 @@ static void forward_step(oracle_t* h, Env* e, int64_t until, Order* internal, in
     if (e->stream_id >= 0 && until / 1000000 >= h->streams[e->stream_id].end_sec) { e->status |= LOBSIM_ST_STREAM_END; return; }
     if (e->stream_id >= 0 && near_exit(h, e) && e->now_us % 1000000 == 0) update_outer_levels(h, e, &c);
 }
+
+static void forward_step(oracle_t* h, Env* e, int64_t until, Order* internal, int n_internal) { forward_step_impl(h, e, until, internal, n_internal, 0); }
+/* (oracle_forward: the internal orders of the call - whose cancellations name their target by FIFO rank at that moment - were
+ * processed by the caller, their fills already in the lists) */
+static void forward_step_keep_fills(oracle_t* h, Env* e, int64_t until) { forward_step_impl(h, e, until, NULL, 0, 1); }
 
 /* reset_episode + get_historical_start_book, :55-68, 90-97 */
 static void reset_episode(oracle_t* h, Env* e, int64_t start_us, const int64_t* explicit_row) {
@@ -1343,13 +1348,15 @@ void oracle_set_threads(int n) {
 /* Beta action -> integer volumes (pinned against scipy in tests/golden/beta_table.npz). */
 void oracle_beta_volumes(const lobsim_cfg* cfg, const double* action, int64_t* buy, int64_t* sell) { beta_volumes(cfg, action, buy, sell); }
 
-/* Fill lists of the last step: out [max][4] = {list (0 internal, 1 external), side, price, volume}. */
-int oracle_get_fills(oracle_t* h, int32_t env, int64_t* out, int32_t max) {
+/* FilledOrders of the last step / forward: out [max_rows][4] = {list (0 internal, 1 external), side, price, volume} (lobsim.h). */
+int oracle_get_fills(oracle_t* h, int32_t env, int64_t* out, int32_t max_rows, int32_t* n_out) {
+    if (!h || env < 0 || env >= h->cfg.n_envs || !n_out || max_rows < 0 || (max_rows && !out)) return LOBSIM_ERR_ARG;
     Env* e = &h->env[env];
     int n = 0;
-    for (int i = 0; i < e->fin.n && n < max; i++, n++) { out[4 * n] = 0; out[4 * n + 1] = e->fin.f[i].side; out[4 * n + 2] = e->fin.f[i].price; out[4 * n + 3] = e->fin.f[i].vol; }
-    for (int i = 0; i < e->fex.n && n < max; i++, n++) { out[4 * n] = 1; out[4 * n + 1] = e->fex.f[i].side; out[4 * n + 2] = e->fex.f[i].price; out[4 * n + 3] = e->fex.f[i].vol; }
-    return n;
+    for (int i = 0; i < e->fin.n && n < max_rows; i++, n++) { out[4 * n] = 0; out[4 * n + 1] = e->fin.f[i].side; out[4 * n + 2] = e->fin.f[i].price; out[4 * n + 3] = e->fin.f[i].vol; }
+    for (int i = 0; i < e->fex.n && n < max_rows; i++, n++) { out[4 * n] = 1; out[4 * n + 1] = e->fex.f[i].side; out[4 * n + 2] = e->fex.f[i].price; out[4 * n + 3] = e->fex.f[i].vol; }
+    *n_out = e->fin.n + e->fex.n;
+    return LOBSIM_OK;
 }
 
 /* Agent order list of the *next* step for `action` without processing it (convert_action_to_orders):
@@ -1367,36 +1374,89 @@ int oracle_peek_agent_orders(oracle_t* h, int32_t env, const double* action, int
     return n;
 }
 
-/* Run one simulator step with no agent to time `until_us` (OrderbookSimulator.forward_step alone, no features). */
-int oracle_debug_forward(oracle_t* h, int32_t env, int32_t stream_id, int64_t until_us) {
-    Env* e = &h->env[env];
-    e->stream_id = stream_id;
-    forward_step(h, e, until_us, NULL, 0);
-    return e->status;
+/* --- simulator-level entry (lobsim.h): OrderbookSimulator.reset_episode / forward_step on their own ------------------------ */
+int oracle_abi_version(void) { return LOBSIM_ABI_VERSION; }
+
+int oracle_get_limits(const oracle_t* h, lobsim_limits* out) { /* the restatement's containers are unbounded, like the reference's */
+    if (!h || !out) return LOBSIM_ERR_ARG;
+    memset(out, 0, sizeof(*out));
+    out->level_slabs = out->far_levels = out->queue_slots = out->agent_orders = out->fill_log_rows = INT32_MAX;
+    return LOBSIM_OK;
 }
 
-/* Feature-level known answers (rl4mm/features/tests/testFeatures.py): feature.reset(state) on the current simulator
- * state, then one forward step without agent orders + feature.update(state) per call; obs [n_features] gets the values. */
-int oracle_debug_features_reset(oracle_t* h, int32_t env) {
-    Env* e = &h->env[env];
-    if (!book_microprice(&e->ex.central, &e->price)) e->price = 0.0;
-    e->fin.n = e->fex.n = 0;
-    for (int f = 0; f < h->cfg.n_features; f++) feature_reset(h, e, &e->feat[f], e->now_us);
-    return e->status;
-}
-int oracle_debug_feature_step(oracle_t* h, int32_t env, double* obs) {
-    Env* e = &h->env[env];
-    env_forward(h, e, NULL, 0);
-    if (e->status) return e->status;
-    for (int f = 0; f < h->cfg.n_features; f++) feature_update(h, e, &e->feat[f]);
-    for (int f = 0; f < h->cfg.n_features; f++) obs[f] = e->feat[f].current_value;
-    return e->status;
+int oracle_get_status(oracle_t* h, int32_t* status) {
+    if (!h || !status) return LOBSIM_ERR_ARG;
+    for (int i = 0; i < h->cfg.n_envs; i++) status[i] = h->env[i].status;
+    return LOBSIM_OK;
 }
 
-int oracle_debug_reset_episode(oracle_t* h, int32_t env, int32_t stream_id, int64_t start_us) {
-    Env* e = &h->env[env];
-    e->status = 0; e->stream_id = stream_id; e->n_resyncs = 0;
-    reset_episode(h, e, start_us, NULL);
-    e->terminal_us = INT64_MAX / 4;
-    return e->status;
+int oracle_reset_episode(oracle_t* h, const int32_t* env_ids, int32_t n, const int32_t* stream_ids, const int64_t* start_us) {
+    if (!h || n <= 0 || n > h->cfg.n_envs || !stream_ids || !start_us) return LOBSIM_ERR_ARG;
+    for (int i = 0; i < n; i++) {
+        int id = env_ids ? env_ids[i] : i;
+        if (id < 0 || id >= h->cfg.n_envs || stream_ids[i] < 0 || stream_ids[i] >= h->n_streams || start_us[i] % 1000000 != 0) return LOBSIM_ERR_ARG;
+    }
+    for (int i = 0; i < n; i++) {
+        Env* e = &h->env[env_ids ? env_ids[i] : i];
+        e->status = 0; e->stream_id = stream_ids[i]; e->n_resyncs = 0;
+        e->min_buy_price = INFINITY; e->max_sell_price = 0; e->initial_buy_range = INFINITY; e->initial_sell_range = INFINITY;
+        reset_episode(h, e, start_us[i], NULL);
+        e->terminal_us = INT64_MAX / 4;
+        e->fin.n = e->fex.n = 0;
+        if (!book_microprice(&e->ex.central, &e->price)) e->price = 0.0;
+    }
+    return LOBSIM_OK;
+}
+
+int oracle_forward(oracle_t* h, const int32_t* env_ids, int32_t n, const int64_t* until_us, const int64_t* orders, const int32_t* n_orders,
+                   int32_t max_orders, int32_t flags, double* obs) {
+    if (!h || n <= 0 || n > h->cfg.n_envs || !until_us || max_orders < 0 || ((orders == NULL) != (n_orders == NULL))) return LOBSIM_ERR_ARG;
+    const int D = oracle_obs_dim(h);
+    for (int i = 0; i < n; i++) {
+        int id = env_ids ? env_ids[i] : i;
+        if (id < 0 || id >= h->cfg.n_envs || (n_orders && (n_orders[i] < 0 || n_orders[i] > max_orders))) return LOBSIM_ERR_ARG;
+    }
+    for (int i = 0; i < n; i++) {
+        Env* e = &h->env[env_ids ? env_ids[i] : i];
+        if (obs) for (int f = 0; f < D; f++) obs[(size_t)i * D + f] = 0.0;
+        if (e->status) { e->fin.n = e->fex.n = 0; continue; }
+        if (!(until_us[i] > e->now_us)) { e->status |= LOBSIM_ST_ASSERT; e->fin.n = e->fex.n = 0; continue; } /* :71-73 */
+        int ni = n_orders ? n_orders[i] : 0;
+        /* agent cancellations name their target by FIFO rank at the price: resolved as each order is reached, so rows are
+         * converted one at a time (forward_step processes the list in order; ranks refer to the book at that moment) */
+        Ctx c = {e, &e->fin, &e->fex};
+        e->fin.n = e->fex.n = 0;
+        for (int k = 0; k < ni && !e->status; k++) {
+            const int64_t* r = orders + ((size_t)i * max_orders + k) * 6;
+            Order o = {(int)r[0], (int)r[1], r[2], r[3], IID_NONE, r[4], (int)r[5]};
+            if (!o.is_ext && (o.type == LOBSIM_CANCELLATION || o.type == LOBSIM_DELETION)) {
+                Level* l = side_find(&e->ex.internal.s[o.side], o.price);
+                if (l && r[4] >= 0 && r[4] < l->n) o.iid = l->q[r[4]].iid; else o.iid = INT64_MAX / 2;
+            }
+            process_order(&c, &o);
+        }
+        if (!e->status) forward_step_keep_fills(h, e, until_us[i]);
+        if (e->status) continue;
+        update_portfolio(e);
+        if (flags & LOBSIM_FWD_UPDATE_FEATURES) {
+            if (!book_microprice(&e->ex.central, &e->price)) { e->status |= LOBSIM_ST_EMPTY_BOOK; continue; }
+            for (int f = 0; f < h->cfg.n_features; f++) feature_update(h, e, &e->feat[f]);
+            if (obs) for (int f = 0; f < h->cfg.n_features; f++) obs[(size_t)i * D + f] = e->feat[f].current_value;
+        }
+    }
+    return LOBSIM_OK;
+}
+
+int oracle_features_reset(oracle_t* h, const int32_t* env_ids, int32_t n) {
+    if (!h || n <= 0 || n > h->cfg.n_envs) return LOBSIM_ERR_ARG;
+    for (int i = 0; i < n; i++) {
+        int id = env_ids ? env_ids[i] : i;
+        if (id < 0 || id >= h->cfg.n_envs) return LOBSIM_ERR_ARG;
+        Env* e = &h->env[id];
+        if (e->status) continue;
+        if (!book_microprice(&e->ex.central, &e->price)) e->price = 0.0;
+        e->fin.n = e->fex.n = 0;
+        for (int f = 0; f < h->cfg.n_features; f++) feature_reset(h, e, &e->feat[f], e->now_us);
+    }
+    return LOBSIM_OK;
 }

@@ -14,6 +14,8 @@ import numpy as np
 
 MAX_FEATURES = 16
 MAX_ACTION_DIM = 5
+ABI_VERSION = 4  # LOBSIM_ABI_VERSION of the include/lobsim.h this file mirrors
+FWD_UPDATE_FEATURES = 1  # enum lobsim_forward_flags
 
 # status bits (include/lobsim.h: enum lobsim_status)
 ST_EMPTY_BOOK, ST_BAD_MESSAGE, ST_LEVEL_OVERFLOW, ST_QUEUE_OVERFLOW = 1, 2, 4, 8
@@ -112,6 +114,18 @@ class OrderView(C.Structure):
     _fields_ = [("id", C.c_int64), ("volume", C.c_int64), ("kind", C.c_int32), ("reserved", C.c_int32)]
 
 
+class Limits(C.Structure):
+    _fields_ = [("level_slabs", C.c_int32), ("ladder_levels", C.c_int32), ("far_levels", C.c_int32), ("queue_slots", C.c_int32),
+                ("agent_orders", C.c_int32), ("fill_log_rows", C.c_int32), ("bytes_per_env", C.c_int64)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class HostIO(C.Structure):
+    _fields_ = [("actions", C.c_void_p), ("active", C.c_void_p), ("obs", C.c_void_p), ("obs_f32", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p)]
+
+
 ORDER_VIEW_DTYPE = np.dtype([("id", "<i8"), ("volume", "<i8"), ("kind", "<i4"), ("reserved", "<i4")])
 
 _P64 = C.POINTER(C.c_int64)
@@ -122,6 +136,7 @@ _PU8 = C.POINTER(C.c_uint8)
 
 # name -> (restype, argtypes); every symbol include/lobsim.h declares
 PROTOTYPES = {
+    "abi_version": (C.c_int, []),
     "create": (C.c_int, [C.POINTER(Cfg), C.POINTER(C.c_void_p)]),
     "destroy": (None, [C.c_void_p]),
     "last_error": (C.c_char_p, [C.c_void_p]),
@@ -141,11 +156,22 @@ PROTOTYPES = {
     "get_best_prices": (C.c_int, [C.c_void_p, _P64, _P64]),
     "get_book": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _P64, _P64, _P32, C.c_int32, _P32]),
     "get_level_orders": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(OrderView), C.c_int32, _P32]),
+    "get_limits": (C.c_int, [C.c_void_p, C.POINTER(Limits)]),
+    "get_status": (C.c_int, [C.c_void_p, _P32]),
+    "host_io_buffers": (C.c_int, [C.c_void_p, C.POINTER(HostIO)]),
+    "step_host_io": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "step_device_skip": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "reset_device": (C.c_int, [C.c_void_p, _P32, C.c_int32, _P32, _P64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "reset_episode": (C.c_int, [C.c_void_p, _P32, C.c_int32, _P32, _P64]),
+    "forward": (C.c_int, [C.c_void_p, _P32, C.c_int32, _P64, _P64, _P32, C.c_int32, C.c_int32, _PD]),
+    "get_fills": (C.c_int, [C.c_void_p, C.c_int32, _P64, C.c_int32, _P32]),
+    "features_reset": (C.c_int, [C.c_void_p, _P32, C.c_int32]),
     "debug_set_book": (C.c_int, [C.c_void_p, C.c_int32, _P64, C.c_int64]),
     "debug_process_orders": (C.c_int, [C.c_void_p, C.c_int32, _P64, C.c_int32, _P64]),
 }
 # the oracle has no device entry points
-ORACLE_SKIP = {"set_stream", "step_device", "sync", "rollout_device", "set_info_buffer", "set_trace_buffer"}
+ORACLE_SKIP = {"set_stream", "step_device", "sync", "rollout_device", "set_info_buffer", "set_trace_buffer", "host_io_buffers", "step_host_io",
+               "step_device_skip", "reset_device"}
 
 
 def _ptr(a: Optional[np.ndarray], typ):
@@ -171,6 +197,9 @@ class Binding:
             f.restype = res
             f.argtypes = args
             self.fn[name] = f
+        got = self.fn["abi_version"]()
+        if got != ABI_VERSION:  # (a prebuilt library from before a struct changed would read lobsim_cfg at the wrong offsets)
+            raise LobsimError(f"{self.path}: {prefix}abi_version() = {got}, this binding mirrors include/lobsim.h at version {ABI_VERSION}: rebuild the library")
 
 
 def make_feature(kind, lookback=0, update_us=100_000, min_value=0.0, max_value=0.0, dparam=0.0, iparam=0, norm_len=0) -> FeatureDesc:
@@ -289,14 +318,90 @@ class Sim:
     def step(self, actions, active=None):
         actions = np.ascontiguousarray(actions, dtype=np.float64).reshape(self.n_envs, self.action_dim)
         act = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
-        obs = np.empty((self.n_envs, self.obs_dim), dtype=np.float64)  # (the call writes all three in full)
-        reward = np.empty(self.n_envs, dtype=np.float64)
-        done = np.empty(self.n_envs, dtype=np.uint8)
+        # (the HIP library writes all three in full; the oracle leaves the rows of envs it does not step alone, so with a mask they
+        # start as zeros)
+        alloc = np.empty if act is None else np.zeros
+        obs = alloc((self.n_envs, self.obs_dim), dtype=np.float64)
+        reward = alloc(self.n_envs, dtype=np.float64)
+        done = alloc(self.n_envs, dtype=np.uint8)
         self._check(self.b.fn["step"](self.h, _ptr(actions, _PD), _ptr(act, _PU8), _ptr(obs, _PD), _ptr(reward, _PD), _ptr(done, _PU8)), "step")
         return obs, reward, done
 
     def step_device(self, d_actions: int, d_active: int, d_obs: int, d_obs_f32: int, d_reward: int, d_done: int, d_return_acc: int = 0):
         self._check(self.b.fn["step_device"](self.h, d_actions, d_active, d_obs, d_obs_f32, d_reward, d_done, d_return_acc), "step_device")
+
+    def step_device_skip(self, d_actions: int, d_skip: int, d_obs: int, d_obs_f32: int, d_reward: int, d_done: int, d_return_acc: int = 0):
+        self._check(self.b.fn["step_device_skip"](self.h, d_actions, d_skip, d_obs, d_obs_f32, d_reward, d_done, d_return_acc), "step_device_skip")
+
+    def reset_device(self, episode_start_us, stream_ids, env_ids, d_obs: int, d_obs_f32: int, d_done: int):
+        ids = np.arange(self.n_envs, dtype=np.int32) if env_ids is None else np.ascontiguousarray(env_ids, dtype=np.int32)
+        sids = np.ascontiguousarray(np.broadcast_to(np.asarray(stream_ids, dtype=np.int32), ids.shape))
+        starts = np.ascontiguousarray(np.broadcast_to(np.asarray(episode_start_us, dtype=np.int64), ids.shape))
+        self._check(self.b.fn["reset_device"](self.h, _ptr(ids, _P32), len(ids), _ptr(sids, _P32), _ptr(starts, _P64), d_obs, d_obs_f32, d_done), "reset_device")
+
+    def host_io(self) -> dict:
+        """numpy views of the handle's pinned step buffers (lobsim_host_io_buffers): fill ``actions``, call step_host_io, read the rest in place."""
+        io = HostIO()
+        self._check(self.b.fn["host_io_buffers"](self.h, C.byref(io)), "host_io_buffers")
+        N, A, D = self.n_envs, self.action_dim, self.obs_dim
+
+        def view(addr, ctype, shape):
+            n = int(np.prod(shape))
+            return np.ctypeslib.as_array((ctype * n).from_address(addr)).reshape(shape)
+
+        return dict(actions=view(io.actions, C.c_double, (N, A)), active=view(io.active, C.c_uint8, (N,)), obs=view(io.obs, C.c_double, (N, D)),
+                    obs_f32=view(io.obs_f32, C.c_float, (N, D)), reward=view(io.reward, C.c_double, (N,)), done=view(io.done, C.c_uint8, (N,)))
+
+    def step_host_io(self, use_active: bool = False, want_obs: int = 1):
+        self._check(self.b.fn["step_host_io"](self.h, int(bool(use_active)), int(want_obs)), "step_host_io")
+
+    def limits(self) -> dict:
+        lim = Limits()
+        self._check(self.b.fn["get_limits"](self.h, C.byref(lim)), "get_limits")
+        return lim.as_dict()
+
+    def status(self) -> np.ndarray:
+        out = np.zeros(self.n_envs, dtype=np.int32)
+        self._check(self.b.fn["get_status"](self.h, _ptr(out, _P32)), "get_status")
+        return out
+
+    # ---- simulator level (OrderbookSimulator.reset_episode / forward_step) ---------------------------------------
+    def reset_episode(self, start_us, stream_ids=0, env_ids=None):
+        ids = np.arange(self.n_envs, dtype=np.int32) if env_ids is None else np.ascontiguousarray(env_ids, dtype=np.int32)
+        sids = np.ascontiguousarray(np.broadcast_to(np.asarray(stream_ids, dtype=np.int32), ids.shape))
+        starts = np.ascontiguousarray(np.broadcast_to(np.asarray(start_us, dtype=np.int64), ids.shape))
+        self._check(self.b.fn["reset_episode"](self.h, _ptr(ids, _P32), len(ids), _ptr(sids, _P32), _ptr(starts, _P64)), "reset_episode")
+
+    def forward(self, until_us, orders=None, env_ids=None, update_features: bool = False):
+        """orders: None, or one [k_i, 6] array per env (rows {type, side, price, volume (-1 none), id, is_external}).  Returns the
+        features' values [n, obs_dim] when update_features, else None."""
+        ids = np.arange(self.n_envs, dtype=np.int32) if env_ids is None else np.ascontiguousarray(env_ids, dtype=np.int32)
+        until = np.ascontiguousarray(np.broadcast_to(np.asarray(until_us, dtype=np.int64), ids.shape))
+        rows = n_ord = None
+        max_orders = 0
+        if orders is not None:
+            per_env = [np.ascontiguousarray(o, dtype=np.int64).reshape(-1, 6) for o in orders]
+            assert len(per_env) == len(ids)
+            max_orders = max(1, max(len(o) for o in per_env))
+            rows = np.zeros((len(ids), max_orders, 6), dtype=np.int64)
+            n_ord = np.array([len(o) for o in per_env], dtype=np.int32)
+            for i, o in enumerate(per_env):
+                rows[i, : len(o)] = o
+        obs = np.zeros((len(ids), self.obs_dim), dtype=np.float64) if update_features else None
+        self._check(self.b.fn["forward"](self.h, _ptr(ids, _P32), len(ids), _ptr(until, _P64), _ptr(rows, _P64), _ptr(n_ord, _P32), max_orders,
+                                         FWD_UPDATE_FEATURES if update_features else 0, _ptr(obs, _PD)), "forward")
+        return obs
+
+    def fills(self, env: int = 0, cap: int = 8192) -> np.ndarray:
+        """FilledOrders of the env's last forward: int64 rows {list (0 internal / 1 external), side, price, volume}."""
+        out = np.zeros((cap, 4), dtype=np.int64)
+        n = C.c_int32(0)
+        self._check(self.b.fn["get_fills"](self.h, env, _ptr(out, _P64), cap, C.byref(n)), "get_fills")
+        return out[: min(n.value, cap)]
+
+    def features_reset(self, env_ids=None):
+        ids = np.arange(self.n_envs, dtype=np.int32) if env_ids is None else np.ascontiguousarray(env_ids, dtype=np.int32)
+        self._check(self.b.fn["features_reset"](self.h, _ptr(ids, _P32), len(ids)), "features_reset")
 
     def rollout_device(self, policy: int, params, T: int, d_actions: int, d_active: int, d_obs: int, d_obs_f32: int, d_reward: int, d_done: int,
                        d_return_acc: int = 0, d_steps_taken: int = 0):

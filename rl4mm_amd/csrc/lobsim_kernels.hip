@@ -97,7 +97,7 @@ struct StepArgs {
     double* return_acc;     // or null: per-env sum of rewards (episode return), accumulated here
     // lobsim_rollout_device with T == 1 runs here too: the action of an on-device policy is worked out in the prologue
     int32_t policy;         // LOBSIM_POLICY_GIVEN: `actions` holds it
-    int32_t pad;
+    int32_t skip_mode;      // 0: `active` names the envs to step; 1: it names the envs NOT to step (lobsim_step_device_skip)
     double params[8];       // policy parameters (lobsim.h)
     int32_t* steps_taken;   // or null: 1 per env that stepped, 0 for an env that was already done
     double* info;           // or null: [n_envs][LOBSIM_INFO_DIM] info arrays (lobsim_set_info_buffer)
@@ -108,6 +108,9 @@ struct ResetArgs {
     const int32_t* stream_ids;
     const int64_t* start_us;
     double* obs;  // [n][obs_dim] or null
+    float* obs_f32;       // [n][obs_dim] or null
+    uint8_t* done_clear;  // [n_envs] or null: the reset envs' done flags are cleared (lobsim_reset_device)
+    int32_t rows_by_env;  // 0: env_ids[k]'s observation goes to row k; 1: to row env_ids[k] (lobsim_reset_device: the caller's [n_envs] buffers)
 };
 
 struct RolloutArgs {
@@ -125,6 +128,19 @@ struct RolloutArgs {
     double* trace;          // or null: [T][n_envs][LOBSIM_TRACE_DIM] per-step series (lobsim_set_trace_buffer)
 };
 
+struct ForwardArgs {  // lobsim_forward: OrderbookSimulator.forward_step for the listed envs
+    const int32_t* env_ids;   // [n]
+    const int64_t* until_us;  // [n]
+    const int64_t* orders;    // [n][max_orders][6] internal orders (rows as in lobsim_debug_process_orders), or null
+    const int32_t* n_orders;  // [n], or null
+    int32_t max_orders;
+    int32_t flags;            // LOBSIM_FWD_*
+    double* obs;              // [n][obs_dim] (LOBSIM_FWD_UPDATE_FEATURES), or null
+    int64_t* flog;            // [n_envs][2][flog_cap][4] fill log: rows {side, price, volume, 0} of FilledOrders.internal / .external
+    int32_t* flog_n;          // [n_envs][2] fills per list of the last forward (may exceed flog_cap: rows beyond it were dropped)
+    int32_t flog_cap;
+};
+
 typedef long long ll2_t __attribute__((ext_vector_type(2)));
 struct alignas(16) I64x2 { int64_t x, y; };
 
@@ -135,7 +151,9 @@ struct alignas(16) I64x2 { int64_t x, y; };
 // from the touch (min_quote_level 0, max_quote_level 10), tick 100, 0.1 s steps, a 4-dim action, no concentration / market
 // order clearing / enter_spread (rl4mm/helpers/main_helper.py:70-100; lobsim_host.inc picks it when the cfg says exactly
 // that).  Measured +3 % per step; every other configuration reads the same values from the kernel arguments.
-template <int LVT, bool SPEC = false>
+// LOG = the simulator-level kernels (lobsim_forward): every fill is written to a per-env fill log, the FilledOrders lists that
+// OrderbookSimulator.forward_step returns (OrderbookSimulator.py:70-88).  A separate instantiation: the env-step kernels carry none of it.
+template <int LVT, bool SPEC = false, bool LOG = false>
 struct Eng {
 static constexpr int LV = LVT;
 static constexpr int HALVES = LVT / 64;  // ladder entries per lane
@@ -167,6 +185,7 @@ struct Lds {
         // the feature phase (one HBM round trip less at the end of the step)
         int64_t rstash[LOBSIM_MAX_FEATURES][2];
         double act[LOBSIM_MAX_ACTION_DIM];  // rollout kernel: the step's action, needed again only by the trace and at the end of the launch
+        struct { int64_t* rows; uint32_t n[2]; uint32_t cap; } flog;  // forward kernel (LOG): this env's fill log [2][cap][4] and the rows written per list
     };
     int32_t info_q[4];  // SimpleInfoCalculator: first quoted level and volume-weighted level sum per side of this step's action
     // Wave-uniform state that is touched rarely (a level opens or empties, the agent trades, an execution is counted).
@@ -919,6 +938,22 @@ SDI int32_t cuts_inside(const int32_t* cuts, int n_cuts, int32_t from, int32_t e
     return lo_a - lo_b;
 }
 
+// (LOG) one row per fill, FIFO order kept: lanes with p append {side, price, vol} to list 0 (FilledOrders.internal) or 1 (.external).
+// Rows beyond the log's capacity are counted, not written (lobsim_get_fills reports the overflow).
+SDI void log_rows(Lds& L, bool p, int list, int side, int64_t price, int32_t vol) {
+    const uint64_t m = ballot(p);
+    if (!m) return;
+    const uint32_t base = (uint32_t)uni((int32_t)L.flog.n[list]), cap = (uint32_t)uni((int32_t)L.flog.cap);
+    int64_t* rows = reinterpret_cast<int64_t*>(uni64(reinterpret_cast<int64_t>(L.flog.rows)));
+    const uint32_t at = base + (uint32_t)popc64(m & ((1ull << lane()) - 1));
+    if (p && at < cap) {
+        int64_t* r = rows + ((size_t)list * cap + at) * 4;
+        r[0] = side; r[1] = price; r[2] = vol; r[3] = 0;
+    }
+    if (lane() == 0) L.flog.n[list] = base + (uint32_t)popc64(m);
+    wsync();
+}
+
 // execute_order (Exchange.py:85-120): the aggressor (side, limit price or market) sweeps the opposite side level by
 // level; inside a level all FIFO slots are matched at once with a prefix sum of the volume ahead.  Returns the
 // unfilled remainder.
@@ -962,6 +997,12 @@ SDI int32_t execute(Lds& L, Scal& S, int side, bool is_agent, bool is_market, in
                 Slot w = s; w.vol = nv; if (gone) w.kind = K_DEAD;
                 sl[i] = w;
                 if (is_ag) L.agent[s.id].vol = nv;
+            }
+            if constexpr (LOG) {  // the reference's fill records (:104-115): the resting order by its own side, at the level's price; an
+                                  // aggressing agent order gets a MarketOrder copy per resting fill
+                log_rows(L, reached && !own && !is_ag, 1, opp, bp, ex);
+                log_rows(L, reached && !own && is_ag, 0, opp, bp, ex);
+                if (is_agent) log_rows(L, reached && !own && !is_ag, 0, side, bp, ex);
             }
             uint64_t reached_agent = ballot(reached && is_ag);
             if (reached_agent) {  // rare: resting agent orders in the swept range
@@ -1798,7 +1839,7 @@ SDI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, 
                                   (((b.meta ^ mm) >> LOBSIM_SIDE_SHIFT) & 1) == 0 && lv > 0 && lv < (1 << 24);
                 const uint64_t sm = ballot(same) >> j;
                 const int run = sm == ~0ull ? 64 - j : ffs64(~sm);  // consecutive lanes from j on
-                if (run >= 2) {
+                if (!LOG && run >= 2) {  // (the fill log wants one record per execution message and resting order: no merged sweeps there)
 #ifdef LOBSIM_PROFILE
                     const uint64_t tr0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -2377,11 +2418,13 @@ SDI void run_agent_ops(Lds& L, Scal& S, const DevCfg& C) {
 
 // OrderbookSimulator.forward_step (:70-88) + update_internal_state (HistoricalOrderbookEnvironment.py:199-204):
 // agent ops first, then the message window, clock, resync check, new price.
+// `until_us` >= 0: the step ends there instead of one step_size ahead, and no price is worked out (OrderbookSimulator.forward_step
+// on its own, lobsim_forward: the simulator has no notion of a step size or of the env's microprice).
 SDI void advance_one_step(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, int stream_id, int64_t& cursor, int64_t& now_us,
                          Ranges& R, int& n_resyncs, double& price, bool with_ops, const MsgBatch& first, int64_t n_msgs, uint64_t ce_first = 0, bool have_ce = false,
-                         EnvHdr* lazy = nullptr) {
+                         EnvHdr* lazy = nullptr, int64_t until_us = -1) {
     if (with_ops) run_agent_ops(L, S, C);
-    int64_t until = now_us + CFG_STEP_US(C);
+    int64_t until = until_us >= 0 ? until_us : now_us + CFG_STEP_US(C);
     if (stream_id >= 0 && !S.status) replay_messages(L, S, P.streams[stream_id], cursor, until, first, ce_first, have_ce);
     now_us = until;
     if (S.status) return;
@@ -2415,7 +2458,7 @@ SDI void advance_one_step(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, in
             if (lazy && lane() == 0) { lazy->min_buy = R.min_buy; lazy->max_sell = R.max_sell; lazy->n_resyncs = n_resyncs; }
         }
     }
-    if (S.status) return;
+    if (S.status || until_us >= 0) return;
     if (!microprice(L, S, price)) S.status |= LOBSIM_ST_EMPTY_BOOK;
 }
 
@@ -2446,7 +2489,7 @@ template <bool EXTRAS>
 SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
     __shared__ Lds L;
     const int env = blockIdx.x, ln = lane();
-    if (A.active && !A.active[env]) return;
+    if (A.active && (A.active[env] != 0) == (A.skip_mode != 0)) return;
     EnvHdr& H = P.hdr[env];
     const int F = C.c.n_features, AD = CFG_ADIM(C), D = C.obs_dim;
 #ifdef LOBSIM_PROFILE
@@ -2812,7 +2855,10 @@ SDI void reset_body(const DevCfg& C, const DevPtrs& P, const ResetArgs& A) {
         if (ln < F) ok = feature_update<EXTRAS>(C.c.features[ln], fs, ring, v, norm_history(C, P, env, ln));
         if (ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
     }
-    if (ln < D && A.obs) A.obs[(size_t)k * D + ln] = ln < F ? fs.current_value : 0.0;  // zeros for the previous action (:158-159)
+    const size_t orow = A.rows_by_env ? (size_t)env : (size_t)k;
+    if (ln < D && A.obs) A.obs[orow * D + ln] = ln < F ? fs.current_value : 0.0;  // zeros for the previous action (:158-159)
+    if (ln < D && A.obs_f32) A.obs_f32[orow * D + ln] = ln < F ? (float)fs.current_value : 0.0f;
+    if (ln == 0 && A.done_clear) A.done_clear[env] = 0;
     if (ln < F) P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln] = fs;
     store_env(L, S, P, env, H);
     if (ln == 0) {
@@ -2843,8 +2889,44 @@ SDI void set_book_body(const DevCfg& C, const DevPtrs& P, int env, const int64_t
     }
 }
 
-// orders [n][6] = {type, side, price, volume (-1 none), id, is_external}; agent cancels address their target by
-// FIFO rank among the agent's orders at that price
+// one order row {type, side, price, volume (-1 none), id, is_external}; agent cancels address their target by FIFO rank
+// among the agent's orders at that price
+SDI void process_raw_order(Lds& L, Scal& S, const int64_t* r) {
+    const int ln = lane();
+    int type = (int)r[0], side = (int)r[1];
+    int64_t price = r[2], vol = r[3], id = r[4];
+    bool is_ext = r[5] != 0;
+    if (vol != -1 && !(vol > 0)) { S.status |= LOBSIM_ST_ASSERT; return; }
+    if (is_ext) {
+        if (type == LOBSIM_LIMIT) submit_limit(L, S, side, price, (int32_t)vol, false, id);
+        else if (type == LOBSIM_MARKET) execute(L, S, side, false, true, 0, (int32_t)vol);
+        else remove_order(L, S, side, price, K_EXT, id, (int32_t)vol);
+    } else if (type == LOBSIM_LIMIT) submit_limit(L, S, side, price, (int32_t)vol, true, 0);
+    else if (type == LOBSIM_MARKET) execute(L, S, side, true, true, 0, (int32_t)vol);
+    else {
+        // rank -> agent index: the id-th oldest live agent order at (side, price)
+        AgentOrd o0 = L.agent[ln], o1 = L.agent[ln + 64];
+        bool m0 = o0.vol > 0 && (int)(o0.seq_side >> 31) == side && o0.price == price;
+        bool m1 = o1.vol > 0 && (int)(o1.seq_side >> 31) == side && o1.price == price;
+        uint32_t q0 = o0.seq_side & 0x7fffffffu, q1 = o1.seq_side & 0x7fffffffu;
+        uint64_t b0 = ballot(m0), b1 = ballot(m1);
+        int older0 = 0, older1 = 0;
+        for (int rr = 0; rr < 2; rr++) {
+            uint64_t bb = rr ? b1 : b0;
+            while (bb) {
+                int t = ffs64(bb);
+                bb &= bb - 1;
+                uint32_t tq = (uint32_t)rl32((int32_t)(rr ? q1 : q0), t);
+                if (tq < q0) older0++;
+                if (tq < q1) older1++;
+            }
+        }
+        uint64_t h0 = ballot(m0 && older0 == id), h1 = ballot(m1 && older1 == id);
+        int aidx = h0 ? ffs64(h0) : (h1 ? 64 + ffs64(h1) : NA + 1000);
+        remove_order(L, S, side, price, K_AGENT, aidx, (int32_t)vol);
+    }
+}
+
 SDI void process_orders_body(const DevCfg& C, const DevPtrs& P, int env, const int64_t* orders, int n, int64_t* fills_out) {
     __shared__ Lds L;
     EnvHdr& H = P.hdr[env];
@@ -2853,48 +2935,139 @@ SDI void process_orders_body(const DevCfg& C, const DevPtrs& P, int env, const i
     load_env(L, S, P, env, H);
     clear_step_fills(L);
     const int64_t cash0 = cur_cash(L);
-    for (int k = 0; k < n && !S.status; k++) {
-        const int64_t* r = orders + 6 * (size_t)k;
-        int type = (int)r[0], side = (int)r[1];
-        int64_t price = r[2], vol = r[3], id = r[4];
-        bool is_ext = r[5] != 0;
-        if (vol != -1 && !(vol > 0)) { S.status |= LOBSIM_ST_ASSERT; break; }
-        if (is_ext) {
-            if (type == LOBSIM_LIMIT) submit_limit(L, S, side, price, (int32_t)vol, false, id);
-            else if (type == LOBSIM_MARKET) execute(L, S, side, false, true, 0, (int32_t)vol);
-            else remove_order(L, S, side, price, K_EXT, id, (int32_t)vol);
-        } else if (type == LOBSIM_LIMIT) submit_limit(L, S, side, price, (int32_t)vol, true, 0);
-        else if (type == LOBSIM_MARKET) execute(L, S, side, true, true, 0, (int32_t)vol);
-        else {
-            // rank -> agent index: the id-th oldest live agent order at (side, price)
-            AgentOrd o0 = L.agent[ln], o1 = L.agent[ln + 64];
-            bool m0 = o0.vol > 0 && (int)(o0.seq_side >> 31) == side && o0.price == price;
-            bool m1 = o1.vol > 0 && (int)(o1.seq_side >> 31) == side && o1.price == price;
-            uint32_t q0 = o0.seq_side & 0x7fffffffu, q1 = o1.seq_side & 0x7fffffffu;
-            uint64_t b0 = ballot(m0), b1 = ballot(m1);
-            int older0 = 0, older1 = 0;
-            for (int rr = 0; rr < 2; rr++) {
-                uint64_t bb = rr ? b1 : b0;
-                while (bb) {
-                    int t = ffs64(bb);
-                    bb &= bb - 1;
-                    uint32_t tq = (uint32_t)rl32((int32_t)(rr ? q1 : q0), t);
-                    if (tq < q0) older0++;
-                    if (tq < q1) older1++;
-                }
-            }
-            uint64_t h0 = ballot(m0 && older0 == id), h1 = ballot(m1 && older1 == id);
-            int aidx = h0 ? ffs64(h0) : (h1 ? 64 + ffs64(h1) : NA + 1000);
-            remove_order(L, S, side, price, K_AGENT, aidx, (int32_t)vol);
-        }
-        // make entries freed by this order reusable, like the reference (no step boundary at this level)
-    }
+    for (int k = 0; k < n && !S.status; k++) process_raw_order(L, S, orders + 6 * (size_t)k);
     if (ln == 0 && fills_out) {
         fills_out[0] = L.ag_cnt[0] + L.ag_cnt[1]; fills_out[1] = L.ag_vol[0]; fills_out[2] = L.ag_vol[1];
         fills_out[3] = L.ext_cnt[0]; fills_out[4] = L.ext_cnt[1]; fills_out[5] = L.ext_vol[0]; fills_out[6] = L.ext_vol[1];
         fills_out[7] = L.cash - cash0;
     }
     store_env(L, S, P, env, H);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// simulator-level entry points: OrderbookSimulator.reset_episode / forward_step on their own (OrderbookSimulator.py:55-88), the
+// surface the reference's simulator and feature tests drive (rl4mm/simulation/tests/testOrderbookSimulator.py:46-108,
+// rl4mm/features/tests/testFeatures.py:152-196)
+// ---------------------------------------------------------------------------------------------------------------
+// reset_episode(start): book <- last snapshot at or before `start` (get_historical_start_book), internal book emptied, price
+// ranges reset, clock = start.  No features, no warm-up, no terminal time.
+SDI void sim_reset_body(const DevCfg& C, const DevPtrs& P, const ResetArgs& A) {
+    __shared__ Lds L;
+    const int k = blockIdx.x, ln = lane();
+    const int env = A.env_ids[k];
+    EnvHdr& H = P.hdr[env];
+    const int Lv = C.c.n_levels;
+    Scal S;
+    S.slots = env_slabs(P, env);
+    S.idc = P.idc + (size_t)env * IDC_N;
+    S.status = 0; S.n_ops = 0;
+    if (ln == 0) { L.inv = H.inventory; L.cash = H.cash; }
+    ladder_clear(L, S, P.n_slab);
+    clear_step_fills(L);
+    const int stream_id = A.stream_ids[k];
+    const StreamDev& st = P.streams[stream_id];
+    const int64_t now = A.start_us[k];
+    int64_t sec = now / 1000000 - st.first_sec;
+    int32_t si = sec < 0 ? -1 : (sec >= st.n_secs ? (int32_t)st.n_snaps - 1 : st.sec_to_snap[sec]);
+    int64_t cursor = sec < 0 ? 0 : (sec >= st.n_secs ? st.n_msgs : st.sec_to_msg[sec]);
+    Ranges R = {(double)INFINITY, 0.0, (double)INFINITY, (double)INFINITY};
+    double price = 0.0;
+    if (si < 0) S.status |= LOBSIM_ST_STREAM_END;  // "There is no data before the episode start time" (:92)
+    if (!S.status) {
+        load_snapshot_book(L, S, st.snaps + (int64_t)si * (2 + 4 * Lv) + 2, Lv, false);
+        int64_t wb, ws;  // _reset_initial_price_ranges (:185-188)
+        if (!S.status && price_range(L, S, wb, ws)) {
+            R.min_buy = (double)wb; R.max_sell = (double)ws;
+            R.init_buy = best_buy_d(L, S) - R.min_buy; R.init_sell = R.max_sell - best_sell_d(L, S);
+        } else S.status |= LOBSIM_ST_EMPTY_BOOK;
+    }
+    if (!S.status && !microprice(L, S, price)) price = 0.0;
+    store_env(L, S, P, env, H);
+    if (ln == 0) {
+        H.now_us = now; H.terminal_us = INT64_MAX / 4; H.episode_start_us = now;
+        H.msg_cursor = cursor; H.stream_id = stream_id; H.price = price; H.n_resyncs = 0;
+        H.min_buy = R.min_buy; H.max_sell = R.max_sell; H.init_buy_range = R.init_buy; H.init_sell_range = R.init_sell;
+        for (int i = 0; i < LOBSIM_MAX_ACTION_DIM; i++) H.prev_action[i] = 0.0;
+    }
+}
+
+// forward_step(until, internal_orders): the internal orders first, then the messages of (now, until], clock = until, the
+// outer-level resync when `until` is a whole second and the book is near the edge of its initial range; every fill logged.
+// With LOBSIM_FWD_UPDATE_FEATURES the env's features are updated on the resulting state (microprice, the step's fills) and
+// written to obs: Feature.update as the reference's feature tests call it.
+SDI void forward_body(const DevCfg& C, const DevPtrs& P, const ForwardArgs& A) {
+    __shared__ Lds L;
+    const int k = blockIdx.x, ln = lane();
+    const int env = A.env_ids[k];
+    EnvHdr& H = P.hdr[env];
+    const int F = C.c.n_features, D = C.obs_dim;
+    Scal S;
+    load_env(L, S, P, env, H);
+    clear_step_fills(L);
+    if (ln == 0) { L.flog.rows = A.flog + (size_t)env * 2 * (size_t)A.flog_cap * 4; L.flog.n[0] = 0; L.flog.n[1] = 0; L.flog.cap = (uint32_t)A.flog_cap; }
+    wsync();
+    int64_t now = H.now_us, cursor = H.msg_cursor;
+    const int stream_id = H.stream_id;
+    const int64_t until = A.until_us[k];
+    const StreamDev& st0 = P.streams[stream_id >= 0 ? stream_id : 0];
+    const int64_t n_msgs = st0.n_msgs;
+    const int64_t* msgs0 = st0.msgs;
+    Ranges R = {0.0, 0.0, 0.0, 0.0};
+    int n_resyncs = 0;
+    double price = H.price;
+    const int entry_status = S.status;
+    if (!S.status && !lt64(now, until)) S.status |= LOBSIM_ST_ASSERT;  // assert until > self.now_is (:71-73)
+    const int n_int = A.n_orders ? A.n_orders[k] : 0;
+    for (int i = 0; i < n_int && !S.status; i++) process_raw_order(L, S, A.orders + ((size_t)k * A.max_orders + i) * 6);
+    if (!S.status) {
+        MsgBatch first = fetch_messages(msgs0, stream_id >= 0 ? cursor : 0);
+        if (stream_id < 0) first.t = INT64_MAX;
+        advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, false, first, n_msgs, 0, false, &H, until);
+    }
+    double val = 0.0;
+    if ((A.flags & LOBSIM_FWD_UPDATE_FEATURES) && !S.status) {
+        if (!microprice(L, S, price)) S.status |= LOBSIM_ST_EMPTY_BOOK;
+        if (!S.status) {
+            StepView v = make_view(L, S, price, now);
+            bool ok = true;
+            if (ln < F) {
+                FeatState fs = P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln];
+                ok = feature_update<true>(C.c.features[ln], fs, P.rings + (size_t)env * C.ring_words + C.ring_off[ln], v, norm_history(C, P, env, ln));
+                P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln] = fs;
+                val = fs.current_value;
+            }
+            if (ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
+        }
+    }
+    if (A.obs && ln < D) A.obs[(size_t)k * D + ln] = ln < F ? val : 0.0;
+    if (ln < 2) A.flog_n[(size_t)env * 2 + ln] = entry_status ? 0 : (int32_t)L.flog.n[ln];
+    store_env(L, S, P, env, H);
+    if (ln == 0 && !entry_status) { H.now_us = now; H.msg_cursor = cursor; H.price = price; }
+}
+
+// Feature.reset(state) for every feature on the simulator's current state (Features.py:88-96) with first_usage = now: the features
+// are live from the next forward step on, no warm-up (rl4mm/features/tests/testFeatures.py resets its features like this)
+SDI void features_reset_body(const DevCfg& C, const DevPtrs& P, const int32_t* env_ids) {
+    __shared__ Lds L;
+    const int env = env_ids[blockIdx.x], ln = lane();
+    EnvHdr& H = P.hdr[env];
+    const int F = C.c.n_features;
+    Scal S;
+    load_env(L, S, P, env, H);
+    const int64_t now = H.now_us;
+    double price = 0.0;
+    if (!microprice(L, S, price)) price = 0.0;
+    if (!S.status) {
+        StepView v = make_view(L, S, price, now);
+        bool ok = true;
+        if (ln < F) {
+            FeatState fs = FeatState();
+            ok = feature_reset(C.c.features[ln], fs, P.rings + (size_t)env * C.ring_words + C.ring_off[ln], v, now, norm_history(C, P, env, ln));
+            P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln] = fs;
+        }
+        if (ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
+    }
+    if (ln == 0) { H.price = price; H.status = S.status; }
 }
 
 };  // struct Eng
@@ -2922,6 +3095,18 @@ template <int LVT>
 __global__ __launch_bounds__(64) void lob_set_book_kernel(DevCfg C, DevPtrs P, int env, const int64_t* row, int64_t now_us) { Eng<LVT>::set_book_body(C, P, env, row, now_us); }
 template <int LVT>
 __global__ __launch_bounds__(64) void lob_process_orders_kernel(DevCfg C, DevPtrs P, int env, const int64_t* orders, int n, int64_t* fills_out) { Eng<LVT>::process_orders_body(C, P, env, orders, n, fills_out); }
+
+template <int LVT>
+__global__ __launch_bounds__(64) void lob_sim_reset_kernel(DevCfg C, DevPtrs P, ResetArgs A) { Eng<LVT>::sim_reset_body(C, P, A); }
+template <int LVT>
+__global__ __launch_bounds__(64) void lob_forward_kernel(DevCfg C, DevPtrs P, ForwardArgs A) { Eng<LVT, false, true>::forward_body(C, P, A); }
+template <int LVT>
+__global__ __launch_bounds__(64) void lob_features_reset_kernel(DevCfg C, DevPtrs P, const int32_t* env_ids) { Eng<LVT>::features_reset_body(C, P, env_ids); }
+
+__global__ void lob_gather_status_kernel(DevPtrs P, int n, int32_t* status) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) status[i] = P.hdr[i].status;
+}
 
 // (inventory, cash, price) of every env, coalesced
 __global__ void lob_gather_portfolios_kernel(DevPtrs P, int n, int64_t* inv, int64_t* cash, double* price) {

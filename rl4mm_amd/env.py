@@ -452,7 +452,23 @@ class HistoricalOrderbookVectorEnv(_RayVectorEnv):
     ``vector_reset / reset_at / vector_step`` have RLlib's list-of-per-env-values shape.  A caller that wants the batch
     as it comes off the device uses the ARRAY path: ``vector_reset_arrays() -> obs[N, D]``,
     ``vector_step_arrays(actions[N, A]) -> (obs[N, D], reward[N], done[N] bool, infos or None)`` - no per-env Python objects
-    (building 4 x 4096 list entries costs 35 x the kernel)."""
+    (building 4 x 4096 list entries costs 35 x the kernel); the kernel reads the actions from and writes its outputs to pinned
+    host memory itself (``lobsim_step_host_io``).  A learner that lives on the GPU - the reference's consumer is a torch PPO
+    learner (rl4mm/helpers/main_helper.py:260-261) - uses the TENSOR path: ``vector_reset_tensors() -> obs``,
+    ``vector_step_tensors(actions) -> (obs, reward, done)`` with torch tensors on the env's device, launched on torch's
+    current stream, nothing crossing PCIe and no host synchronisation per step.
+
+    Errors.  Where the reference raises inside ``step`` (``EmptyOrderbookError``, an assert: rl4mm/orderbook/Exchange.py:32-37,
+    59-60,180-186) or where a capacity of this implementation is exceeded, the env stops: it reports ``done=True`` once, with
+    ``infos[i]["error"]`` (list path) naming the condition, and ``env.status`` (int32[N], bits of ``enum lobsim_status``) says
+    which envs stopped and why on every path.  ``env.limits`` holds the capacities of the handle (``lobsim_get_limits``).
+
+    ``reset_at``.  RLlib resets finished envs one ``reset_at(i)`` call at a time, and every env of a batch ends its episode on
+    the same step.  A reset replays the features' warm-up (3000 steps for the default features) - tens of milliseconds of
+    latency for one env, but the same tens of milliseconds for 4096 of them in one launch.  So the first ``reset_at`` after a
+    step that reported dones resets ALL finished envs in one launch, drawing their start times in index order (the order in
+    which RLlib's loop calls ``reset_at``, so ``np.random`` ends where the one-at-a-time calls leave it), and the calls
+    for the other finished envs return their cached rows."""
 
     def __init__(
         self,
@@ -484,6 +500,7 @@ class HistoricalOrderbookVectorEnv(_RayVectorEnv):
         device_id: int = 0,
         ladder_levels: int = 0,
         max_levels: int = 0,
+        obs_dtype=np.float64,
     ):
         # action space, HistoricalOrderbookEnvironment.py:85-94
         if concentration is not None:
@@ -522,10 +539,14 @@ class HistoricalOrderbookVectorEnv(_RayVectorEnv):
             enter_spread=enter_spread, inc_prev_action_in_obs=inc_prev_action_in_obs, per_step_reward=self.per_step_reward_function.desc(),
             terminal_reward=self.terminal_reward_function.desc(), device_id=device_id,
             ladder_levels=ladder_levels,  # price levels per side kept ON CHIP (0 = 64 for books of <= 56 visible levels, else 128): a performance knob
-            max_levels=max_levels,  # price levels per side an env can hold in all (0 = 1024 if memory allows): the reference keeps stale levels that left
-                                    # LOBSTER's visible range for the rest of the episode - one per tick of price drift; beyond it an env stops with
-                                    # LOBSIM_ST_LEVEL_OVERFLOW
+            max_levels=max_levels,  # an env's budget of price levels (0 = 512: 2 x 512 levels over both sides, 8 MiB of device memory per env): the
+                                    # reference keeps stale levels that left LOBSTER's visible range for the rest of the episode - one per tick of
+                                    # price drift; beyond the budget an env stops with LOBSIM_ST_LEVEL_OVERFLOW (env.limits tells what the handle has)
         )  # fmt: skip
+        # observations as the reference returns them are float64 (np.array of Python floats, HistoricalOrderbookEnvironment.py:189-194); its
+        # observation_space is float32 (:131-135), which is what RLlib casts to anyway: obs_dtype=np.float32 has the kernel write that
+        self.obs_dtype = np.dtype(obs_dtype)
+        assert self.obs_dtype in (np.dtype(np.float64), np.dtype(np.float32)), "obs_dtype is float64 (the reference's arrays) or float32 (its observation_space)"
         if _RayVectorEnv is not object:
             super().__init__(self.observation_space, self.action_space, num_envs)
         self.sim = _lib.new_sim(cfg)  # raises if the HIP library or the GPU is missing: there is no CPU path
@@ -539,6 +560,17 @@ class HistoricalOrderbookVectorEnv(_RayVectorEnv):
         self._dones = np.zeros(num_envs, dtype=bool)
         self._any_done = False
         self._day_table = None
+        self.limits = self.sim.limits()  # capacities of this handle (lobsim_get_limits): level_slabs, queue_slots, agent_orders, ...
+        self.status = np.zeros(num_envs, dtype=np.int32)  # enum lobsim_status bits of the envs that stopped on an error (refreshed when a step reports done)
+        self._io = None          # pinned step buffers (array path), mapped on first use
+        self._reset_cache = {}   # env index -> first observation of a reset made ahead of its reset_at call
+        self._t = None           # tensor path state
+
+    def __repr__(self):
+        lim = self.limits
+        return (f"{type(self).__name__}(num_envs={self.num_envs}, ticker={self.ticker!r}, step_size={self.step_size}, obs_dtype={self.obs_dtype.name}, "
+                f"limits: {lim['level_slabs']} price levels per env (both sides; {lim['ladder_levels']} per side on chip), {lim['queue_slots']} orders per level, "
+                f"{lim['agent_orders']} agent orders, {lim['bytes_per_env'] / 2**20:.1f} MiB per env)")
 
     # ---- start-time draw: same np.random calls, in the same order, as the reference (:196, :333-351) -------------
     def _random_offset_timestamp(self) -> timedelta:
@@ -656,33 +688,170 @@ class HistoricalOrderbookVectorEnv(_RayVectorEnv):
         start_us = _us(self.min_start_timedelta) + off * _us(self.step_size)
         return sids.astype(np.int32), (start_us // 1_000_000) * 1_000_000  # "start episode on sec" (:341)
 
+    # ---- errors --------------------------------------------------------------------------------------------------
+    @staticmethod
+    def error_text(status: int) -> str:
+        """What a status word means, in the reference's words where it raises on the same condition."""
+        parts = []
+        if status & _capi.ST_EMPTY_BOOK:
+            parts.append("EmptyOrderbookError: Trying take liquidity from empty side of the book.")  # Exchange.py:186
+        if status & _capi.ST_ASSERT:
+            parts.append("AssertionError: Order volume must be positive.")  # Exchange.py:60 (and RollingSharpe's non-positive AUM)
+        if status & _capi.ST_BAD_MESSAGE:
+            parts.append("AssertionError: cross_trade / trading_halt message in the stream")  # HistoricalOrderGenerator.py:54-56
+        if status & _capi.ST_LEVEL_OVERFLOW:
+            parts.append("LOBSIM_ST_LEVEL_OVERFLOW: more price levels than the env's budget (max_levels; the reference never drops a level that left "
+                         "LOBSTER's visible range: one stale level per tick of price drift) - pass a larger max_levels (up to 2048) or shorten the episode")
+        if status & _capi.ST_QUEUE_OVERFLOW:
+            parts.append("LOBSIM_ST_QUEUE_OVERFLOW: more than 512 live orders at one price")
+        if status & _capi.ST_AGENT_OVERFLOW:
+            parts.append("LOBSIM_ST_AGENT_OVERFLOW: more than 128 live agent orders (entries freed in a step are reusable from the next one): fewer quote levels")
+        if status & _capi.ST_STREAM_END:
+            parts.append("LOBSIM_ST_STREAM_END: no snapshot at the episode's start, or stepped past the end of the loaded stream")
+        if status & _capi.ST_NOT_RESET:
+            parts.append("LOBSIM_ST_NOT_RESET: step() before reset()")
+        return "; ".join(parts) or f"status {status}"
+
+    def _note_dones(self, done: np.ndarray):
+        """Bookkeeping after a step that reported dones: which of them are errors (the reference would have raised)."""
+        self._dones |= done
+        self._any_done = True
+        self.status = self.sim.status()
+
     # ---- array path ------------------------------------------------------------------------------------------------
     def vector_reset_arrays(self) -> np.ndarray:
         sids, starts = self._draw(self.num_envs)
         obs = self.sim.reset(starts, sids)
         self._dones[:] = False
         self._any_done = False
-        return obs
+        self._reset_cache = {}
+        self.status = self.sim.status()
+        return obs.astype(self.obs_dtype, copy=False)
 
-    def vector_step_arrays(self, actions, want_infos: bool = True):
-        """-> (obs f64[N, D], reward f64[N], done bool[N], infos).  infos is None when there is no info calculator (the
-        reference's default) or when not asked for."""
-        actions = np.asarray(actions, dtype=np.float64)
-        active = (~self._dones).view(np.uint8) if self._any_done else None  # (nothing to mask until an env has finished)
-        obs, reward, done = self.sim.step(actions, active=active)
-        done = done.view(np.bool_)
-        if done.any():
-            self._dones |= done
-            self._any_done = True
-        infos = self.info_calculator.calculate_dicts(self.sim, actions) if (want_infos and self.info_calculator is not None) else None
+    def vector_step_arrays(self, actions, want_infos: bool = True, copy: bool = True):
+        """-> (obs obs_dtype[N, D], reward f64[N], done bool[N], infos).  infos is None when nothing is to be said (no info
+        calculator - the reference's default - and no env stopped on an error) or when not asked for; otherwise one dict per env.
+        copy=False returns views of the handle's pinned buffers, valid until the next step."""
+        if self._io is None:
+            self._io = self.sim.host_io()
+        io = self._io
+        self._reset_cache = {}  # (observations of resets made ahead of their reset_at call: stale once the envs step)
+        np.copyto(io["actions"], np.asarray(actions, dtype=np.float64).reshape(io["actions"].shape))
+        use_active = self._any_done  # (nothing to mask until an env has finished)
+        if use_active:
+            np.logical_not(self._dones, out=io["active"].view(np.bool_))
+        f32 = self.obs_dtype == np.float32
+        self.sim.step_host_io(use_active, 2 if f32 else 1)
+        obs, reward, done = io["obs_f32" if f32 else "obs"], io["reward"], io["done"].view(np.bool_)
+        if use_active:  # an env that finished earlier and was not reset did not step: it keeps saying done, with no reward
+            reward = np.where(self._dones, 0.0, reward)
+            new_done = done & ~self._dones
+            done = done.copy() if copy else done
+        else:
+            new_done = done
+            if copy:
+                reward, done = reward.copy(), done.copy()
+        if copy:
+            obs = obs.copy()
+        if new_done.any():
+            self._note_dones(new_done)
+        infos = None
+        if want_infos:
+            if self.info_calculator is not None:
+                infos = self.info_calculator.calculate_dicts(self.sim, actions)
+            bad = np.nonzero(new_done & (self.status != 0))[0] if new_done.any() else ()
+            if len(bad):
+                infos = infos if infos is not None else [{} for _ in range(self.num_envs)]
+                for i in bad:
+                    infos[i] = dict(infos[i], error=self.error_text(int(self.status[i])), status=int(self.status[i]))
         return obs, reward, done, infos
+
+    # ---- tensor path: torch tensors on the env's device, torch's current stream, no PCIe, no host sync per step ----------
+    def _tensors(self):
+        if self._t is None:
+            import torch
+
+            dev = torch.device("cuda", self.sim.cfg.device_id)
+            D, N = self.sim.obs_dim, self.num_envs
+            f32 = self.obs_dtype == np.float32
+            self._t = dict(torch=torch, dev=dev, obs=torch.zeros((N, D), dtype=torch.float32 if f32 else torch.float64, device=dev),
+                           reward=torch.zeros(N, dtype=torch.float64, device=dev), done=torch.zeros(N, dtype=torch.uint8, device=dev), bound=None, side=None)  # fmt: skip
+        return self._t
+
+    def _bind_stream(self, t):
+        """Launch on torch's current stream.  The null stream cannot be handed to the library (0 means "your own stream"): work on
+        it is ordered against a side stream with two stream waits."""
+        torch = t["torch"]
+        cur = torch.cuda.current_stream(t["dev"])
+        target = cur
+        if cur.cuda_stream == 0:
+            if t["side"] is None:
+                t["side"] = torch.cuda.Stream(device=t["dev"])
+            target = t["side"]
+            target.wait_stream(cur)
+        if t["bound"] != target.cuda_stream:
+            self.sim.set_stream(target.cuda_stream)  # (synchronises the previous stream: a one-off)
+            t["bound"] = target.cuda_stream
+        return cur, target
+
+    def vector_reset_tensors(self):
+        """env.reset() of every env -> obs tensor [N, D] (obs_dtype) on the device."""
+        t = self._tensors()
+        cur, target = self._bind_stream(t)
+        sids, starts = self._draw(self.num_envs)
+        f32 = self.obs_dtype == np.float32
+        self.sim.reset_device(starts, sids, None, 0 if f32 else t["obs"].data_ptr(), t["obs"].data_ptr() if f32 else 0, t["done"].data_ptr())
+        self._dones[:] = False
+        self._any_done = False
+        self._reset_cache = {}
+        return t["obs"]
+
+    def vector_step_tensors(self, actions):
+        """actions: float64 CUDA tensor [N, A] on the env's device -> (obs [N, D], reward f64 [N], done uint8 [N]): the env's
+        own tensors, overwritten by the next step.  Asynchronous.  An env that reports done is left alone by later steps (its
+        rows keep their last values, done stays 1) until reset_done_tensors() / vector_reset_tensors()."""
+        t = self._tensors()
+        torch = t["torch"]
+        assert actions.is_cuda and actions.dtype == torch.float64 and actions.is_contiguous() and tuple(actions.shape) == (self.num_envs, self.sim.action_dim)
+        cur, target = self._bind_stream(t)
+        f32 = self.obs_dtype == np.float32
+        p = t["obs"].data_ptr()
+        self.sim.step_device_skip(actions.data_ptr(), t["done"].data_ptr(), 0 if f32 else p, p if f32 else 0, t["reward"].data_ptr(), t["done"].data_ptr())
+        if target is not cur:
+            cur.wait_stream(target)
+        return t["obs"], t["reward"], t["done"]
+
+    def reset_done_tensors(self):
+        """Reset every env whose done flag is set (one launch; synchronises: the flags are read on the host).  Returns the indices
+        reset; ``status`` then holds the error bits those envs had stopped with (0 = a normal episode end)."""
+        t = self._tensors()
+        cur, target = self._bind_stream(t)
+        self.sim.sync()
+        ids = np.nonzero(t["done"].cpu().numpy())[0].astype(np.int32)
+        if len(ids) == 0:
+            return ids
+        self.status = self.sim.status()
+        sids, starts = self._draw(len(ids))
+        f32 = self.obs_dtype == np.float32
+        self.sim.reset_device(starts, sids, ids, 0 if f32 else t["obs"].data_ptr(), t["obs"].data_ptr() if f32 else 0, t["done"].data_ptr())
+        return ids
 
     # ---- VectorEnv API ------------------------------------------------------------------------------------------
     def vector_reset(self) -> List[np.ndarray]:
         return list(self.vector_reset_arrays())
 
     def reset_at(self, index: Optional[int] = None) -> np.ndarray:
-        index = 0 if index is None else index
+        index = 0 if index is None else int(index)
+        row = self._reset_cache.pop(index, None)
+        if row is not None:
+            return row
+        if self._dones[index]:
+            # the first reset_at after a step that reported dones: every finished env in ONE launch, their start times drawn in
+            # index order (= the order of RLlib's reset_at calls); the others' observations wait in the cache
+            ids = np.nonzero(self._dones)[0].astype(np.int32)
+            obs = self.reset_many(ids)
+            self._reset_cache = {int(i): obs[k] for k, i in enumerate(ids)}
+            return self._reset_cache.pop(index)
         return self.reset_many([index])[0]
 
     def reset_many(self, indices: Sequence[int]) -> np.ndarray:
@@ -691,7 +860,8 @@ class HistoricalOrderbookVectorEnv(_RayVectorEnv):
         obs = self.sim.reset(starts, sids, ids)
         self._dones[ids] = False
         self._any_done = bool(self._dones.any())
-        return obs
+        self.status[ids] = 0
+        return obs.astype(self.obs_dtype, copy=False)
 
     def vector_step(self, actions):
         obs, reward, done, infos = self.vector_step_arrays(actions)
@@ -733,9 +903,8 @@ class HistoricalOrderbookEnvironment(_GymEnv):
 
     def step(self, action: np.ndarray):
         obs, reward, done, info = self._venv.vector_step(np.asarray(action, dtype=np.float64)[None, :])
-        st = self._venv.sim.env_state(0) if done[0] else None
-        if st is not None and st["status"]:
-            self._raise(st["status"])
+        if done[0] and self._venv.status[0]:
+            self._raise(int(self._venv.status[0]))
         return obs[0], float(reward[0]), bool(done[0]), info[0]
 
     @staticmethod
@@ -744,19 +913,7 @@ class HistoricalOrderbookEnvironment(_GymEnv):
             raise EmptyOrderbookError("Trying take liquidity from empty side of the book.")
         if status & _capi.ST_ASSERT:
             raise AssertionError("Order volume must be positive.")
-        hints = []
-        if status & _capi.ST_LEVEL_OVERFLOW:
-            hints.append("more price levels than cfg.max_levels provides slabs for (the reference never drops a level that left LOBSTER's "
-                         "visible range: one stale level per tick of price drift): pass a larger max_levels (up to 2048), or shorten the episode")
-        if status & _capi.ST_QUEUE_OVERFLOW:
-            hints.append("more than 512 live orders at one price")
-        if status & _capi.ST_AGENT_OVERFLOW:
-            hints.append("more than 128 live agent orders (entries freed in a step are reusable from the next one): fewer quote levels")
-        if status & _capi.ST_STREAM_END:
-            hints.append("stepped past the end of the loaded stream")
-        if status & _capi.ST_NOT_RESET:
-            hints.append("step() before reset()")
-        raise RuntimeError(f"env stopped with status {status} (include/lobsim.h: enum lobsim_status)" + ("; " + "; ".join(hints) if hints else ""))
+        raise RuntimeError(f"env stopped with status {status} (include/lobsim.h: enum lobsim_status): " + HistoricalOrderbookVectorEnv.error_text(status))
 
     def seed(self, seed=42):
         self.np_random = np.random.RandomState(seed)

@@ -1,0 +1,385 @@
+"""Host-side mirror of the reference's simulator surface, backed by the HIP library's simulator-level entry points.
+
+* order records            ``Order / LimitOrder / MarketOrder / Cancellation / Deletion / FilledOrders / Orderbook``
+                           (reference rl4mm/orderbook/models.py:17-107: same names, fields and properties)
+* ``OrderbookSimulator``   ``reset_episode(start_date) -> Orderbook``, ``forward_step(until, internal_orders) -> FilledOrders``,
+                           ``now_is``, ``min_buy_price / max_sell_price / initial_*_price_range``, ``exchange.central_orderbook`` /
+                           ``exchange.internal_orderbook`` (rl4mm/simulation/OrderbookSimulator.py:23-135)
+
+The book lives on the GPU (one env of a ``lobsim_t`` handle): ``reset_episode`` is ``lobsim_reset_episode``, ``forward_step`` is one
+``lobsim_forward`` launch - the internal orders, then the window's messages, then the outer-level resync - and the
+``FilledOrders`` it returns are read back from the kernel's fill log (``lobsim_get_fills``).  The ``Orderbook`` objects are
+snapshots decoded from device state when asked for.  There is no CPU path: without the HIP library and a GPU the constructor raises.
+
+What differs from the reference, by construction:
+* the data source is a ``StreamCatalog`` / ``PackedStream`` (rl4mm_amd/stream.py) where the reference takes a ``HistoricalDatabase``;
+  ``order_generators`` is accepted and ignored (the packed stream IS the historical order generator's output);
+* the agent's orders are identified by ``internal_id`` as in the reference (``forward_step`` assigns one to every LimitOrder it
+  books and the agent cancels by it); the library addresses an agent order by its FIFO rank at its price, this class keeps the
+  map.  A cancellation in the same ``forward_step`` call as an own order that could sweep the agent's other orders (a
+  self-crossing order) is refused: the rank of the target is then not knowable on the host - submit them in separate calls;
+* ``FilledOrders.internal`` entries are ``LimitOrder`` records (direction, price, volume) for resting fills and aggressing fills
+  alike - the reference makes the latter ``MarketOrder`` copies with a price; every consumer reads direction / price / volume.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from datetime import datetime, timedelta
+from typing import Dict, List, Optional, Tuple, Union
+
+import numpy as np
+
+from . import _capi, _lib
+from .stream import PackedStream
+
+try:  # (the reference's container; plain dicts kept sorted otherwise)
+    from sortedcontainers import SortedDict
+except Exception:  # noqa: BLE001  # pragma: no cover
+    SortedDict = None
+
+US = timedelta(microseconds=1)
+SIDE = {"buy": 0, "sell": 1}
+SIDE_NAME = ("buy", "sell")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# order records, rl4mm/orderbook/models.py:17-61
+# ---------------------------------------------------------------------------------------------------------------------
+@dataclass
+class Order:
+    timestamp: datetime
+    direction: str  # "buy" | "sell"
+    ticker: str
+    internal_id: Optional[int]
+    external_id: Optional[int]
+    is_external: bool
+
+    def __lt__(self, other):
+        return self.timestamp < other.timestamp
+
+
+@dataclass
+class MarketOrder(Order):
+    volume: int
+    price: Optional[int] = None
+
+
+@dataclass
+class LimitOrder(Order):
+    price: int
+    volume: int
+
+
+@dataclass
+class Deletion(Order):
+    price: int
+    volume: Optional[int]
+
+
+@dataclass
+class Cancellation(Deletion):
+    volume: int
+
+
+@dataclass
+class FilledOrders:  # models.py:104-107
+    internal: List[Order] = field(default_factory=list)
+    external: List[Order] = field(default_factory=list)
+
+
+def _sorted(d: dict):
+    return SortedDict(d) if SortedDict is not None else dict(sorted(d.items()))
+
+
+@dataclass
+class Orderbook:  # models.py:64-101
+    buy: dict  # price -> list[LimitOrder], ascending prices like the reference's SortedDict
+    sell: dict
+    ticker: str
+    tick_size: int = 100
+
+    @property
+    def best_buy_price(self):
+        return next(reversed(self.buy), 0)
+
+    @property
+    def best_sell_price(self):
+        return next(iter(self.sell.keys()), np.inf)
+
+    @property
+    def best_buy_volume(self):
+        return sum(order.volume for order in self.buy[self.best_buy_price])
+
+    @property
+    def best_sell_volume(self):
+        return sum(order.volume for order in self.sell[self.best_sell_price])
+
+    @property
+    def midprice(self):
+        return (self.best_sell_price + self.best_buy_price) / 2
+
+    @property
+    def imbalance(self):
+        return (self.best_buy_volume - self.best_sell_volume) / (self.best_buy_volume + self.best_sell_volume)
+
+    @property
+    def microprice(self):
+        return (1 + self.imbalance) / 2 * self.best_sell_price + (1 - self.imbalance) / 2 * self.best_buy_price
+
+    @property
+    def spread(self):
+        return self.best_sell_price - self.best_buy_price
+
+
+def convert_to_lobster_format(orderbook: Orderbook, n_levels: int = 10) -> dict:
+    """rl4mm/extras/orderbook_comparison.py:6-19."""
+    out = {}
+    for direction in ("buy", "sell"):
+        half = getattr(orderbook, direction)
+        prices = reversed(half) if direction == "buy" else iter(half)
+        for level, price in enumerate(prices):
+            if level < n_levels:
+                out[f"{direction}_price_{level}"] = float(price)
+                out[f"{direction}_volume_{level}"] = float(sum(o.volume for o in half[price]))
+    return out
+
+
+class _Exchange:
+    """The attributes of ``Exchange`` (rl4mm/orderbook/Exchange.py:40-57,149-169) that callers of the simulator read; every access
+    decodes the current device state."""
+
+    def __init__(self, owner: "OrderbookSimulator"):
+        self._o = owner
+        self.ticker = owner.ticker
+        self.tick_size = 100
+
+    @property
+    def central_orderbook(self) -> Orderbook:
+        return self._o._read_book(internal=False)
+
+    @property
+    def internal_orderbook(self) -> Orderbook:
+        return self._o._read_book(internal=True)
+
+    @property
+    def best_buy_price(self):
+        return self._o._state()["best_buy"]
+
+    @property
+    def best_sell_price(self):
+        b = self._o._state()["best_sell"]
+        return np.inf if b == np.iinfo(np.int64).max else b
+
+    @property
+    def orderbook_price_range(self) -> Tuple[int, int]:
+        book = self.central_orderbook
+        return (next(p for p in book.buy if p > 0), next(p for p in reversed(book.sell) if p < 9999999999))
+
+
+class EmptyOrderbookError(Exception):  # rl4mm/orderbook/Exchange.py:32-33
+    pass
+
+
+class OrderbookSimulator:
+    def __init__(
+        self,
+        ticker: str = "MSFT",
+        exchange=None,
+        order_generators=None,
+        n_levels: int = 50,
+        database=None,
+        preload_orders: bool = True,
+        episode_length: timedelta = timedelta(minutes=30),
+        warm_up: timedelta = timedelta(seconds=0),
+        outer_levels: int = 20,
+        device_id: int = 0,
+        ladder_levels: int = 0,
+        max_levels: int = 0,
+        _new_sim=None,  # (tests of this class's host logic bind another library with the same C-ABI)
+    ) -> None:
+        if database is None:
+            raise ValueError("pass database=StreamCatalog(...) or a PackedStream: packed streams replace the reference's HistoricalDatabase")
+        self.ticker = ticker
+        self.n_levels = n_levels
+        self.database = database
+        self.preload_orders = preload_orders
+        self.episode_length, self.warm_up, self.outer_levels = episode_length, warm_up, outer_levels
+        self.now_is: datetime = datetime(2000, 1, 1)  # OrderbookSimulator.py:41
+        cfg = _capi.make_cfg(1, n_levels, [_capi.make_feature(_capi.F_INVENTORY, min_value=-1e6, max_value=1e6)], outer_levels=outer_levels,
+                             device_id=device_id, ladder_levels=ladder_levels, max_levels=max_levels)  # fmt: skip
+        self.sim = (_new_sim or _lib.new_sim)(cfg)  # raises without the HIP library / a GPU
+        self.exchange = _Exchange(self)
+        self._stream_ids: Dict[str, int] = {}
+        self._day0: Optional[datetime] = None
+        self._next_internal_id = 0
+        self._agent: Dict[Tuple[int, int], List[List[int]]] = {}  # (side, price) -> [[internal_id, volume], ...] in queue order
+
+    # ---- data ---------------------------------------------------------------------------------------------------
+    def _stream_for(self, day: datetime) -> int:
+        key = day.strftime("%Y-%m-%d")
+        if key not in self._stream_ids:
+            db = self.database
+            stream = db if isinstance(db, PackedStream) else db.get(self.ticker, key)
+            if stream.trading_date != key or stream.ticker != self.ticker:
+                raise KeyError(f"no packed stream for {self.ticker} on {key}")
+            self._stream_ids[key] = self.sim.add_stream(stream)
+        return self._stream_ids[key]
+
+    def _us(self, t: datetime) -> int:
+        return int((t - self._day0) / US)
+
+    # ---- OrderbookSimulator.py:55-68 ------------------------------------------------------------------------------
+    def reset_episode(self, start_date: datetime, start_book: Optional[Orderbook] = None) -> Orderbook:
+        if start_book is not None:
+            raise NotImplementedError("start_book: the book of an episode is the stream's snapshot (lobsim_debug_set_book takes an explicit one)")
+        assert start_date.microsecond == 0, "Episodes must be started on the second."
+        self._day0 = datetime(start_date.year, start_date.month, start_date.day)
+        sid = self._stream_for(self._day0)
+        self.sim.reset_episode(self._us(start_date), sid)
+        st = self._state()
+        assert not (st["status"] & _capi.ST_STREAM_END), f"There is no data before the episode start time: {start_date}"
+        self._raise_on_status(st["status"])
+        self.now_is = start_date
+        self._agent = {}
+        return self.exchange.central_orderbook
+
+    # ---- OrderbookSimulator.py:70-88 ------------------------------------------------------------------------------
+    def forward_step(self, until: datetime, internal_orders: Optional[List[Order]] = None) -> FilledOrders:
+        assert until > self.now_is, f"The current time is {self.now_is.time()}, but we are trying to step forward in time until {until.time()}!"
+        rows = self._rows_of(internal_orders or [])
+        self.sim.forward(self._us(until), orders=[rows] if len(rows) else None)
+        st = self._state()
+        self._raise_on_status(st["status"])
+        self.now_is = until
+        self._reconcile_agent_orders()
+        filled = FilledOrders()
+        for lst, side, price, vol in self.sim.fills(0):
+            o = LimitOrder(timestamp=until, direction=SIDE_NAME[side], ticker=self.ticker, internal_id=None, external_id=None, is_external=bool(lst),
+                           price=int(price), volume=int(vol))  # fmt: skip
+            (filled.external if lst else filled.internal).append(o)
+        return filled
+
+    # ---- re-synchronisation bookkeeping, OrderbookSimulator.py:47-53 -----------------------------------------------
+    @staticmethod
+    def _inf(v):
+        return np.inf if v == np.iinfo(np.int64).max else v
+
+    @property
+    def min_buy_price(self):
+        return self._inf(self._state()["min_buy_price"])
+
+    @property
+    def max_sell_price(self):
+        return self._state()["max_sell_price"]
+
+    @property
+    def initial_buy_price_range(self):
+        return self._inf(self._state()["initial_buy_range"])
+
+    @property
+    def initial_sell_price_range(self):
+        return self._inf(self._state()["initial_sell_range"])
+
+    def close(self):
+        self.sim.close()
+
+    # ---- internals ----------------------------------------------------------------------------------------------
+    def _state(self) -> dict:
+        return self.sim.env_state(0)
+
+    @staticmethod
+    def _raise_on_status(status: int):
+        if status & _capi.ST_EMPTY_BOOK:
+            raise EmptyOrderbookError("Trying take liquidity from empty side of the book.")
+        if status & _capi.ST_ASSERT:
+            raise AssertionError("Order volume must be positive.")
+        if status:
+            raise RuntimeError(f"simulator stopped with status {status} (include/lobsim.h: enum lobsim_status)")
+
+    def _rows_of(self, orders: List[Order]) -> np.ndarray:
+        """Internal orders -> rows of lobsim_forward; assigns internal ids to new limit orders and turns the internal id a
+        cancellation names into the FIFO rank of its target among the agent's orders at that price."""
+        rows = []
+        may_have_swept_own = False
+        for o in orders:
+            assert not o.is_external, "internal_orders are the agent's own orders (historical messages come from the packed stream)"
+            side = SIDE[o.direction]
+            if isinstance(o, LimitOrder):
+                opp_live = any(s == 1 - side and (p <= o.price if side == 0 else p >= o.price) for (s, p), q in self._agent.items() if q)
+                may_have_swept_own = may_have_swept_own or opp_live
+                self._next_internal_id += 1
+                o.internal_id = self._next_internal_id
+                self._agent.setdefault((side, int(o.price)), []).append([o.internal_id, int(o.volume)])
+                rows.append((_capi_type("limit"), side, int(o.price), int(o.volume), 0, 0))
+            elif isinstance(o, MarketOrder):
+                may_have_swept_own = may_have_swept_own or any(s == 1 - side and q for (s, _), q in self._agent.items())
+                rows.append((_capi_type("market"), side, 0, int(o.volume), 0, 0))
+            elif isinstance(o, Deletion):  # Cancellation is a Deletion
+                if may_have_swept_own:
+                    raise NotImplementedError("a cancellation after a self-crossing own order in one forward_step call: submit them in separate calls")
+                q = self._agent.get((side, int(o.price)), [])
+                rank = next((i for i, e in enumerate(q) if e[0] == o.internal_id), None)
+                typ = _capi_type("cancellation" if isinstance(o, Cancellation) else "deletion")
+                if rank is None:  # not one of the agent's live orders: the reference warns and moves on (Exchange.py:128-139)
+                    rows.append((typ, side, int(o.price), -1 if o.volume is None else int(o.volume), 1 << 30, 0))
+                    continue
+                vol = q[rank][1] if o.volume is None else min(int(o.volume), q[rank][1])
+                q[rank][1] -= vol
+                if q[rank][1] == 0:
+                    q.pop(rank)
+                rows.append((typ, side, int(o.price), -1 if o.volume is None else int(o.volume), rank, 0))
+            else:
+                raise TypeError(f"unsupported internal order {type(o).__name__}")
+        return np.array(rows, dtype=np.int64).reshape(-1, 6)
+
+    def _reconcile_agent_orders(self):
+        """After a step: fills (and sweeps of own orders) consume the agent's orders at a price from the front, the resync
+        re-queues them in order - so what is left at a price are the LAST entries of the host's list, with the device's volumes."""
+        q = self.sim.queues(0)
+        live: Dict[Tuple[int, int], List[int]] = {}
+        for side, price, kind, _rank, vol in q:
+            if kind == 1:
+                live.setdefault((int(side), int(price)), []).append(int(vol))
+        new = {}
+        for key, vols in live.items():
+            mine = self._agent.get(key, [])
+            assert len(mine) >= len(vols), "agent order bookkeeping out of step with the device"
+            keep = mine[len(mine) - len(vols) :]
+            new[key] = [[iid, v] for (iid, _), v in zip(keep, vols)]
+        self._agent = new
+
+    def _read_book(self, internal: bool) -> Orderbook:
+        q = self.sim.queues(0)
+        day0 = self._day0 or datetime(2000, 1, 1)
+        sides = ({}, {})
+        for side, price, kind, oid, vol in q:
+            side, price, kind = int(side), int(price), int(kind)
+            if internal and kind != 1:
+                continue
+            if kind == 1:
+                iid = self._agent.get((side, price), [])
+                iid = iid[int(oid)][0] if int(oid) < len(iid) else None
+                o = LimitOrder(timestamp=self.now_is, direction=SIDE_NAME[side], ticker=self.ticker, internal_id=iid, external_id=None, is_external=False, price=price, volume=int(vol))
+            else:  # tracked external order (kind 0) or snapshot aggregate (kind 2: internal_id == -1, external)
+                o = LimitOrder(timestamp=day0, direction=SIDE_NAME[side], ticker=self.ticker, internal_id=-1 if kind == 2 else None,
+                               external_id=None if kind == 2 else int(oid), is_external=True, price=price, volume=int(vol))  # fmt: skip
+            sides[side].setdefault(price, []).append(o)
+        return Orderbook(buy=_sorted(sides[0]), sell=_sorted(sides[1]), ticker=self.ticker, tick_size=100)
+
+
+def _capi_type(name: str) -> int:
+    return {"limit": 1, "cancellation": 2, "deletion": 3, "market": 4}[name]
+
+
+def create_order(order_type: str, order_dict: dict) -> Order:
+    """rl4mm/orderbook/create_order.py:4-42."""
+    d = dict(order_dict)
+    if order_type == "limit":
+        return LimitOrder(**{k: d[k] for k in ("timestamp", "direction", "ticker", "internal_id", "external_id", "is_external", "price", "volume")})
+    if order_type == "market":
+        return MarketOrder(**{k: d[k] for k in ("timestamp", "direction", "ticker", "internal_id", "external_id", "is_external", "volume")})
+    if order_type == "cancellation":
+        return Cancellation(**{k: d[k] for k in ("timestamp", "direction", "ticker", "internal_id", "external_id", "is_external", "price", "volume")})
+    if order_type == "deletion":
+        return Deletion(**{k: d[k] for k in ("timestamp", "direction", "ticker", "internal_id", "external_id", "is_external", "price", "volume")})
+    raise NotImplementedError(order_type)

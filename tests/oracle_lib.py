@@ -24,18 +24,8 @@ def oracle_binding() -> _capi.Binding:
         P64, PD = C.POINTER(C.c_int64), C.POINTER(C.c_double)
         b.lib.oracle_beta_volumes.restype = None
         b.lib.oracle_beta_volumes.argtypes = [C.POINTER(_capi.Cfg), PD, P64, P64]
-        b.lib.oracle_get_fills.restype = C.c_int
-        b.lib.oracle_get_fills.argtypes = [C.c_void_p, C.c_int32, P64, C.c_int32]
         b.lib.oracle_peek_agent_orders.restype = C.c_int
         b.lib.oracle_peek_agent_orders.argtypes = [C.c_void_p, C.c_int32, PD, P64, C.c_int32]
-        b.lib.oracle_debug_forward.restype = C.c_int
-        b.lib.oracle_debug_forward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64]
-        b.lib.oracle_debug_reset_episode.restype = C.c_int
-        b.lib.oracle_debug_reset_episode.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64]
-        b.lib.oracle_debug_features_reset.restype = C.c_int
-        b.lib.oracle_debug_features_reset.argtypes = [C.c_void_p, C.c_int32]
-        b.lib.oracle_debug_feature_step.restype = C.c_int
-        b.lib.oracle_debug_feature_step.argtypes = [C.c_void_p, C.c_int32, PD]
         PI32, PU8 = C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
         b.lib.oracle_rollout.restype = C.c_int
         b.lib.oracle_rollout.argtypes = [C.c_void_p, C.c_int32, PD, C.c_int32, PD, PU8, PD, PD, PU8, PD, PI32, PD]
@@ -65,9 +55,7 @@ def oracle_sim(cfg) -> _capi.Sim:
 
 
 def oracle_fills(sim, env=0, cap=4096) -> np.ndarray:
-    out = np.zeros((cap, 4), dtype=np.int64)
-    n = sim.b.lib.oracle_get_fills(sim.h, env, out.ctypes.data_as(C.POINTER(C.c_int64)), cap)
-    return out[:n]
+    return sim.fills(env, cap)
 
 
 def oracle_peek_orders(sim, action, env=0, cap=1024) -> np.ndarray:

@@ -265,7 +265,7 @@ def test_batch_step_sizes_against_oracle(step_us, ladder_levels):
     stream = ol.golden_stream("synth_small")  # 09:54:50 .. 10:01:50
     gpu, cpu = _lib.new_sim(cfg), ol.oracle_sim(cfg)
     rng = np.random.Generator(np.random.PCG64(1000 + step_us // 1000))
-    starts = (35_730 + rng.integers(0, 120, size=n)) * 1_000_000
+    starts = (35_735 + rng.integers(0, 115, size=n)) * 1_000_000  # (the longest warm-up is 40 s: the first snapshot is at 09:54:50)
     for sim in (gpu, cpu):
         sim.add_stream(stream)
         sim.set_portfolio(0, 10**9)

@@ -1,0 +1,149 @@
+"""Simulator-level surface on the HIP path (`OrderbookSimulator` with reset_episode / forward_step -> FilledOrders):
+the reference-held vectors G2 (LOBSTER agreement replay), G8 (outer-level resync with internal orders) and G6 (feature known
+answers) straight through lobsim_reset_episode / lobsim_forward / lobsim_get_fills / lobsim_features_reset, the reference's
+own simulator tests through the rl4mm_amd.simulator.OrderbookSimulator class, and random forward steps with internal orders
+against the oracle, fill by fill.  Needs a real MI355X: `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import sim_facade_checks as fc
+from rl4mm_amd import _capi, _lib
+from traj_util import check_feature_known_answers, check_replay_msft, check_resync_msft, feature_known_answer_cfg, simulator_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("ladder_levels", [64, 128])
+def test_replay_msft_on_the_hip_path(ladder_levels):
+    cfg = simulator_cfg()
+    cfg.ladder_levels = ladder_levels
+    sim = _lib.new_sim(cfg)
+    check_replay_msft(sim)
+    sim.close()
+
+
+@pytest.mark.parametrize("ladder_levels", [64, 128])
+def test_resync_msft_with_internal_orders_on_the_hip_path(ladder_levels):
+    cfg = simulator_cfg()
+    cfg.ladder_levels = ladder_levels
+    sim = _lib.new_sim(cfg)
+    check_resync_msft(sim)
+    sim.close()
+
+
+def test_feature_known_answers_on_the_hip_path():
+    sim = _lib.new_sim(feature_known_answer_cfg())
+    check_feature_known_answers(sim)
+    sim.close()
+
+
+def test_reference_simulator_tests_through_the_facade_class():
+    fc.check_agreement_with_lobster(_lib.new_sim)
+    fc.check_update_outer_levels_with_internal_orders(_lib.new_sim)
+    fc.check_internal_orders_by_id(_lib.new_sim)
+
+
+def _random_internal_orders(rng, cpu, env, max_n):
+    """Agent orders against the oracle's current book: limits near the touch (some marketable), market orders, cancellations /
+    deletions by FIFO rank of the agent's live orders."""
+    st = cpu.env_state(env)
+    bb, bs = st["best_buy"], st["best_sell"]
+    rows = []
+    q = cpu.queues(env)
+    mine = q[q[:, 2] == 1]
+    for _ in range(int(rng.integers(0, max_n + 1))):
+        r = rng.random()
+        side = int(rng.integers(0, 2))
+        if r < 0.55:
+            off = int(rng.integers(-2, 6)) * 100  # negative: marketable
+            price = bb - off if side == 0 else bs + off
+            rows.append((1, side, price, int(rng.integers(1, 40)) * 10, 0, 0))
+        elif r < 0.7:
+            rows.append((4, side, 0, int(rng.integers(1, 30)) * 10, 0, 0))
+        elif len(mine):
+            m = mine[int(rng.integers(0, len(mine)))]
+            typ = 2 if rng.random() < 0.6 else 3
+            vol = int(rng.integers(1, int(m[4]) + 20)) if typ == 2 or rng.random() < 0.5 else -1
+            rows.append((typ, int(m[0]), int(m[1]), vol, int(m[3]), 0))
+    return np.array(rows, dtype=np.int64).reshape(-1, 6)
+
+
+@pytest.mark.parametrize("ladder_levels", [64, 128])
+def test_forward_steps_with_internal_orders_against_oracle(ladder_levels):
+    """64 envs on the synthetic stream: forward steps of random length (50 ms .. 2.5 s, so that some end on whole seconds and run
+    the outer-level check) with up to 6 random internal orders each, 60 rounds.  After every round, for every env: the fill lists
+    (FilledOrders.internal / .external, row by row), portfolio, book top and resync bookkeeping against the oracle; per-order
+    queues every 10 rounds."""
+    n, rounds = 64, 60
+    feats = [_capi.make_feature(_capi.F_INVENTORY, min_value=-1e6, max_value=1e6)]
+    cfg = _capi.make_cfg(n, 10, feats, step_us=100_000, outer_levels=20, ladder_levels=ladder_levels)
+    stream = ol.golden_stream("synth_small")
+    gpu, cpu = _lib.new_sim(cfg), ol.oracle_sim(cfg)
+    rng = np.random.Generator(np.random.PCG64(77 + ladder_levels))
+    starts = (35_700 + rng.integers(0, 200, size=n)) * 1_000_000
+    for sim in (gpu, cpu):
+        sim.add_stream(stream)
+        sim.set_portfolio(0, 10**9)
+        sim.reset_episode(starts, 0)
+    now = starts.copy()
+    n_fills = n_internal = 0
+    for r in range(rounds):
+        dt = np.where(rng.random(n) < 0.3, (10**6 - now % 10**6), rng.integers(1, 50, size=n) * 50_000)  # a third end on the next whole second
+        dt = np.where(dt == 0, 10**6, dt)
+        now = now + dt
+        orders = [_random_internal_orders(rng, cpu, e, 6) for e in range(n)]
+        gpu.forward(now, orders=orders)
+        cpu.forward(now, orders=orders)
+        sg, sc = gpu.status(), cpu.status()
+        assert np.array_equal(sg, sc), f"round {r}: status differs in envs {np.nonzero(sg != sc)[0][:8]}"
+        ig, cg, _ = gpu.portfolios()
+        ic, cc, _ = cpu.portfolios()
+        ok = sc == 0  # (an env that stopped on an error - the reference raises mid-step there - has no defined portfolio)
+        assert np.array_equal(ig[ok], ic[ok]) and np.array_equal(cg[ok], cc[ok]), f"round {r}: portfolio differs in envs {np.nonzero(ok & ((ig != ic) | (cg != cc)))[0][:8]}"
+        for e in range(n):
+            if sc[e]:
+                continue
+            fg, fcp = gpu.fills(e), cpu.fills(e)
+            assert np.array_equal(fg, fcp), f"round {r} env {e}: fill lists differ\n{fg}\n{fcp}"
+            n_fills += len(fg)
+            n_internal += int((fg[:, 0] == 0).sum())
+            a, b = gpu.env_state(e), cpu.env_state(e)
+            for k in ("now_us", "best_buy", "best_sell", "n_buy_levels", "n_sell_levels", "n_agent_orders", "n_resyncs", "min_buy_price", "max_sell_price"):
+                assert a[k] == b[k], (r, e, k, a[k], b[k])
+        if r % 10 == 9:
+            for e in range(0, n, 7):
+                assert np.array_equal(gpu.queues(e), cpu.queues(e)), f"round {r} env {e}: per-order book differs"
+        # envs the agent emptied a side of (EmptyOrderbookError) start over
+        dead = np.nonzero(sc != 0)[0].astype(np.int32)
+        if len(dead):
+            now[dead] = (now[dead] // 10**6 + 1) * 10**6
+            for sim in (gpu, cpu):
+                sim.reset_episode(now[dead], 0, dead)
+    assert n_fills > 2000 and n_internal > 200
+    assert max(cpu.env_state(e)["n_resyncs"] for e in range(n)) > 0
+    gpu.close()
+
+
+def test_forward_argument_errors_and_fill_log_overflow():
+    cfg = simulator_cfg()
+    sim = _lib.new_sim(cfg)
+    sid = sim.add_stream(ol.golden_stream("msft"))
+    with pytest.raises(_capi.LobsimError):
+        sim.reset_episode(36_000_000_001, sid)  # not on the second (OrderbookSimulator.py:61)
+    sim.reset_episode(36_000_000_000, sid)
+    sim.forward(36_000_000_000)  # until == now: the reference's assert
+    assert sim.env_state(0)["status"] & _capi.ST_ASSERT
+    sim.reset_episode(36_000_000_000, sid)
+    lim = sim.limits()
+    assert lim["fill_log_rows"] >= 256 and lim["level_slabs"] >= 256 and lim["queue_slots"] == 512 and lim["agent_orders"] == 128
+    # one agent market order per resting order: more fills than the log holds is reported, not silently truncated
+    book = sim.queues(0)
+    asks = book[book[:, 0] == 1]
+    vol = int(asks[:, 4].sum()) - 1
+    rows = np.array([[1, 0, int(asks[-1, 1]), 1, 0, 0]] * 0 + [[4, 0, 0, 1, 0, 0]] * (lim["fill_log_rows"] + 5), dtype=np.int64)
+    if vol > len(rows):
+        sim.forward(36_000_100_000, orders=[rows])
+        with pytest.raises(_capi.LobsimError):
+            sim.fills(0, cap=4 * lim["fill_log_rows"])
+    sim.close()

@@ -400,3 +400,58 @@ def test_7z_archives_go_through_the_7z_executable(tmp_path, monkeypatch):
     monkeypatch.setenv("PATH", str(tmp_path / "nowhere"))
     with pytest.raises(RuntimeError, match="no 7z executable"):
         ingest._extract(arc, data)
+
+
+def test_orderbook_simulator_class_host_logic_on_the_reference_simulator_tests():
+    """rl4mm_amd.simulator.OrderbookSimulator's own logic (datetime <-> stream time, internal ids <-> FIFO ranks, Orderbook /
+    FilledOrders decoding) through the reference's simulator tests (testOrderbookSimulator.py:46-108), with the class bound to
+    the CPU restatement (same C-ABI).  The HIP library runs the same checks in tests/test_gpu_simulator.py."""
+    import sim_facade_checks as fc
+
+    fc.check_agreement_with_lobster(ol.oracle_sim)
+    fc.check_update_outer_levels_with_internal_orders(ol.oracle_sim)
+    fc.check_internal_orders_by_id(ol.oracle_sim)
+
+
+def test_reset_at_resets_all_finished_envs_in_one_launch_and_keeps_the_rng_sequence():
+    """RLlib calls reset_at(i) once per finished env, in index order, and all envs of a batch finish together: the first call
+    resets every finished env in ONE reset launch (one launch replays the warm-up of 4096 envs as fast as of one), the others
+    return cached rows.  Start draws and the state np.random is left in must equal one-env-at-a-time resets."""
+
+    class StubSim:
+        def __init__(self):
+            self.launches = []
+
+        def reset(self, starts, sids, ids):
+            self.launches.append(np.array(ids))
+            return np.stack([np.asarray(starts, dtype=np.float64), np.asarray(ids, dtype=np.float64)], axis=1)
+
+        def status(self):
+            return np.zeros(16, dtype=np.int32)
+
+    def fresh():
+        env = _bare_vector_env(datetime(2018, 2, 1), datetime(2018, 3, 15), 30, 0.1)
+        env.num_envs, env.sim, env.obs_dtype = 16, StubSim(), np.dtype(np.float64)
+        env._dones, env._any_done, env._reset_cache, env.status = np.zeros(16, dtype=bool), False, {}, np.zeros(16, dtype=np.int32)
+        return env
+
+    finished = [1, 2, 5, 6, 7, 11, 15]
+    np.random.seed(5)
+    one_by_one = fresh()
+    rows_a = [one_by_one.reset_many([i])[0] for i in finished]  # round 3's reset_at: a launch per env
+    after_a = np.random.randint(0, 1 << 30)
+    assert len(one_by_one.sim.launches) == len(finished)
+
+    np.random.seed(5)
+    batched = fresh()
+    batched._dones[finished] = True
+    batched._any_done = True
+    rows_b = [batched.reset_at(i) for i in finished]
+    after_b = np.random.randint(0, 1 << 30)
+    assert len(batched.sim.launches) == 1 and list(batched.sim.launches[0]) == finished
+    assert np.array_equal(np.array(rows_a), np.array(rows_b)) and after_a == after_b
+    assert not batched._dones.any() and not batched._any_done and batched._reset_cache == {}
+    # an env that is not finished (or a second reset_at of one that was) is a reset of its own
+    batched.reset_at(3)
+    batched.reset_at(5)
+    assert [list(x) for x in batched.sim.launches[1:]] == [[3], [5]]

@@ -7,7 +7,7 @@ import pytest
 
 import oracle_lib as ol
 from rl4mm_amd import _capi
-from traj_util import replay_and_check, run_engine_case
+from traj_util import check_feature_known_answers, check_replay_msft, check_resync_msft, feature_known_answer_cfg, replay_and_check, run_engine_case, simulator_cfg
 
 TRAJ = ["msft_fixed", "msft_teradactyl_ad", "msft_random_allfeat", "synth_default_random", "synth_teradactyl_ad_spread", "synth_amihud", "synth_info_moc", "synth_info_spread",
         "synth_moc_conc", "synth_moc_crash", "synth_q5_fixed", "synth_norm", "synth_track_internal",
@@ -48,46 +48,12 @@ def test_engine_case(name):
 
 def test_replay_msft_agrees_with_reference_and_lobster():
     """G2 = rl4mm/simulation/tests/testOrderbookSimulator.py:46-75 with per-100ms checkpoints."""
-    z = np.load(ol.GOLD / "replay_msft.npz")
-    ps = ol.golden_stream("msft")
-    cfg = _capi.make_cfg(1, 50, [_capi.make_feature(_capi.F_INVENTORY, max_value=1e6, min_value=-1e6)], outer_levels=48)
-    sim = ol.oracle_sim(cfg)
-    sid = sim.add_stream(ps)
-    b = sim.b
-    assert b.lib.oracle_debug_reset_episode(sim.h, 0, sid, int(z["times"][0])) == 0
-    assert np.array_equal(sim.top(0, 55), z["tops"][0])
-    # known answer: the start book IS the LOBSTER snapshot row
-    row = ps.snaps[ps.last_snapshot_at(int(z["times"][0])), 2:]
-    top = sim.top(0, 50)
-    assert np.array_equal(top[1, :, 0], row[0::4]) and np.array_equal(top[1, :, 1], row[1::4])
-    assert np.array_equal(top[0, :, 0], row[2::4]) and np.array_equal(top[0, :, 1], row[3::4])
-    for k in range(1, len(z["times"])):
-        assert b.lib.oracle_debug_forward(sim.h, 0, sid, int(z["times"][k])) == 0
-        assert np.array_equal(sim.top(0, 55), z["tops"][k]), f"checkpoint {k}"
-        f = ol.oracle_fills(sim)
-        assert np.array_equal(f, z["fills"][z["fill_off"][k - 1] : z["fill_off"][k]]), f"fills at checkpoint {k}"
-    assert np.array_equal(sim.queues(0), z["queues"])
-    st = sim.env_state(0)
-    assert st["min_buy_price"] == int(z["min_buy"]) and st["max_sell_price"] == int(z["max_sell"])
-    # LOBSTER agreement after 1 s and 2 s on the levels both sides know about (as the reference's test does)
-    for sec in (36001, 36002):
-        pass
+    check_replay_msft(ol.oracle_sim(simulator_cfg()))
 
 
 def test_resync_msft_with_internal_orders():
     """G8 = testOrderbookSimulator.py:77-108."""
-    z = np.load(ol.GOLD / "resync_msft.npz")
-    ps = ol.golden_stream("msft")
-    cfg = _capi.make_cfg(1, 50, [_capi.make_feature(_capi.F_INVENTORY, max_value=1e6, min_value=-1e6)], outer_levels=48)
-    sim = ol.oracle_sim(cfg)
-    sid = sim.add_stream(ps)
-    assert sim.b.lib.oracle_debug_reset_episode(sim.h, 0, sid, int(z["start_us"])) == 0
-    sim.debug_process_orders(0, z["agent_orders"])
-    assert sim.b.lib.oracle_debug_forward(sim.h, 0, sid, int(z["until_us"])) == 0
-    assert np.array_equal(sim.queues(0), z["queues"])
-    st = sim.env_state(0)
-    assert st["min_buy_price"] == int(z["min_buy"]) and st["max_sell_price"] == int(z["max_sell"])
-    assert st["n_resyncs"] == 1
+    check_resync_msft(ol.oracle_sim(simulator_cfg()))
 
 
 @pytest.mark.parametrize("name", TRAJ)
@@ -155,25 +121,8 @@ def test_known_answers_from_reference_tests():
 
 
 def test_feature_known_answers_of_reference_test():
-    """G6, rl4mm/features/tests/testFeatures.py:152-196 (test_order_direction_and_volume_imbalance): the reference's simulator
-    replays the MSFT slice from the first whole second in 0.1 s steps without an agent; TradeDirectionImbalance(10) and
-    TradeVolumeImbalance(10, track_internal=True) are 0 for nine updates, then 1.0 x 7, 6/36, 13/43 and 1.0 x 7, -988/14642,
-    -188/15442 (the numbers the reference's test asserts).  The fixture holds what the reference's classes produced here for
-    all 19 steps; the oracle must give exactly those."""
-    z = np.load(ol.GOLD / "feature_known_answers.npz")
-    feats = [_capi.make_feature(_capi.F_TRADE_DIRECTION_IMBALANCE, 10, 100_000, -1, 1), _capi.make_feature(_capi.F_TRADE_VOLUME_IMBALANCE, 10, 100_000, -1, 1, iparam=1)]
-    sim = ol.oracle_sim(_capi.make_cfg(1, 50, feats, step_us=100_000, outer_levels=48))
-    sid = sim.add_stream(ol.golden_stream("msft"))
-    lib = sim.b.lib
-    assert lib.oracle_debug_reset_episode(sim.h, 0, sid, int(z["start_us"])) == 0
-    assert lib.oracle_debug_features_reset(sim.h, 0) == 0
-    vals = np.zeros((19, 2))
-    for k in range(19):
-        assert lib.oracle_debug_feature_step(sim.h, 0, vals[k].ctypes.data_as(C.POINTER(C.c_double))) == 0
-    assert np.array_equal(vals, z["values"])
-    assert np.all(vals[:9] == 0)
-    for k in range(9):  # assertAlmostEqual (7 places) against the constants in the reference's test
-        assert round(vals[9 + k, 0] - z["expected_dir"][k], 7) == 0 and round(vals[9 + k, 1] - z["expected_vol"][k], 7) == 0
+    """G6, rl4mm/features/tests/testFeatures.py:152-196."""
+    check_feature_known_answers(ol.oracle_sim(feature_known_answer_cfg()))
 
 
 @pytest.mark.parametrize("name", list(ol.TERADACTYL_GOLDEN))

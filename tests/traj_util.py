@@ -92,3 +92,82 @@ def run_engine_case(sim, z, name, L):
         exp = [len(ag), ag[ag[:, 1] == 0][:, 3].sum(), ag[ag[:, 1] == 1][:, 3].sum(), (ex[:, 1] == 0).sum(), (ex[:, 1] == 1).sum(),
                ex[ex[:, 1] == 0][:, 3].sum(), ex[ex[:, 1] == 1][:, 3].sum(), cash]  # fmt: skip
         assert list(agg) == [int(x) for x in exp], f"{name} op {i} {ops[i]}: fills {list(agg)} != {exp}"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# simulator-level goldens (G2 / G8 / G6): the reference's own OrderbookSimulator and feature tests, through lobsim_reset_episode /
+# lobsim_forward / lobsim_get_fills / lobsim_features_reset of whichever library `sim` is bound to (oracle or HIP)
+# ---------------------------------------------------------------------------------------------------------------------
+def simulator_cfg(features=None, n_envs=1):
+    from rl4mm_amd import _capi
+
+    feats = features or [_capi.make_feature(_capi.F_INVENTORY, max_value=1e6, min_value=-1e6)]
+    return _capi.make_cfg(n_envs, 50, feats, step_us=100_000, outer_levels=48)
+
+
+def check_replay_msft(sim, env=0):
+    """G2 = rl4mm/simulation/tests/testOrderbookSimulator.py:46-75 with per-100ms checkpoints: book after every forward_step,
+    the FilledOrders it returned, the per-order queues at the end, the price ranges; the start book IS the LOBSTER row."""
+    z = np.load(ol.GOLD / "replay_msft.npz")
+    ps = ol.golden_stream("msft")
+    sid = sim.add_stream(ps)
+    ids = np.array([env], dtype=np.int32)
+    sim.reset_episode(int(z["times"][0]), sid, ids)
+    assert sim.env_state(env)["status"] == 0
+    assert np.array_equal(sim.top(env, 55), z["tops"][0])
+    row = ps.snaps[ps.last_snapshot_at(int(z["times"][0])), 2:]
+    top = sim.top(env, 50)
+    assert np.array_equal(top[1, :, 0], row[0::4]) and np.array_equal(top[1, :, 1], row[1::4])
+    assert np.array_equal(top[0, :, 0], row[2::4]) and np.array_equal(top[0, :, 1], row[3::4])
+    for k in range(1, len(z["times"])):
+        sim.forward(int(z["times"][k]), env_ids=ids)
+        assert sim.env_state(env)["status"] == 0, f"checkpoint {k}"
+        assert np.array_equal(sim.top(env, 55), z["tops"][k]), f"checkpoint {k}"
+        assert np.array_equal(sim.fills(env), z["fills"][z["fill_off"][k - 1] : z["fill_off"][k]]), f"fills at checkpoint {k}"
+    assert np.array_equal(sim.queues(env), z["queues"])
+    st = sim.env_state(env)
+    assert st["min_buy_price"] == int(z["min_buy"]) and st["max_sell_price"] == int(z["max_sell"])
+    assert st["now_us"] == int(z["times"][-1])
+
+
+def check_resync_msft(sim, env=0):
+    """G8 = testOrderbookSimulator.py:77-108 (test_update_outer_levels_with_internal_orders): two internal orders handed to
+    forward_step, which ends on a whole second near the edge of the initial range -> update_outer_levels with the agent's
+    orders cancelled and put back behind the replaced levels."""
+    z = np.load(ol.GOLD / "resync_msft.npz")
+    sid = sim.add_stream(ol.golden_stream("msft"))
+    ids = np.array([env], dtype=np.int32)
+    sim.reset_episode(int(z["start_us"]), sid, ids)
+    sim.forward(int(z["until_us"]), orders=[z["agent_orders"]], env_ids=ids)
+    assert np.array_equal(sim.queues(env), z["queues"])
+    st = sim.env_state(env)
+    assert st["status"] == 0 and st["n_resyncs"] == 1 and st["n_agent_orders"] == 2
+    assert st["min_buy_price"] == int(z["min_buy"]) and st["max_sell_price"] == int(z["max_sell"])
+
+
+def feature_known_answer_cfg():
+    from rl4mm_amd import _capi
+
+    feats = [_capi.make_feature(_capi.F_TRADE_DIRECTION_IMBALANCE, 10, 100_000, -1, 1), _capi.make_feature(_capi.F_TRADE_VOLUME_IMBALANCE, 10, 100_000, -1, 1, iparam=1)]
+    return simulator_cfg(feats)
+
+
+def check_feature_known_answers(sim, env=0):
+    """G6, rl4mm/features/tests/testFeatures.py:152-196 (test_order_direction_and_volume_imbalance): the simulator replays the
+    MSFT slice from the first whole second in 0.1 s steps without an agent; TradeDirectionImbalance(10) and
+    TradeVolumeImbalance(10, track_internal=True) are 0 for nine updates, then 1.0 x 7, 6/36, 13/43 and 1.0 x 7, -988/14642,
+    -188/15442 (the constants the reference's test asserts).  The fixture holds what the reference's classes produced for all 19
+    steps; `sim` must give exactly those."""
+    z = np.load(ol.GOLD / "feature_known_answers.npz")
+    sid = sim.add_stream(ol.golden_stream("msft"))
+    ids = np.array([env], dtype=np.int32)
+    sim.reset_episode(int(z["start_us"]), sid, ids)
+    sim.features_reset(ids)
+    vals = np.zeros((19, 2))
+    for k in range(19):
+        vals[k] = sim.forward(int(z["start_us"]) + 100_000 * (k + 1), env_ids=ids, update_features=True)[0]
+        assert sim.env_state(env)["status"] == 0
+    assert np.array_equal(vals, z["values"])
+    assert np.all(vals[:9] == 0)
+    for k in range(9):  # assertAlmostEqual (7 places) against the constants in the reference's test
+        assert round(vals[9 + k, 0] - z["expected_dir"][k], 7) == 0 and round(vals[9 + k, 1] - z["expected_vol"][k], 7) == 0
