@@ -172,8 +172,8 @@ def test_batched_env_reports_why_an_env_stopped():
     assert all("LOBSIM_ST_LEVEL_OVERFLOW" in d["error"] and d["status"] == _capi.ST_LEVEL_OVERFLOW for d in infos)
     obs, rew, done, infos = v.vector_step(act)  # finished envs keep saying done, nothing new to report
     assert all(done) and infos[0] == {}
-    v.reset_at(0)
-    assert v.status[0] == 0 and v.status[1] == _capi.ST_LEVEL_OVERFLOW
+    v.reset_at(0)  # (resets every finished env, see reset_at)
+    assert not v.status.any() and not v._dones.any()
     v.close()
     # (2) EmptyOrderbookError: market-order clearing of an inventory larger than the ask side
     stream = ol.golden_stream("synth_small")

@@ -120,6 +120,7 @@ def test_forward_steps_with_internal_orders_against_oracle(ladder_levels):
             now[dead] = (now[dead] // 10**6 + 1) * 10**6
             for sim in (gpu, cpu):
                 sim.reset_episode(now[dead], 0, dead)
+                sim.set_portfolio(0, 10**9, dead)  # (reset_episode keeps the portfolio, and the one an error left behind is not defined)
     assert n_fills > 2000 and n_internal > 200
     assert max(cpu.env_state(e)["n_resyncs"] for e in range(n)) > 0
     gpu.close()
