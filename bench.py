@@ -36,7 +36,7 @@ HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md
 ENVS_PER_GPU = 4096
 STEP_US = 100_000
 EPISODE_US = 1_800_000_000  # 30 min, the reference default
-PROFILE_ROUND = "r3"
+PROFILE_ROUND = "r4"
 REPEATS = 5  # timed regions of --steps steps per invocation; `value` is the median region
 
 WORKLOADS = {
@@ -85,7 +85,7 @@ def build_stream(sim_seconds):
 
 
 def shared_streams(workload, sim_seconds, rank, dist):
-    """The streams of a multi-rank job: local rank 0 generates them once and parks them as .npz, the others load them
+    """The streams of a multi-rank job (one node): rank 0 generates them once and parks them as .npz, the others load them
     (eight generators next to eight ranks on a box that grants 16 CPUs made every rank's set-up - and its first timed
     steps - jittery).  One rank: just build."""
     if dist is None:
@@ -96,6 +96,8 @@ def shared_streams(workload, sim_seconds, rank, dist):
 
     n = len(DEEP50_RATES) if workload == "deep50" else 1
     d = Path(tempfile.gettempdir()) / f"lobsim_bench_{os.environ.get('MASTER_PORT', '0')}_{workload}_{sim_seconds}"
+    # (the hand-over goes through a node-local directory: one node, as the contract says - `--nnodes=1`)
+    assert int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))) == int(os.environ.get("WORLD_SIZE", "1")), "bench.py runs the ranks of ONE node"
     if rank == 0:
         d.mkdir(parents=True, exist_ok=True)
         for i, s in enumerate(build_streams(workload, sim_seconds)):
@@ -284,41 +286,80 @@ def cpu_baseline(workload, budget_s=10.0):
 # the Python boundary (reported beside `value`, never as it)
 # ---------------------------------------------------------------------------------------------------------------------
 def facade_leg(sim, stream, n_envs, device_id, steps=60):
-    """env-steps/s through the API the reference's callers hold: HistoricalOrderbookVectorEnv.vector_step_arrays (numpy in,
-    numpy out: actions cross PCIe to the device, observations / rewards / dones back, every step), the same through RLlib's
-    list-shaped vector_step, and the C-ABI's host-pointer lobsim_step underneath them; plus vector_reset (start draws on
-    the host + 3000 warm-up steps per env on the device)."""
+    """env-steps/s through the API the reference's callers hold (reported beside `value`, never as it):
+      vector_step_tensors  torch CUDA tensors in and out on torch's current stream, no PCIe, no host sync per step - the path of a
+                           learner that lives on the GPU (rl4mm/helpers/main_helper.py:260-261: the reference's consumer is a torch PPO)
+      vector_step_arrays   numpy in, numpy out: the kernel reads the actions from / writes its outputs to pinned host memory itself
+      lobsim_step          the C-ABI's host-pointer entry underneath (caller's pageable arrays: two memcpys around the same launch)
+      vector_step          RLlib's list-shaped VectorEnv call
+    plus vector_reset (start draws on the host + 3000 warm-up steps per env on the device) and RLlib's episode boundary: N
+    consecutive reset_at(i) calls after all envs finished (one launch for all of them since round 4)."""
     from datetime import datetime, timedelta
+
+    import torch
 
     from rl4mm_amd import env as E
 
     rng = np.random.Generator(np.random.PCG64(7))
     acts = rng.uniform(0, 10, size=(steps + 5, n_envs, 4))
-    out = {"unit": "env-steps/s", "steps": steps, "envs": n_envs, "note": "host numpy arrays in and out every step (PCIe inclusive); `value` is the device-pointer entry"}
+    out = {"unit": "env-steps/s", "steps": steps, "envs": n_envs,
+           "note": "vector_step_tensors: device tensors, asynchronous; the others: host numpy arrays in and out every step (PCIe inclusive); `value` is the device-pointer entry"}
 
-    def rate(fn):
+    def rate(fn, sync=None):  # fn(t): one step with the t-th action batch
         for t in range(5):
-            fn(acts[t])
+            fn(t)
+        if sync:
+            sync()
         t0 = time.perf_counter()
-        for t in range(steps):
-            fn(acts[5 + t])
+        for t in range(5, 5 + steps):
+            fn(t)
+        if sync:
+            sync()
         return n_envs * steps / (time.perf_counter() - t0)
 
-    out["lobsim_step_host_pointers"] = rate(lambda a: sim.step(a))
+    out["lobsim_step_host_pointers"] = rate(lambda t: sim.step(acts[t]))
     day = datetime.strptime(stream.trading_date, "%Y-%m-%d")
-    venv = E.HistoricalOrderbookVectorEnv(
-        n_envs, E.StreamCatalog().add(stream), ticker=stream.ticker, n_levels=stream.n_levels, min_date=day, max_date=day,
-        min_start_timedelta=timedelta(hours=10), max_end_timedelta=timedelta(hours=10, minutes=31), episode_length=timedelta(minutes=30),
-        initial_portfolio=E.Portfolio(inventory=0, cash=10**12), per_step_reward_function=E.PnL(), terminal_reward_function=E.PnL(), device_id=device_id, max_levels=128,
-    )  # fmt: skip
+
+    def make(obs_dtype, **kw):
+        return E.HistoricalOrderbookVectorEnv(
+            n_envs, E.StreamCatalog().add(stream), ticker=stream.ticker, n_levels=stream.n_levels, min_date=day, max_date=day,
+            min_start_timedelta=timedelta(hours=10), max_end_timedelta=timedelta(hours=10, minutes=31), episode_length=timedelta(minutes=30),
+            initial_portfolio=E.Portfolio(inventory=0, cash=10**12), per_step_reward_function=E.PnL(), terminal_reward_function=E.PnL(), device_id=device_id,
+            obs_dtype=obs_dtype, **kw)  # fmt: skip
+
+    venv = make(np.float64)
     np.random.seed(11)
     venv.vector_reset_arrays()
     t0 = time.perf_counter()
     venv.vector_reset_arrays()
     out["vector_reset_ms"] = (time.perf_counter() - t0) * 1e3
-    out["vector_step_arrays"] = rate(lambda a: venv.vector_step_arrays(a))
-    out["vector_step_lists"] = rate(lambda a: venv.vector_step(a))
+    out["vector_step_arrays"] = rate(lambda t: venv.vector_step_arrays(acts[t]))
+    out["vector_step_arrays_views"] = rate(lambda t: venv.vector_step_arrays(acts[t], copy=False))
+    out["vector_step_lists"] = rate(lambda t: venv.vector_step(acts[t]))
     venv.close()
+    venv = make(np.float32)
+    venv.vector_reset_arrays()
+    out["vector_step_arrays_f32_obs"] = rate(lambda t: venv.vector_step_arrays(acts[t]))
+    # tensor path on a torch side stream (the null stream costs two stream waits per step)
+    d_acts = torch.from_numpy(acts).to(torch.device("cuda", device_id))
+    venv.vector_reset_tensors()
+    with torch.cuda.stream(torch.cuda.Stream(device=torch.device("cuda", device_id))):
+        out["vector_step_tensors_f32_obs"] = rate(lambda t: venv.vector_step_tensors(d_acts[t]), sync=torch.cuda.synchronize)
+    venv.close()
+    # RLlib's episode boundary: every env finishes on the same step, then reset_at(i) for each
+    short = E.HistoricalOrderbookVectorEnv(
+        n_envs, E.StreamCatalog().add(stream), ticker=stream.ticker, n_levels=stream.n_levels, min_date=day, max_date=day, min_start_timedelta=timedelta(hours=10),
+        max_end_timedelta=timedelta(hours=10, seconds=30), episode_length=timedelta(seconds=0.5), initial_portfolio=E.Portfolio(inventory=0, cash=10**12),
+        per_step_reward_function=E.PnL(), terminal_reward_function=E.PnL(), device_id=device_id)  # fmt: skip
+    short.vector_reset_arrays()
+    for t in range(5):
+        _, _, done, _ = short.vector_step_arrays(acts[t])
+    assert done.all()
+    t0 = time.perf_counter()
+    for i in range(n_envs):
+        short.reset_at(i)
+    out["reset_at_all_ms"] = (time.perf_counter() - t0) * 1e3
+    short.close()
     return out
 
 
@@ -384,7 +425,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of all-core CPU work in the cpu_baseline sample")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # CPU test of the launcher (gloo, no lobsim)
     ap.add_argument("--repeats", type=int, default=REPEATS, help="timed regions of --steps steps; `value` is the median region")
-    ap.add_argument("--ladder-levels", type=int, default=0, help="price levels per side kept on chip (0 = the library's choice: 64 for books of <= 16 visible levels, else 128)")
+    ap.add_argument("--ladder-levels", type=int, default=0, help="price levels per side kept on chip (0 = the library's choice: 64 for books of <= 56 visible levels, else 128)")
     ap.add_argument("--no-facade", action="store_true", help="skip the Python-boundary leg (VectorEnv.vector_step_arrays, host-pointer lobsim_step)")
     args = ap.parse_args()
     if args.envs is None:

@@ -145,8 +145,8 @@ typedef long long ll2_t __attribute__((ext_vector_type(2)));
 struct alignas(16) I64x2 { int64_t x, y; };
 
 // Everything below is a member of Eng<LVT>: LVT = price levels per side the LDS-resident ladder holds (64 or 128; the HBM
-// image always has room for lobk::LV = 128).  The 64-level build is the one the 10-level configurations run: 7.5 KB of
-// ladder + agent state per env leaves LDS room for the message batch and the feature state to be prefetched by LDS-DMA.
+// image always has room for lobk::LV = 128).  The 64-level build is the one books of up to 56 visible levels run (lobsim_create;
+// the levels beyond the on-chip ladder live in the far rings, so the width is a performance choice): 7.5 KB of LDS per env.
 // SPEC = the kernels of the reference's DEFAULT env configuration with its constants folded at compile time: 10 quote levels
 // from the touch (min_quote_level 0, max_quote_level 10), tick 100, 0.1 s steps, a 4-dim action, no concentration / market
 // order clearing / enter_spread (rl4mm/helpers/main_helper.py:70-100; lobsim_host.inc picks it when the cfg says exactly
