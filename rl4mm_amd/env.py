@@ -563,6 +563,7 @@ class HistoricalOrderbookVectorEnv(_RayVectorEnv):
         self.limits = self.sim.limits()  # capacities of this handle (lobsim_get_limits): level_slabs, queue_slots, agent_orders, ...
         self.status = np.zeros(num_envs, dtype=np.int32)  # enum lobsim_status bits of the envs that stopped on an error (refreshed when a step reports done)
         self._io = None          # pinned step buffers (array path), mapped on first use
+        self._out_pool = []      # output arrays of vector_step_arrays(copy=True), reused once the caller has dropped them
         self._reset_cache = {}   # env index -> first observation of a reset made ahead of its reset_at call
         self._t = None           # tensor path state
 
@@ -743,16 +744,15 @@ class HistoricalOrderbookVectorEnv(_RayVectorEnv):
         f32 = self.obs_dtype == np.float32
         self.sim.step_host_io(use_active, 2 if f32 else 1)
         obs, reward, done = io["obs_f32" if f32 else "obs"], io["reward"], io["done"].view(np.bool_)
+        if copy:
+            o, r, d = self._out_buffers(obs.dtype)
+            np.copyto(o, obs), np.copyto(r, reward), np.copyto(d, done)
+            obs, reward, done = o, r, d
         if use_active:  # an env that finished earlier and was not reset did not step: it keeps saying done, with no reward
             reward = np.where(self._dones, 0.0, reward)
             new_done = done & ~self._dones
-            done = done.copy() if copy else done
         else:
             new_done = done
-            if copy:
-                reward, done = reward.copy(), done.copy()
-        if copy:
-            obs = obs.copy()
         if new_done.any():
             self._note_dones(new_done)
         infos = None
@@ -765,6 +765,21 @@ class HistoricalOrderbookVectorEnv(_RayVectorEnv):
                 for i in bad:
                     infos[i] = dict(infos[i], error=self.error_text(int(self.status[i])), status=int(self.status[i]))
         return obs, reward, done, infos
+
+    def _out_buffers(self, obs_dtype):
+        """Arrays for one step's outputs.  Fresh memory for 4096 envs' worth of outputs costs more than the copy itself (the pages are
+        faulted in on first touch): a set the caller no longer references - the usual case, a loop that consumes a step's outputs
+        before the next step - is handed out again; a set that is still referenced (by the caller or by a view of it) is left
+        alone and a new one is made, so holding on to results stays safe."""
+        import sys
+
+        for bufs in self._out_pool:
+            if bufs[0].dtype == obs_dtype and all(sys.getrefcount(b) == 3 for b in bufs):  # (the pool's tuple, the loop variable's tuple element, getrefcount's argument)
+                return bufs
+        bufs = (np.empty((self.num_envs, self.sim.obs_dim), dtype=obs_dtype), np.empty(self.num_envs, dtype=np.float64), np.empty(self.num_envs, dtype=np.bool_))
+        if len(self._out_pool) < 8:
+            self._out_pool.append(bufs)
+        return bufs
 
     # ---- tensor path: torch tensors on the env's device, torch's current stream, no PCIe, no host sync per step ----------
     def _tensors(self):

@@ -204,3 +204,33 @@ def test_limits_and_default_level_budget():
         assert lim["bytes_per_env"] > slabs * 8192
         s.close()
     assert _lib.binding().fn["abi_version"]() == _capi.ABI_VERSION
+
+
+def test_array_path_outputs_stay_valid_while_referenced():
+    """vector_step_arrays(copy=True) recycles its output arrays only once the caller has dropped them: arrays (or views of them)
+    that are kept hold their values over later steps; copy=False hands out the pinned buffers themselves, which the next step
+    overwrites."""
+    n = 64
+    v = _venv(n)
+    np.random.seed(1)
+    v.vector_reset_arrays()
+    rng = np.random.Generator(np.random.PCG64(2))
+    kept = []
+    for t in range(12):
+        obs, rew, done, _ = v.vector_step_arrays(rng.uniform(0, 10, size=(n, 4)))
+        kept.append((obs, obs.copy(), rew[3:5], rew[3:5].copy()))  # the array itself and a view of the reward array
+    for obs, obs_then, rv, rv_then in kept:
+        assert np.array_equal(obs, obs_then) and np.array_equal(rv, rv_then)
+    assert len({id(k[0]) for k in kept}) == 12
+    ids = set()
+    for t in range(12):  # dropped every step: the same buffers come back
+        obs, rew, done, _ = v.vector_step_arrays(rng.uniform(0, 10, size=(n, 4)))
+        ids.add(id(obs))
+        del obs, rew, done
+    assert len(ids) <= 2
+    a = v.vector_step_arrays(rng.uniform(0, 10, size=(n, 4)), copy=False)[0]
+    a_then = a.copy()
+    b = v.vector_step_arrays(rng.uniform(0, 10, size=(n, 4)), copy=False)[0]
+    assert a is b or np.shares_memory(a, b)
+    assert not np.array_equal(a_then, b)
+    v.close()
