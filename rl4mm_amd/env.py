@@ -777,8 +777,9 @@ class HistoricalOrderbookVectorEnv(_RayVectorEnv):
             if bufs[0].dtype == obs_dtype and all(sys.getrefcount(b) == 3 for b in bufs):  # (the pool's tuple, the loop variable's tuple element, getrefcount's argument)
                 return bufs
         bufs = (np.empty((self.num_envs, self.sim.obs_dim), dtype=obs_dtype), np.empty(self.num_envs, dtype=np.float64), np.empty(self.num_envs, dtype=np.bool_))
-        if len(self._out_pool) < 8:
-            self._out_pool.append(bufs)
+        if len(self._out_pool) >= 8:
+            self._out_pool.pop(0)  # (all in use: the oldest set now belongs to whoever still holds it)
+        self._out_pool.append(bufs)
         return bufs
 
     # ---- tensor path: torch tensors on the env's device, torch's current stream, no PCIe, no host sync per step ----------
