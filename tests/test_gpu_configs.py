@@ -132,11 +132,14 @@ def test_config4_shard_8192_envs_50_levels_full_episode():
     one batch, 100 ms snapshot frequency, and a FULL 30-minute episode (18000 steps after the 5-minute warm-up) - the run that
     shows whether the per-env capacities (price levels, queue slots, agent orders) hold on deep books: no env may raise a
     status bit, every env must report done exactly at the last step, and 256 envs (64 per ticker) must agree with the oracle
-    over the whole episode: inventory / cash / price (bit-exact) and the observation after every 300-step launch, the fill
-    counters and resync counts at the end, the whole book of sixteen of them order by order."""
+    over the whole episode: inventory / cash / price (bit-exact) and the observation after every 300 steps, the fill
+    counters and resync counts at the end, the whole book of sixteen of them order by order.  The first 2100 steps are 2100
+    launches of the step kernel (lobsim_step_device, what `bench.py --workload deep50` times), the rest 300-step launches of
+    the rollout kernel."""
     import torch
 
     n, T, chunk = 8192, 18000, 300
+    per_step_chunks = 7
     with mp.get_context("spawn").Pool(4) as pool:
         streams = pool.map(_deep_stream, range(4))
     cfg = bench.workload_cfg(_capi, "deep50", n)
@@ -156,9 +159,14 @@ def test_config4_shard_8192_envs_50_levels_full_episode():
     for c in range(T // chunk):
         acts = torch.rand((chunk, n, 4), dtype=torch.float64, device="cuda", generator=gen) * 10.0
         torch.cuda.synchronize()  # the handle launches on its own stream: the actions (torch's stream) must be complete
-        gpu.rollout_device(_capi.POLICY_GIVEN, [], chunk, acts.data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr(), 0, steps.data_ptr())
-        gpu.sync()
-        assert int(steps.min()) == chunk, f"chunk {c}: an env stopped early (status bit or early done)"
+        if c < per_step_chunks:  # one launch of the deep-book STEP kernel per env.step(): 2100 consecutive steps of the whole shard
+            for t in range(chunk):
+                gpu.step_device(acts[t].data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr())
+            gpu.sync()
+        else:
+            gpu.rollout_device(_capi.POLICY_GIVEN, [], chunk, acts.data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr(), 0, steps.data_ptr())
+            gpu.sync()
+            assert int(steps.min()) == chunk, f"chunk {c}: an env stopped early (status bit or early done)"
         last = c == T // chunk - 1
         assert int(done.sum()) == (n if last else 0), f"chunk {c}: {int(done.sum())} envs done"
         out = ol.oracle_rollout(cpu, _capi.POLICY_GIVEN, [], chunk, acts[:, torch.from_numpy(sample).cuda()].cpu().numpy(), want_actions=False)
