@@ -427,6 +427,12 @@ def main():
     ap.add_argument("--repeats", type=int, default=REPEATS, help="timed regions of --steps steps; `value` is the median region")
     ap.add_argument("--ladder-levels", type=int, default=0, help="price levels per side kept on chip (0 = the library's choice: 64 for books of <= 56 visible levels, else 128)")
     ap.add_argument("--no-facade", action="store_true", help="skip the Python-boundary leg (VectorEnv.vector_step_arrays, host-pointer lobsim_step)")
+    # multi-rank readiness on a ONE-GPU box (tests/test_gpu_multirank.py): every rank uses device 0; RCCL refuses two ranks on one
+    # device, so the collectives of that mode run over gloo on host copies - the rank body, sharding, seeding, timing harness and
+    # gather are the ones of the real multi-GPU run
+    ap.add_argument("--ranks-share-gpu", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--seed-rank", type=int, default=None, help=argparse.SUPPRESS)  # a single-rank run with the seeds of this rank of a larger job
+    ap.add_argument("--dump-returns", default=None, help=argparse.SUPPRESS)  # .npy of the gathered per-env episode returns
     args = ap.parse_args()
     if args.envs is None:
         args.envs = 8192 if args.workload == "deep50" else ENVS_PER_GPU
@@ -450,12 +456,18 @@ def main():
     from rl4mm_amd import _capi, _lib
 
     dist = None
+    if args.ranks_share_gpu:
+        local_rank = 0
     if under_torchrun:  # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.ranks_share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    seed_rank = rank if args.seed_rank is None else args.seed_rank
     K, W, N, wl, R = args.steps, args.warmup, args.envs, args.workload, max(1, args.repeats)
     if os.environ.get("LOBSIM_LIB") and rank == 0:
         print(f"bench.py: LOBSIM_LIB override active, running {os.environ['LOBSIM_LIB']} (no staleness check)", file=sys.stderr)
@@ -470,7 +482,7 @@ def main():
     for s in streams:
         sim.add_stream(s)
     sim.set_portfolio(0, 10**12)  # initial_cash 1e12 (main_helper.py:78)
-    starts, sids = workload_starts(wl, N, len(streams), 1234 + rank)
+    starts, sids = workload_starts(wl, N, len(streams), 1234 + seed_rank)
     t0 = time.perf_counter()
     sim.reset(starts, sids)  # snapshot + 3000 warm-up steps per env (5 min Volatility window)
     reset_s = time.perf_counter() - t0
@@ -488,7 +500,7 @@ def main():
         def step(t):  # one env.step() per env per launch, the rule-based agent's action computed in the kernel prologue
             sim.rollout_device(_capi.POLICY_TERADACTYL, TERADACTYL_PARAMS, 1, 0, 0, *out_ptrs, 0)
     else:
-        acts = torch.from_numpy(np.random.Generator(np.random.PCG64(42 + rank)).uniform(0, 10, size=(R * K + W, N, 4))).to(dev)
+        acts = torch.from_numpy(np.random.Generator(np.random.PCG64(42 + seed_rank)).uniform(0, 10, size=(R * K + W, N, 4))).to(dev)
         # device addresses worked out ahead of the timed region (a short region - the driver times 20 steps - would otherwise
         # charge the tensor indexing of its first step as GPU idle time)
         act_ptrs = [acts[t].data_ptr() for t in range(R * K + W)]
@@ -535,15 +547,18 @@ def main():
     if dist:
         from rl4mm_amd.dist import gather_episode_returns
 
-        mine = torch.tensor([local_elapsed / K * 1e3], dtype=torch.float64, device=dev)
+        cdev = torch.device("cpu") if dist.get_backend() == "gloo" else dev  # (gloo: ranks sharing one GPU, host copies)
+        mine = torch.tensor([local_elapsed / K * 1e3], dtype=torch.float64, device=cdev)
         allms = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allms, mine)
         per_rank_ms = [float(x.item()) for x in allms]
-        all_returns = gather_episode_returns(returns)
+        all_returns = gather_episode_returns(returns.to(cdev))
     else:
         all_returns = returns
     n_bad = int((torch.isnan(all_returns)).sum().item())
 
+    if rank == 0 and args.dump_returns:
+        np.save(args.dump_returns, all_returns.cpu().numpy())
     if rank == 0:
         # algorithmic bytes per env-step: 32 B per replayed message + 105 B of step I/O
         t_lo = starts + W * STEP_US
@@ -582,6 +597,11 @@ def main():
             }
         if os.environ.get("LOBSIM_LIB"):
             out["config"]["lobsim_lib_override"] = os.environ["LOBSIM_LIB"]
+        if args.ranks_share_gpu:
+            out["config"]["ranks_share_one_gpu"] = True
+            out["config"]["collective_backend"] = "gloo on host copies (RCCL refuses two ranks on one device); not a scaling measurement"
+        if world > 1:
+            out["config"]["collective_backend"] = out["config"].get("collective_backend", "nccl (RCCL)")
         if world == 1 and wl == "random" and not args.no_facade:
             out["facade"] = facade_leg(sim, streams[0], N, local_rank)
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,41 @@
+"""The N > 1 rank body of bench.py on a box with ONE GPU: two torchrun ranks that both use cuda:0 run the real (non-stub) path end
+to end - stream hand-over, env sharding and seeding by rank, the barrier-bracketed timed regions with the MAX over ranks, the
+episode-return gather - and each rank's returns must be exactly those of a single-rank run with that rank's seeds.  RCCL refuses
+two ranks on one device, so the collectives of this mode go over gloo on host copies; RCCL over xGMI and a scaling curve need the
+multi-GPU node the driver has (no scaling is measured or claimed here).  Needs a real MI355X: `pytest -m gpu`."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _bench(args, tmp_path, tag):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = tmp_path / f"returns_{tag}.npy"
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args, "--envs", "512", "--steps", "12", "--warmup", "3", "--repeats", "2", "--no-cpu-baseline", "--no-facade",
+                        "--dump-returns", str(out)], env=env, capture_output=True, text=True, timeout=900)  # fmt: skip
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0]), np.load(out)
+
+
+def test_two_ranks_on_one_gpu_run_the_real_rank_body(tmp_path):
+    line, returns = _bench(["--gpus", "2", "--ranks-share-gpu"], tmp_path, "two")
+    assert line["n_gpus"] == 2 and line["config"]["ranks"] == 2 and line["config"]["global_envs"] == 1024 and line["config"]["gathered_returns"] == 1024
+    assert line["config"]["ranks_share_one_gpu"] and len(line["config"]["ms_per_step_per_rank"]) == 2 and line["repeats"] == 2
+    assert line["config"]["envs_in_error_state_sampled"] == 0 and line["config"]["nan_returns"] == 0
+    assert line["value"] == pytest.approx(2 * 512 / (line["ms_per_step"] * 1e-3), rel=1e-6) and line["scaling"] == "weak"
+    assert returns.shape == (1024,) and np.abs(returns).max() > 0
+    for r in range(2):
+        one, ret_r = _bench(["--seed-rank", str(r)], tmp_path, f"one{r}")
+        assert one["n_gpus"] == 1 and ret_r.shape == (512,)
+        assert np.array_equal(returns[512 * r : 512 * (r + 1)], ret_r), f"rank {r}: returns differ from a single-rank run with its seeds"
+    assert not np.array_equal(returns[:512], returns[512:])
