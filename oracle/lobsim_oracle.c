@@ -130,6 +130,8 @@ typedef struct {
     int64_t inventory, cash;
     double price;
     FillList fin, fex; /* state.filled_orders.internal / .external of the last step */
+    int hw_queue, hw_agent, hw_levels[2]; /* high-water marks since creation: orders at one price, live agent orders, levels per side
+                                             (the reference's containers are unbounded; the HIP layout's capacities are checked against these) */
     Feature feat[LOBSIM_MAX_FEATURES];
     int status;
     int n_resyncs;
@@ -410,6 +412,16 @@ static void submit_order(Ctx* c, Order* o) {
         Level* l = side_find(&books[k]->s[o->side], o->price);
         if (!l) l = side_insert(&books[k]->s[o->side], o->price);
         level_append(l, r);
+        if (k == 0 && l->n > c->env->hw_queue) c->env->hw_queue = l->n;
+    }
+    {
+        Env* e = c->env;
+        if (ex->central.s[o->side].n > e->hw_levels[o->side]) e->hw_levels[o->side] = ex->central.s[o->side].n;
+        if (!o->is_ext) {
+            int na = 0;
+            for (int sd = 0; sd < 2; sd++) for (int i = 0; i < ex->internal.s[sd].n; i++) na += ex->internal.s[sd].lv[i].n;
+            if (na > e->hw_agent) e->hw_agent = na;
+        }
     }
 }
 
@@ -1458,5 +1470,16 @@ int oracle_features_reset(oracle_t* h, const int32_t* env_ids, int32_t n) {
         e->fin.n = e->fex.n = 0;
         for (int f = 0; f < h->cfg.n_features; f++) feature_reset(h, e, &e->feat[f], e->now_us);
     }
+    return LOBSIM_OK;
+}
+
+/* High-water marks of an env since the handle was created: out = {most orders at one price, most live agent orders, most buy
+ * levels, most sell levels} (test infrastructure: the capacities of the HIP layout are held against these). */
+int oracle_get_high_water(oracle_t* h, int32_t env, int32_t* out) {
+    if (!h || env < 0 || env >= h->cfg.n_envs || !out) return LOBSIM_ERR_ARG;
+    const Env* e = &h->env[env];
+    int lv[2] = {e->hw_levels[0], e->hw_levels[1]};
+    for (int sd = 0; sd < 2; sd++) if (e->ex.central.s[sd].n > lv[sd]) lv[sd] = e->ex.central.s[sd].n; /* (levels the snapshot / resync put there) */
+    out[0] = e->hw_queue; out[1] = e->hw_agent; out[2] = lv[0]; out[3] = lv[1];
     return LOBSIM_OK;
 }

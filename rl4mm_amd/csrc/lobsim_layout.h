@@ -26,7 +26,10 @@ namespace lobk {
 
 constexpr int WAVE = 64;
 constexpr int LV = 128;          // price levels per side of the NEAR ladder (the part of a side an env keeps in LDS; 2 per lane)
-constexpr int SLOTS = 512;       // order slots per price level (8 chunks of one wave-load each; 8 KiB slab)
+#ifndef LOBSIM_SLOTS
+#define LOBSIM_SLOTS 512
+#endif
+constexpr int SLOTS = LOBSIM_SLOTS;  // order slots per price level (chunks of one wave-load each; 16 B per slot)
 constexpr int NSLAB = 2 * LV;    // slabs whose free mask lives in the header / in LDS (the first ones handed out)
 // Levels beyond the near ladder ("far" levels: the worse end of a side) live in HBM, one ring per side that is ordered
 // best-first from its front: the level next to the near ladder's worst is at `front`, the k-th best far level at

@@ -47,8 +47,10 @@ def ramp_path(seconds_per_tick: float, sign: int = 1):
 
 
 def drift_lobster(seed: int, path, n_levels: int = 10, start_s: float = 34_200.0, duration_s: float = 2_400.0, mid: int = 2_700_000,
-                  noise_per_s: float = 12.0, depth_pad: int = 40, max_excursion: int = 2500):
-    """-> dict of LOBSTER columns (time_s, type, id, size, price, direction) + books[n, 4 * n_levels]."""
+                  noise_per_s: float = 12.0, depth_pad: int = 40, max_excursion: int = 2500, target_depth: int = 0):
+    """-> dict of LOBSTER columns (time_s, type, id, size, price, direction) + books[n, 4 * n_levels].
+    target_depth > 0: queues as deep as a thick large-cap book's - every level starts with about that many resting orders and the
+    noise keeps the visible levels near it (an order leaves with a probability proportional to its queue's length)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     next_id = [10_000_000]
 
@@ -61,7 +63,8 @@ def drift_lobster(seed: int, path, n_levels: int = 10, start_s: float = 34_200.0
     n_deep = n_levels + depth_pad + max_excursion
     for i in range(n_deep):
         for side, p in ((0, mid - TICK * (i + 1)), (1, mid + TICK * i)):
-            book[side][p] = deque([[new_id(), int(100 * rng.integers(1, 40))] for _ in range(int(rng.integers(1, 4)))])
+            n0 = int(rng.integers(1, 4)) if not target_depth or i >= n_levels + 5 else int(target_depth * rng.uniform(0.7, 1.1))
+            book[side][p] = deque([[new_id(), int(100 * rng.integers(1, 40))] for _ in range(n0)])
     cols = {k: [] for k in ("time_s", "type", "id", "size", "price", "direction")}
     rows = []
 
@@ -127,6 +130,8 @@ def drift_lobster(seed: int, path, n_levels: int = 10, start_s: float = 34_200.0
         p = vis[i]
         q = book[side][p]
         u = rng.random()
+        if target_depth:  # mean-reverting queue length: arrivals at a constant rate, departures in proportion to the queue
+            u = 0.2 if rng.random() < target_depth / (target_depth + len(q)) else (0.6 if u < 0.8 else u)
         if u < 0.45:
             oid, vol = new_id(), int(100 * rng.integers(1, 20))
             q.append([oid, vol])

@@ -58,6 +58,16 @@ def oracle_fills(sim, env=0, cap=4096) -> np.ndarray:
     return sim.fills(env, cap)
 
 
+def oracle_high_water(sim) -> np.ndarray:
+    """[n_envs, 4] = most orders at one price, most live agent orders, most buy levels, most sell levels an env has held so far."""
+    out = np.zeros((sim.n_envs, 4), dtype=np.int32)
+    sim.b.lib.oracle_get_high_water.restype = C.c_int
+    sim.b.lib.oracle_get_high_water.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+    for e in range(sim.n_envs):
+        assert sim.b.lib.oracle_get_high_water(sim.h, e, out[e].ctypes.data_as(C.POINTER(C.c_int32))) == 0
+    return out
+
+
 def oracle_peek_orders(sim, action, env=0, cap=1024) -> np.ndarray:
     out = np.zeros((cap, 5), dtype=np.int64)
     a = np.ascontiguousarray(action, dtype=np.float64)

@@ -255,3 +255,46 @@ def test_drifting_stream_with_agent_whole_batch(path):
     assert peak >= (250 if path == "triangle" else 400), peak
     _assert_same_books(gpu, cpu, (0, 37, 128, n - 1))
     gpu.close()
+
+
+def test_capacity_margins_on_a_drifting_day_with_deep_queues():
+    """What a trending day on a thick book asks of the layout's capacities - the reference's SortedDict / deques / internal book
+    are unbounded, this implementation's are not (lobsim_limits).  A constructed 30-minute day: every visible level holds ~180
+    resting orders (the queue depth of a large-cap book), 150 messages per second keep them there, the price climbs one tick every
+    6 s (each tick executes a whole level, order by order).  64 envs run the full episode with random Beta-policy actions against
+    the oracle (portfolios of every env after every 600-step launch, books at the end); the oracle's high-water marks - most
+    orders at one price, most live agent orders, most price levels - must leave a factor of two to the handle's limits."""
+    import torch
+
+    n, T, chunk = 64, 18000, 600
+    ps = ds.drift_stream(21, ds.ramp_path(6.0), duration_s=1_900.0, noise_per_s=150.0, target_depth=180)
+    F = _capi.make_feature
+    feats = [F(_capi.F_SPREAD, 0, 100_000, 0, 5000), F(_capi.F_INVENTORY, 0, 100_000, -1e6, 1e6), F(_capi.F_TRADE_VOLUME_IMBALANCE, 20, 100_000, -1, 1)]
+    cfg = _capi.make_cfg(n, 10, feats, step_us=100_000, episode_us=1_800_000_000)
+    gpu, cpu = _lib.new_sim(cfg), ol.oracle_sim(cfg)
+    starts = (34_205 + np.arange(n) % 50) * 1_000_000
+    for sim in (gpu, cpu):
+        sim.add_stream(ps)
+        sim.set_portfolio(0, 10**12)
+    assert np.array_equal(gpu.reset(starts, 0), cpu.reset(starts, 0))
+    D = gpu.obs_dim
+    obs, reward, done = torch.zeros((n, D), dtype=torch.float64).cuda(), torch.zeros(n, dtype=torch.float64).cuda(), torch.zeros(n, dtype=torch.uint8).cuda()
+    rng = np.random.Generator(np.random.PCG64(5))
+    for c in range(T // chunk):
+        acts = rng.uniform(0, 10, size=(chunk, n, 4))
+        d_acts = _dev(acts)
+        gpu.rollout_device(_capi.POLICY_GIVEN, [], chunk, d_acts.data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr(), 0, 0)
+        gpu.sync()
+        out = ol.oracle_rollout(cpu, _capi.POLICY_GIVEN, [], chunk, acts, want_actions=False)
+        for a, b, what in zip(gpu.portfolios(), cpu.portfolios(), ("inventory", "cash", "price")):
+            assert np.array_equal(a, b), f"launch {c}: {what} differs in envs {np.nonzero(a != b)[0][:8]}"
+        assert np.allclose(obs.cpu().numpy(), out["obs"], rtol=1e-12, atol=1e-9), c
+    assert not gpu.status().any() and not cpu.status().any()
+    assert done.cpu().numpy().all()
+    _assert_same_books(gpu, cpu, (0, 21, n - 1))
+    hw, lim = ol.oracle_high_water(cpu).max(axis=0), gpu.limits()
+    print(f"deep-queue drifting day: most orders at one price {hw[0]} (of {lim['queue_slots']}), live agent orders {hw[1]} (of {lim['agent_orders']}), "
+          f"levels per side {hw[2]} / {hw[3]} (of {lim['level_slabs']} in all)")
+    assert hw[0] >= 150 and hw[2] >= 250, hw  # (the day must be what the docstring says)
+    assert 2 * hw[0] <= lim["queue_slots"] and 2 * hw[1] <= lim["agent_orders"] and 2 * (hw[2] + hw[3]) <= lim["level_slabs"], (hw, lim)
+    gpu.close()

@@ -480,6 +480,12 @@ def test_real_lobster_slice_4096_envs_against_oracle():
         assert np.abs(gpu.portfolios()[0]).max() > 0, "the agent must have traded"
         for e in (0, 2047, n - 1):
             assert np.array_equal(gpu.queues(e), cpu.queues(e)), e
+        # what the real data asks of the layout's capacities (the reference's containers are unbounded): the most orders at one price,
+        # live agent orders and price levels any env held, against what the handle provides - with a factor of two to spare
+        hw, lim = ol.oracle_high_water(cpu).max(axis=0), gpu.limits()
+        print(f"MSFT slice, enter_spread={spread}: most orders at one price {hw[0]} (of {lim['queue_slots']}), live agent orders {hw[1]} (of {lim['agent_orders']}), "
+              f"levels per side {hw[2]} / {hw[3]} (of {lim['level_slabs']} in all)")
+        assert 2 * hw[0] <= lim["queue_slots"] and 2 * hw[1] <= lim["agent_orders"] and 2 * (hw[2] + hw[3]) <= lim["level_slabs"]
         gpu.close()
 
 
