@@ -64,9 +64,22 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     return LIB_PATH
 
 
+def _one_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so (SONAME libamdhip64.so.7, the one liblobsim.so
+    names).  With torch imported FIRST the loader resolves liblobsim's dependency to that copy: one HIP runtime in the process.
+    The other way round the process ends up with two runtimes, and the one that initialises second finds no GPU ("No HIP GPUs
+    are available" from the first torch.cuda call after a handle was created).  torch is the device-memory / stream plumbing of
+    this package anyway (env.py's tensor path, bench.py), so it is imported here when it is installed."""
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
 def binding() -> _capi.Binding:
     global _binding
     if _binding is None:
+        _one_hip_runtime()
         alt = os.environ.get("LOBSIM_LIB")  # diagnostics: a prebuilt variant of the same library (tools/build_variant.sh)
         if alt:
             import sys

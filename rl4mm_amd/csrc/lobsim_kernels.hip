@@ -1647,42 +1647,20 @@ SDI MsgBatch fetch_messages(const StreamDev& st, int64_t cursor) { return fetch_
 // cancellation never changes where an append lands (tail positions only grow); compaction and level creation are not
 // taken here.  Returns the lanes appended; `seg_end` = first lane that needs the general routine first (or cnt).
 // Half of all messages take this path with no scalar-unit work per message.
-#ifndef LOBSIM_PAR_EXEC
-#define LOBSIM_PAR_EXEC 1  // an isolated execution message (one resting order, partly or wholly) is booked in the lane-parallel pass
-#endif
-SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt, int& seg_end, int& li_memo, uint32_t& memo_levels, uint64_t ce_batch, uint64_t booked) {
+SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt, int& seg_end, int& li_memo, uint32_t& memo_levels, uint64_t ce_batch) {
     const int ln = lane();
-    const bool in = ln >= j0 && ln < cnt && !((booked >> ln) & 1);  // (`booked`: appends an earlier pass of this batch made ahead of the message it stopped at)
+    const bool in = ln >= j0 && ln < cnt;
     const int type = (int)((b.meta >> LOBSIM_TYPE_SHIFT) & 0xf), side = (int)((b.meta >> LOBSIM_SIDE_SHIFT) & 1);
     const int64_t vol64 = b.meta & LOBSIM_VOL_MASK;
     const bool is_lim = in && type == LOBSIM_LIMIT, is_rem = in && (type == LOBSIM_CANCELLATION || type == LOBSIM_DELETION) && vol64 > 0;
-    // ---- an ISOLATED execution (LOBSTER sends one execution message per resting order a marketable order consumed; runs of them
-    // are one merged sweep in replay_messages) is the removal of `volume` shares from the HEAD of the best level of the resting
-    // side, plus a fill record.  It is taken here when that is certain to stay inside the best level whatever else this segment
-    // does: its volume is smaller than the level's volume minus everything the segment's cancellations could take from that
-    // level.  Then the sweep can neither empty the level nor reach an order appended behind it, so every other lane of the
-    // segment commutes with it except those that name the very slot it consumes (the duplicate test below).  One execution per
-    // resting side and pass: a second one would have to know what the first left of the head.
-    bool exec = false;
-    if constexpr (!LOG)
-        if (LOBSIM_PAR_EXEC) {
-            const bool mk = ln < cnt && type == LOBSIM_MARKET;
-            const uint64_t mk0 = ballot(mk && side == 0), mk1 = ballot(mk && side == 1);
-            if (mk0 | mk1) {
-                const uint64_t mine = side ? mk1 : mk0;  // executions with my aggressor side, neighbours outside the segment included
-                const bool nb = (ln > 0 && ((mine >> (ln - 1)) & 1)) || (ln < 63 && ((mine >> (ln + 1)) & 1));
-                exec = in && mk && !nb && vol64 > 0 && vol64 < (1ll << 31) && S.n_lv[side ^ 1] > 0;
-            }
-        }
-    const int tside = exec ? side ^ 1 : side;  // the side of the book this lane works on
     // the level every lane's price names: searched once per batch and kept across the segments of the batch for as
     // long as no level was opened or removed (S.ladder_ver counts those)
     if (memo_levels != S.ladder_ver) {
         li_memo = (ln < cnt && (type == LOBSIM_LIMIT || type == LOBSIM_CANCELLATION || type == LOBSIM_DELETION)) ? lane_find_level(L, side, S.n_lv[side], b.price) : -1;
         memo_levels = S.ladder_ver;
     }
-    const int li = (is_lim || is_rem) ? li_memo : (exec ? 0 : -1);
-    const uint64_t m = li >= 0 ? L.meta[tside][li] : 0;
+    const int li = (is_lim || is_rem) ? li_memo : -1;
+    const uint64_t m = li >= 0 ? L.meta[side][li] : 0;
 #if LOBSIM_SLOT_EARLY
     // cancellations: the position-cache entries were read once for the whole batch (replay_messages; an entry only changes
     // when its order is appended or moved in this very batch, and then the stale copy fails the verification below and the
@@ -1698,29 +1676,17 @@ SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt,
     if (is_lim && S.n_lv[side ^ 1] > 0) { const int64_t bp = L.price[side ^ 1][0]; cross = side == LOBSIM_BUY ? b.price >= bp : b.price <= bp; }
     const bool plain = is_lim && vol64 > 0 && vol64 < (1ll << 31) && li >= 0 && !cross && m_live(m) > 0 &&
                        m_tail(m) <= SLOTS - WAVE && m_tail(m) - m_head(m) - m_live(m) < LOBSIM_TOMB;
-    if (ballot(exec)) {  // (rare enough to keep its arithmetic out of the common path)
-        // first execution per resting side; the others end the segment
-        const uint64_t e0 = ballot(exec && tside == 0), e1 = ballot(exec && tside == 1);
-        const int f0 = e0 ? ffs64(e0) : 64, f1 = e1 ? ffs64(e1) : 64;
-        // what the segment's cancellations could take from each best level (their asked volumes: an upper bound)
-        const int32_t rv = (is_rem && li == 0) ? (vol64 > 0x3fffffffll ? 0x3fffffff : (int32_t)vol64) : 0;
-        const int32_t r0 = wave_sum(side == 0 ? rv : 0), r1 = wave_sum(side == 1 ? rv : 0);
-        const int64_t room = exec ? (int64_t)L.vol[tside][0] - (tside ? r1 : r0) : 0;
-        exec = exec && ln == (tside ? f1 : f0) && m_live(m) > 0 && vol64 < room;
-    }
-    const uint64_t stop = ballot(in && !(plain || is_rem || exec));
+    const uint64_t stop = ballot(in && !(plain || is_rem));
     seg_end = stop ? ffs64(stop) : cnt;
     const bool app = plain && ln < seg_end;
-    bool exe = exec && ln < seg_end;
     const uint64_t below = (1ull << ln) - 1;
 #if LOBSIM_SLOT_EARLY
-    int cslab = (int)((ce >> 16) & 0xffff), cpos = (int)(ce & 0xffff);
+    const int cslab = (int)((ce >> 16) & 0xffff), cpos = (int)(ce & 0xffff);
     // (range check against the level's meta word as it is BEFORE this segment's appends: they only move the tail up)
     bool rem = is_rem && ln < seg_end && li >= 0 && (uint32_t)(ce >> 32) == idc_tag(b.eid) && cslab == m_slab(m) && cpos >= m_head(m) && cpos < m_tail(m);
-    if (exe) { cslab = m_slab(m); cpos = m_head(m); }  // an execution takes the head of the queue (a lower bound: a tombstone there sends it to the general routine)
     // (no branch around the load: the compiler would wait for it at the end of the branch, i.e. before the appends instead
     // of behind them; a lane without a removal reads slot 0 of slab 0 and ignores it)
-    const Slot cs = S.slots[(rem || exe) ? (size_t)cslab * SLOTS + cpos : (size_t)0];
+    const Slot cs = S.slots[rem ? (size_t)cslab * SLOTS + cpos : (size_t)0];
 #endif
     const int key = (side << 8) | li;
     int rank = 0;
@@ -1745,67 +1711,47 @@ SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt,
     // segment name one order (the other, later one is replayed by the general routine afterwards, in order).
 #if !LOBSIM_SLOT_EARLY
     bool rem = is_rem && ln < seg_end && li >= 0 && (uint32_t)(ce >> 32) == idc_tag(b.eid);
-    int cslab = (int)((ce >> 16) & 0xffff), cpos = (int)(ce & 0xffff);
+    const int cslab = (int)((ce >> 16) & 0xffff), cpos = (int)(ce & 0xffff);
     const uint64_t m2 = rem ? L.meta[side][li] : 0;  // after the appends of this segment
     rem = rem && cslab == m_slab(m2) && cpos >= m_head(m2) && cpos < m_tail(m2);
-    if (exe) { cslab = m_slab(m); cpos = m_head(m); }
     Slot cs = dead_slot();
-    if (rem || exe) cs = S.slots[(size_t)cslab * SLOTS + cpos];
+    if (rem) cs = S.slots[(size_t)cslab * SLOTS + cpos];
 #endif
     rem = rem && cs.kind == K_EXT && cs.id == b.eid;
-    // an execution books against the head only if that is a resting order other than the agent's (whose fills move the portfolio:
-    // the general routine) holding at least the executed volume
-    bool exe_ok = exe && (cs.kind == K_EXT || cs.kind == K_SNAP) && (int64_t)cs.vol >= vol64;
     const int rkey = (cslab << 16) | cpos;
     // duplicates: same slot named twice -> keep the first lane only.  Rare, so first a cheap test: every lane drops its
     // number into a 64-entry table at a hash of its slot; a lane that reads back another number shares the entry (a true
     // duplicate or a hash clash), and only then does the exact loop run (one turn per distinct slot).
     uint64_t todo = 0;
-    const uint64_t rem_lanes = ballot(rem || exe_ok);
+    const uint64_t rem_lanes = ballot(rem);
 #if LOBSIM_DEDUPE_HASH
     if (rem_lanes & (rem_lanes - 1)) {  // (two or more removals: only then can two of them name one slot)
         uint32_t* tbl = reinterpret_cast<uint32_t*>(&L.cur[0][0]);
         const uint32_t h = ((uint32_t)rkey * 0x9E3779B1u) >> 26;
-        if (rem || exe_ok) tbl[h] = (uint32_t)ln;
+        if (rem) tbl[h] = (uint32_t)ln;
         wsync();
-        const bool clash = (rem || exe_ok) && tbl[h] != (uint32_t)ln;
-        if (ballot(clash)) todo = rem_lanes;
+        const bool clash = rem && tbl[h] != (uint32_t)ln;
+        if (ballot(clash)) todo = ballot(rem);
     }
 #else
-    todo = rem_lanes;
+    todo = ballot(rem);
 #endif
     for (; todo;) {
         const int f = ffs64(todo);
         const int k = rl32(rkey, f);
-        const uint64_t grp = ballot((rem || exe_ok) && rkey == k);
-        if (rkey == k && ln != f) { rem = false; exe_ok = false; }
+        const uint64_t grp = ballot(rem && rkey == k);
+        if (rem && rkey == k && ln != f) rem = false;
         todo &= ~grp;
     }
-    // A cancellation IN FRONT of the execution, at the same best level, that this pass leaves to the general routine (its order was
-    // not where the position cache said) may be the cancellation of the very order at the head: the execution must then wait too.
-    if (ballot(exe_ok)) {
-        const uint64_t left0 = ballot(is_rem && li == 0 && side == 0 && ln < seg_end && !rem), left1 = ballot(is_rem && li == 0 && side == 1 && ln < seg_end && !rem);
-        if (exe_ok && ((tside ? left1 : left0) & below)) exe_ok = false;
-    }
-    // An execution that could not be booked here ends the segment where it stands: the general routine replays it in order, and
-    // no removal behind it may have been applied before it (the appends behind it have been - harmless: see the top).
-    const uint64_t failed = ballot(exe && !exe_ok);
-    if (failed) {
-        seg_end = ffs64(failed);
-        rem = rem && ln < seg_end;
-        exe_ok = exe_ok && ln < seg_end;
-    }
     bool gone = false;
-    if (rem || exe_ok) {
+    if (rem) {
         const int32_t v = vol64 > 0x7fffffffll ? 0x7fffffff : (int32_t)vol64;
         const int32_t rv = v > cs.vol ? cs.vol : v, nv = cs.vol - rv;  // CancellationVolumeExceededError -> whole remainder
         gone = nv == 0;
         Slot w = cs; w.vol = nv; if (gone) w.kind = K_DEAD;
         S.slots[(size_t)cslab * SLOTS + cpos] = w;
-        atomicAdd(&L.vol[tside][li], -rv);
-        // live -= 1; the head moves on when it was the head that went (it stays a lower bound of the first live slot)
-        if (gone) atomicAdd(reinterpret_cast<unsigned long long*>(&L.meta[tside][li]), (unsigned long long)(-(1ll << 48)) + (cpos == m_head(m) ? (1ull << 16) : 0ull));
-        if (exe_ok) { atomicAdd(&L.ext_cnt[tside], 1); atomicAdd(&L.ext_vol[tside], rv); }  // the fill record: a resting external order, by its side (Q10)
+        atomicAdd(&L.vol[side][li], -rv);
+        if (gone) atomicAdd(reinterpret_cast<unsigned long long*>(&L.meta[side][li]), (unsigned long long)(-(1ll << 48)));  // live -= 1
     }
     wsync();
     // levels emptied by these removals leave the ladder (rare; sequential, looked up again by price)
@@ -1817,7 +1763,7 @@ SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt,
         if (ix >= 0 && m_live((uint64_t)uni64((int64_t)L.meta[sd][ix])) == 0) ladder_remove(L, S, sd, ix);
     }
     wsync();
-    return ballot(app || rem || exe_ok);
+    return ballot(app || rem);
 }
 
 // the window (now, until] of historical messages, in stream order (OrderbookSimulator.py:70-85).  `b` is the batch
@@ -1837,9 +1783,6 @@ SDI uint64_t batch_cache_entries(const Scal& S, const MsgBatch& b, int64_t until
 // plain messages.  Only the order among the waves of a SIMD matters (s_setprio).
 #ifndef LOBSIM_PRIO_RUN_W
 #define LOBSIM_PRIO_RUN_W 8  // measured 0 / 8 / 12 / 16: 140.5 / 143.8 - 144.7 / 142.0 / 141.1 - 141.6 M env-steps/s per step (thresholds 12/24/36, 16/28/40, 20/30/44 alike)
-#endif
-#ifndef LOBSIM_PRIO_ESC
-#define LOBSIM_PRIO_ESC 0  // > 0: a window that has been cut into this many lane-parallel passes runs at the top priority from then on
 #endif
 SDI int window_weight(const MsgBatch& b, int64_t until_us) {
     const bool in = b.t <= until_us;
@@ -1879,9 +1822,6 @@ SDI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, 
         if (have_ce) { ce_batch = ce_first; have_ce = false; }
         else ce_batch = batch_cache_entries(S, b, until_us);
 #endif
-#if LOBSIM_PRIO_ESC
-        int n_seg = 0;
-#endif
         uint64_t applied = 0;  // lanes whose limit order the lane-parallel pass has already booked
         int classified = 0;    // lanes below this have been through append_segment
         for (int j = 0; j < cnt && !S.status; j++) {
@@ -1892,10 +1832,7 @@ SDI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, 
                 const uint64_t ts0 = __builtin_amdgcn_s_memtime();
                 if (first_pass) { S.ev_x[8] += (uint32_t)(ts0 - t_entry); first_pass = false; }  // cycles from the top of the window to its first pass
 #endif
-                applied |= append_segment(L, S, b, j, cnt, seg_end, li_memo, memo_ver, ce_batch, applied);
-#if LOBSIM_PRIO_ESC
-                if (++n_seg == LOBSIM_PRIO_ESC) __builtin_amdgcn_s_setprio(3);
-#endif
+                applied |= append_segment(L, S, b, j, cnt, seg_end, li_memo, memo_ver, ce_batch);
 #ifdef LOBSIM_PROFILE
                 S.ev_x[2] += (uint32_t)(__builtin_amdgcn_s_memtime() - ts0);  // cycles in the lane-parallel passes
 #endif
@@ -2608,9 +2545,8 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
     }
     const bool last_step = 2 * (terminal_us - (now + CFG_STEP_US(C))) < CFG_STEP_US(C);  // terminal_time - now < step_size / 2 (:172-174), as of the end of this step
     const BetaLogs bl = beta_logs(C);  // first in the queue: the Beta volumes are computed while the rest travels
-    const StreamDev& st0 = P.streams[stream_id >= 0 ? stream_id : 0];  // (a handle has >= 1 stream once reset)
-    const int64_t* msgs0 = st0.msgs;
-    const int64_t n_msgs0 = st0.n_msgs;
+    const int64_t* msgs0 = H.msgs;  // (= streams[stream_id].msgs, the handle's empty stream for an env without one: cached in the header)
+    const int64_t n_msgs0 = H.n_msgs;
     const MsgBatch first_raw = fetch_messages(msgs0, stream_id >= 0 ? cursor : 0);  // in flight while the agent's orders are built
     // (only what the ring addresses need travels early; lanes beyond the features read feature 0's: no branch)
     const int lf = ln < F ? ln : 0;
@@ -2942,6 +2878,7 @@ SDI void reset_body(const DevCfg& C, const DevPtrs& P, const ResetArgs& A) {
         H.msg_cursor = cursor; H.stream_id = stream_id; H.price = price; H.n_resyncs = n_resyncs;
         H.min_buy = R.min_buy; H.max_sell = R.max_sell; H.init_buy_range = R.init_buy; H.init_sell_range = R.init_sell;
         for (int i = 0; i < LOBSIM_MAX_ACTION_DIM; i++) H.prev_action[i] = 0.0;
+        H.msgs = st.msgs; H.n_msgs = st.n_msgs;
     }
 }
 
@@ -2962,6 +2899,7 @@ SDI void set_book_body(const DevCfg& C, const DevPtrs& P, int env, const int64_t
         H.now_us = now_us; H.terminal_us = INT64_MAX / 4; H.episode_start_us = now_us; H.msg_cursor = 0; H.stream_id = -1;
         H.price = 0.0; H.n_resyncs = 0; H.min_buy = (double)INFINITY; H.max_sell = 0.0;
         H.init_buy_range = (double)INFINITY; H.init_sell_range = (double)INFINITY; H.status = S.status & ~LOBSIM_ST_EMPTY_BOOK;
+        H.msgs = P.streams[0].msgs; H.n_msgs = 0;  // (no stream: the batch the step kernel reads unconditionally comes from a valid address and is masked)
     }
 }
 
@@ -3064,6 +3002,7 @@ SDI void sim_reset_body(const DevCfg& C, const DevPtrs& P, const ResetArgs& A) {
         H.msg_cursor = cursor; H.stream_id = stream_id; H.price = price; H.n_resyncs = 0;
         H.min_buy = R.min_buy; H.max_sell = R.max_sell; H.init_buy_range = R.init_buy; H.init_sell_range = R.init_sell;
         for (int i = 0; i < LOBSIM_MAX_ACTION_DIM; i++) H.prev_action[i] = 0.0;
+        H.msgs = st.msgs; H.n_msgs = st.n_msgs;
     }
 }
 
@@ -3210,6 +3149,7 @@ __global__ void lob_init_hdr_kernel(DevPtrs P, int n) {
     for (int w = 0; w < NSLAB / 64; w++) h.slab_free[w] = ~0ull;
     for (int w = 0; w < NA / 64; w++) h.agent_free[w] = ~0ull;
     h.min_buy = (double)INFINITY; h.init_buy_range = (double)INFINITY; h.init_sell_range = (double)INFINITY;
+    h.msgs = P.streams[0].msgs; h.n_msgs = 0;  // (the handle's empty stream: a step before any reset still reads a batch from a valid address)
     P.hdr[i] = h;
 }
 

@@ -96,6 +96,11 @@ struct alignas(16) EnvHdr {
     int64_t info_moc_count;    // SimpleInfoCalculator.market_order_count / market_order_total_volume (InfoCalculators.py:26-27, 85-87):
     double info_moc_volume;    // live as long as the env object, never reset
     double prev_action[LOBSIM_MAX_ACTION_DIM];
+    // the env's stream as the step kernel needs it at the very top (set at reset: a copy of streams[stream_id].msgs / .n_msgs, whose
+    // arrays live as long as the handle): read with the rest of the header, it saves the dependent trip through the stream table that
+    // stood between the header and every other load of the step's prologue
+    const int64_t* msgs;
+    int64_t n_msgs;
 };
 
 // Feature scalars, one per (env, feature).
