@@ -133,7 +133,7 @@ typedef struct lobsim_cfg {
                               sides (a side can take nearly all of it, up to ladder_levels + 2048).  The reference's book is an
                               unbounded SortedDict (rl4mm/orderbook/models.py:64-69) that keeps every level that left LOBSTER's visible
                               range, so a drifting price piles up stale levels on the side it leaves (10 + one per tick of net excursion).
-                              0 = the default, 512 (8 MiB of slabs per env, whatever else is on the GPU); otherwise 64 .. 2048, raised
+                              0 = the default, 512 (16 MiB of slabs per env, whatever else is on the GPU); otherwise 64 .. 2048, raised
                               to 128 at least and rounded up to a multiple of 32.  If the pool cannot be allocated, lobsim_create
                               retries with half (down to 128): lobsim_get_limits reports what the handle really has.  The operation
                               that needs one level more sets LOBSIM_ST_LEVEL_OVERFLOW on that env (ignored by the oracle) */
@@ -279,7 +279,7 @@ typedef struct lobsim_limits {
     int32_t level_slabs;     /* price levels an env can hold in all, both sides together (= 2 x the effective max_levels) */
     int32_t ladder_levels;   /* levels per side kept on chip (64 / 128); a performance property, bounds nothing */
     int32_t far_levels;      /* levels per side beyond the on-chip ladder (2048) */
-    int32_t queue_slots;     /* live orders + tombstones at one price (512) */
+    int32_t queue_slots;     /* live orders + tombstones at one price (1024) */
     int32_t agent_orders;    /* live agent orders (128) */
     int32_t fill_log_rows;   /* rows per list of the fill log of lobsim_forward */
     int64_t bytes_per_env;   /* device memory per env */

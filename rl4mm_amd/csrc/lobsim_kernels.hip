@@ -662,6 +662,28 @@ SDI void ladder_remove(Lds& L, Scal& S, int side, int pos) {
 // ---------------------------------------------------------------------------------------------------------------
 SDI Slot dead_slot() { Slot s; s.id = 0; s.vol = 0; s.kind = K_DEAD; return s; }
 
+// Cache policy of the slot traffic (an experiment knob): an XCD's 4 MB of L2 hold 8 KB per env, about what
+// the state an env re-reads every step takes (header, ladder, agent orders, feature state, the current ring lines: ~40 lines of
+// 128 B); the ~35 slot lines a step touches compete with it.  Bits: 1 = the agent's slot stores, 2 = appended external orders,
+// 4 = cancelled external orders' stores, 8 = their loads.
+#ifndef LOBSIM_SLOT_NT
+#define LOBSIM_SLOT_NT 0
+#endif
+template <int BIT>
+SDI void slot_store(Slot* p, const Slot& w) {
+    if constexpr ((LOBSIM_SLOT_NT & BIT) != 0) {
+        ll2_t v = {w.id, (long long)(((unsigned long long)(uint32_t)w.kind << 32) | (uint32_t)w.vol)};
+        __builtin_nontemporal_store(v, reinterpret_cast<ll2_t*>(p));
+    } else *p = w;
+}
+template <int BIT>
+SDI Slot slot_load(const Slot* p) {
+    if constexpr ((LOBSIM_SLOT_NT & BIT) != 0) {
+        const ll2_t v = __builtin_nontemporal_load(reinterpret_cast<const ll2_t*>(p));
+        Slot s; s.id = v.x; s.vol = (int32_t)(uint32_t)v.y; s.kind = (int32_t)((unsigned long long)v.y >> 32);
+        return s;
+    } else return *p;
+}
 SDI Slot load_slot(const Slot* sl, int i, int head, int tail) {
     if (i >= head && i < tail) return sl[i];
     return dead_slot();
@@ -1440,7 +1462,7 @@ SDI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
         const int aidx = 32 * word + nth_set_bit32(qw, r - (word == 0 ? 0 : word == 1 ? c0 : word == 2 ? c1 : c2));
         const int tail = m_tail(m), live = m_live(m);
         Slot w; w.id = aidx; w.vol = op.vol; w.kind = K_AGENT;
-        sl[tail] = w;
+        slot_store<1>(&sl[tail], w);
         L.meta[side][li] = mk_meta(m_slab(m), live == 0 ? tail : m_head(m), tail + 1, live + 1);
         L.vol[side][li] += op.vol;
         AgentOrd o; o.price = price; o.vol = op.vol;
@@ -1469,7 +1491,7 @@ SDI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
         const int32_t cv = op.vol > cs.vol ? cs.vol : op.vol, nv = cs.vol - cv;
         gone = nv == 0;
         Slot w = cs; w.vol = nv; if (gone) w.kind = K_DEAD;
-        sl[pos] = w;
+        slot_store<1>(&sl[pos], w);
         L.agent[idx].vol = nv;
         atomicAdd(&L.vol[side][li], -cv);
         if (gone) {
@@ -1686,7 +1708,7 @@ SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt,
     bool rem = is_rem && ln < seg_end && li >= 0 && (uint32_t)(ce >> 32) == idc_tag(b.eid) && cslab == m_slab(m) && cpos >= m_head(m) && cpos < m_tail(m);
     // (no branch around the load: the compiler would wait for it at the end of the branch, i.e. before the appends instead
     // of behind them; a lane without a removal reads slot 0 of slab 0 and ignores it)
-    const Slot cs = S.slots[rem ? (size_t)cslab * SLOTS + cpos : (size_t)0];
+    const Slot cs = slot_load<8>(&S.slots[rem ? (size_t)cslab * SLOTS + cpos : (size_t)0]);
 #endif
     const int key = (side << 8) | li;
     int rank = 0;
@@ -1699,7 +1721,7 @@ SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt,
     if (app) {
         Slot w; w.id = b.eid; w.vol = (int32_t)vol64; w.kind = K_EXT;
         const int pos = m_tail(m) + rank;
-        S.slots[(size_t)m_slab(m) * SLOTS + pos] = w;
+        slot_store<2>(&S.slots[(size_t)m_slab(m) * SLOTS + pos], w);
         idc_put(S, b.eid, m_slab(m), pos);
         atomicAdd(reinterpret_cast<unsigned long long*>(&L.meta[side][li]), (1ull << 32) + (1ull << 48));  // tail += 1, live += 1
         atomicAdd(&L.vol[side][li], (int32_t)vol64);
@@ -1749,7 +1771,7 @@ SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt,
         const int32_t rv = v > cs.vol ? cs.vol : v, nv = cs.vol - rv;  // CancellationVolumeExceededError -> whole remainder
         gone = nv == 0;
         Slot w = cs; w.vol = nv; if (gone) w.kind = K_DEAD;
-        S.slots[(size_t)cslab * SLOTS + cpos] = w;
+        slot_store<4>(&S.slots[(size_t)cslab * SLOTS + cpos], w);
         atomicAdd(&L.vol[side][li], -rv);
         if (gone) atomicAdd(reinterpret_cast<unsigned long long*>(&L.meta[side][li]), (unsigned long long)(-(1ll << 48)));  // live -= 1
     }

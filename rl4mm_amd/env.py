@@ -539,7 +539,7 @@ class HistoricalOrderbookVectorEnv(_RayVectorEnv):
             enter_spread=enter_spread, inc_prev_action_in_obs=inc_prev_action_in_obs, per_step_reward=self.per_step_reward_function.desc(),
             terminal_reward=self.terminal_reward_function.desc(), device_id=device_id,
             ladder_levels=ladder_levels,  # price levels per side kept ON CHIP (0 = 64 for books of <= 56 visible levels, else 128): a performance knob
-            max_levels=max_levels,  # an env's budget of price levels (0 = 512: 2 x 512 levels over both sides, 8 MiB of device memory per env): the
+            max_levels=max_levels,  # an env's budget of price levels (0 = 512: 2 x 512 levels over both sides, 16 MiB of device memory per env): the
                                     # reference keeps stale levels that left LOBSTER's visible range for the rest of the episode - one per tick of
                                     # price drift; beyond the budget an env stops with LOBSIM_ST_LEVEL_OVERFLOW (env.limits tells what the handle has)
         )  # fmt: skip
@@ -704,7 +704,7 @@ class HistoricalOrderbookVectorEnv(_RayVectorEnv):
             parts.append("LOBSIM_ST_LEVEL_OVERFLOW: more price levels than the env's budget (max_levels; the reference never drops a level that left "
                          "LOBSTER's visible range: one stale level per tick of price drift) - pass a larger max_levels (up to 2048) or shorten the episode")
         if status & _capi.ST_QUEUE_OVERFLOW:
-            parts.append("LOBSIM_ST_QUEUE_OVERFLOW: more than 512 live orders at one price")
+            parts.append("LOBSIM_ST_QUEUE_OVERFLOW: more live orders at one price than a level's queue holds (lobsim_limits.queue_slots: 1024)")
         if status & _capi.ST_AGENT_OVERFLOW:
             parts.append("LOBSIM_ST_AGENT_OVERFLOW: more than 128 live agent orders (entries freed in a step are reusable from the next one): fewer quote levels")
         if status & _capi.ST_STREAM_END:

@@ -751,7 +751,7 @@ def test_argument_validation_and_status_flags():
     assert sim.env_state(0)["status"] & _capi.ST_STREAM_END
     # more live orders at one price than a slab holds
     sim.debug_set_book(0, None, 0)
-    orders = np.array([[1, 0, 300000, 1, 10_000 + i, 1] for i in range(600)], dtype=np.int64)
+    orders = np.array([[1, 0, 300000, 1, 10_000 + i, 1] for i in range(sim.limits()["queue_slots"] + 90)], dtype=np.int64)
     sim.debug_process_orders(0, orders)
     assert sim.env_state(0)["status"] & _capi.ST_QUEUE_OVERFLOW
     # more price levels on a side than the on-chip ladder holds: not an error (the book is unbounded like the reference's

@@ -316,7 +316,7 @@ def test_env_classes_are_gym_env_and_rllib_vector_env_when_those_import(monkeypa
         def fake_sim(cfg):  # no GPU here: the handle is not what this test is about
             made["cfg"] = cfg
             return types.SimpleNamespace(add_stream=lambda s: 0, set_portfolio=lambda *a: None, close=lambda: None, n_envs=cfg.n_envs,
-                                         limits=lambda: dict(level_slabs=1024, ladder_levels=64, far_levels=2048, queue_slots=512, agent_orders=128, fill_log_rows=1024, bytes_per_env=9 << 20))
+                                         limits=lambda: dict(level_slabs=1024, ladder_levels=64, far_levels=2048, queue_slots=1024, agent_orders=128, fill_log_rows=1024, bytes_per_env=9 << 20))
 
         monkeypatch.setattr(E._lib, "new_sim", fake_sim)
         cat = E.StreamCatalog().add(synthetic_stream(3, 10, 50.0, 9.5 * 3600, 9.5 * 3600 + 5, ticker="SYN", trading_date="2018-02-21"))
