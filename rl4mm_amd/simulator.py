@@ -91,57 +91,59 @@ def _sorted(d: dict):
     return SortedDict(d) if SortedDict is not None else dict(sorted(d.items()))
 
 
-@dataclass
-class Orderbook:  # models.py:64-101
-    buy: dict  # price -> list[LimitOrder], ascending prices like the reference's SortedDict
-    sell: dict
-    ticker: str
-    tick_size: int = 100
+class Orderbook:
+    """What callers read of the reference's ``Orderbook`` (rl4mm/orderbook/models.py:64-101): the two sides as price -> FIFO list
+    of ``LimitOrder`` (ascending prices, a ``SortedDict`` when sortedcontainers is installed) and the touch statistics derived
+    from them.  A snapshot decoded from device state, not the live book."""
+
+    def __init__(self, buy: dict, sell: dict, ticker: str, tick_size: int = 100):
+        self.buy, self.sell, self.ticker, self.tick_size = buy, sell, ticker, tick_size
+
+    def _touch(self, side: str):
+        """(best price, resting volume there) of one side; (0, 0) / (inf, 0) when the side is empty, like the reference's defaults."""
+        book = getattr(self, side)
+        if not book:
+            return (0, 0) if side == "buy" else (np.inf, 0)
+        price = max(book) if side == "buy" else min(book)
+        return price, sum(o.volume for o in book[price])
+
+    best_buy_price = property(lambda self: self._touch("buy")[0])
+    best_sell_price = property(lambda self: self._touch("sell")[0])
+    best_buy_volume = property(lambda self: self._touch("buy")[1])
+    best_sell_volume = property(lambda self: self._touch("sell")[1])
 
     @property
-    def best_buy_price(self):
-        return next(reversed(self.buy), 0)
-
-    @property
-    def best_sell_price(self):
-        return next(iter(self.sell.keys()), np.inf)
-
-    @property
-    def best_buy_volume(self):
-        return sum(order.volume for order in self.buy[self.best_buy_price])
-
-    @property
-    def best_sell_volume(self):
-        return sum(order.volume for order in self.sell[self.best_sell_price])
+    def spread(self):
+        return self.best_sell_price - self.best_buy_price
 
     @property
     def midprice(self):
         return (self.best_sell_price + self.best_buy_price) / 2
 
     @property
-    def imbalance(self):
-        return (self.best_buy_volume - self.best_sell_volume) / (self.best_buy_volume + self.best_sell_volume)
+    def imbalance(self):  # (bid volume - ask volume) / (bid volume + ask volume) at the touch, models.py:88-90
+        (_, bv), (_, av) = self._touch("buy"), self._touch("sell")
+        return (bv - av) / (bv + av)
 
     @property
-    def microprice(self):
-        return (1 + self.imbalance) / 2 * self.best_sell_price + (1 - self.imbalance) / 2 * self.best_buy_price
+    def microprice(self):  # the touch prices weighted by the OPPOSITE side's share of the volume, models.py:92-97
+        imb = self.imbalance
+        return (1 + imb) / 2 * self.best_sell_price + (1 - imb) / 2 * self.best_buy_price
 
-    @property
-    def spread(self):
-        return self.best_sell_price - self.best_buy_price
+    def __repr__(self):
+        return f"Orderbook({self.ticker}: {len(self.buy)} buy levels, {len(self.sell)} sell levels, touch {self.best_buy_price} / {self.best_sell_price})"
 
 
 def convert_to_lobster_format(orderbook: Orderbook, n_levels: int = 10) -> dict:
-    """rl4mm/extras/orderbook_comparison.py:6-19."""
-    out = {}
-    for direction in ("buy", "sell"):
-        half = getattr(orderbook, direction)
-        prices = reversed(half) if direction == "buy" else iter(half)
-        for level, price in enumerate(prices):
-            if level < n_levels:
-                out[f"{direction}_price_{level}"] = float(price)
-                out[f"{direction}_volume_{level}"] = float(sum(o.volume for o in half[price]))
-    return out
+    """A book as one LOBSTER row dict - ``{side}_price_{i}`` / ``{side}_volume_{i}`` for the best n_levels levels of each side, floats -
+    what the reference's tests compare with the database's snapshot rows (rl4mm/extras/orderbook_comparison.py:6-19)."""
+    row = {}
+    for side, best_first in (("buy", True), ("sell", False)):
+        levels = getattr(orderbook, side)
+        for i, price in enumerate(sorted(levels, reverse=best_first)[:n_levels]):
+            row[f"{side}_price_{i}"] = float(price)
+            row[f"{side}_volume_{i}"] = float(sum(o.volume for o in levels[price]))
+    return row
 
 
 class _Exchange:
