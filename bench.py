@@ -600,8 +600,8 @@ def main():
         if args.ranks_share_gpu:
             out["config"]["ranks_share_one_gpu"] = True
             out["config"]["collective_backend"] = "gloo on host copies (RCCL refuses two ranks on one device); not a scaling measurement"
-        if world > 1:
-            out["config"]["collective_backend"] = out["config"].get("collective_backend", "nccl (RCCL)")
+        if dist:
+            out["config"]["collective_backend"] = out["config"].get("collective_backend", f"{dist.get_backend()} (RCCL)" if dist.get_backend() == "nccl" else dist.get_backend())
         if world == 1 and wl == "random" and not args.no_facade:
             out["facade"] = facade_leg(sim, streams[0], N, local_rank)
         if world == 1 and not args.no_cpu_baseline:

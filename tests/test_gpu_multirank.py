@@ -39,3 +39,21 @@ def test_two_ranks_on_one_gpu_run_the_real_rank_body(tmp_path):
         assert one["n_gpus"] == 1 and ret_r.shape == (512,)
         assert np.array_equal(returns[512 * r : 512 * (r + 1)], ret_r), f"rank {r}: returns differ from a single-rank run with its seeds"
     assert not np.array_equal(returns[:512], returns[512:])
+
+
+def test_one_rank_under_torchrun_goes_through_rccl(tmp_path):
+    """The launch form the driver uses for N > 1 (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) with
+    the one GPU there is: backend "nccl" (= RCCL) is initialised on the device, the barriers, the MAX all-reduce of the region
+    times and the all-gathers of the per-rank times and episode returns run on device tensors through it.  One rank moves no
+    bytes between GPUs - what this covers is that the RCCL path of the rank body is alive end to end."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = tmp_path / "returns.npy"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29631",
+           str(ROOT / "bench.py"), "--gpus", "1", "--envs", "512", "--steps", "12", "--warmup", "3", "--repeats", "2", "--no-cpu-baseline", "--no-facade", "--dump-returns", str(out)]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == 1 and line["config"]["collective_backend"].startswith("nccl") and line["config"]["gathered_returns"] == 512
+    plain, ret_plain = _bench([], tmp_path, "plain")
+    assert np.array_equal(np.load(out), ret_plain)
