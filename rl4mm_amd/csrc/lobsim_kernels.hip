@@ -101,6 +101,7 @@ struct StepArgs {
     double params[8];       // policy parameters (lobsim.h)
     int32_t* steps_taken;   // or null: 1 per env that stepped, 0 for an env that was already done
     double* info;           // or null: [n_envs][LOBSIM_INFO_DIM] info arrays (lobsim_set_info_buffer)
+    const int32_t* order;   // or null: workgroup b steps env order[b] (longest job first across a launch that does not fit the chip at once)
 };
 
 struct ResetArgs {
@@ -126,6 +127,7 @@ struct RolloutArgs {
     int32_t* steps_taken;
     double* info;           // or null: [n_envs][LOBSIM_INFO_DIM], the info of the last step each env took
     double* trace;          // or null: [T][n_envs][LOBSIM_TRACE_DIM] per-step series (lobsim_set_trace_buffer)
+    const int32_t* order;   // or null: workgroup b runs env order[b]
 };
 
 struct ForwardArgs {  // lobsim_forward: OrderbookSimulator.forward_step for the listed envs
@@ -2525,7 +2527,9 @@ SDI void load_snapshot_book(Lds& L, Scal& S, const int64_t* row, int Lv, bool sk
 template <bool EXTRAS>
 SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
     __shared__ Lds L;
-    const int env = blockIdx.x, ln = lane();
+    // (A launch of more envs than the chip holds at once runs in rounds: the envs of the busiest streams go first - the host sorts
+    // them by their stream's message rate - so that the last round is made of short windows.  Null when all envs are resident.)
+    const int env = A.order ? A.order[blockIdx.x] : (int)blockIdx.x, ln = lane();
     if (A.active && (A.active[env] != 0) == (A.skip_mode != 0)) return;
     EnvHdr& H = P.hdr[env];
     const int F = C.c.n_features, AD = CFG_ADIM(C), D = C.obs_dim;
@@ -2726,7 +2730,7 @@ SDI Act5 teradactyl_action(const double* p, double inventory) {
 template <bool EXTRAS>
 SDI void rollout_body(const DevCfg& C, const DevPtrs& P, const RolloutArgs& A) {
     __shared__ Lds L;
-    const int env = blockIdx.x, ln = lane();
+    const int env = A.order ? A.order[blockIdx.x] : (int)blockIdx.x, ln = lane();
     if (A.active && !A.active[env]) return;
     EnvHdr& H = P.hdr[env];
     const int F = C.c.n_features, AD = C.c.action_dim, D = C.obs_dim, N = gridDim.x;
