@@ -151,12 +151,12 @@ def test_batched_env_reports_why_an_env_stopped():
     """Where the reference raises (EmptyOrderbookError: a clearing market order larger than the whole ask side) or a capacity
     is exceeded (a drifting day with a small level budget), the batched env says so: done=True with infos[i]["error"], the
     status array on every path, the reference's exception type from the single-env facade."""
-    # (1) LEVEL_OVERFLOW: price drifting one tick per 2 s, 128-level budget (256 slabs): the episode cannot hold its stale levels
+    # (1) LEVEL_OVERFLOW: price drifting one tick per 2 s, the smallest level budget (max_levels=64 -> 256 slabs): the episode cannot hold its stale levels
     ps = ds.drift_stream(11, ds.ramp_path(2.0), duration_s=1_000.0)
     day = datetime.strptime(ps.trading_date, "%Y-%m-%d")
     kw = dict(features=[E.Spread(), E.Inventory()], ticker=ps.ticker, n_levels=ps.n_levels, min_date=day, max_date=day, min_start_timedelta=timedelta(hours=9, minutes=31),
               max_end_timedelta=timedelta(hours=9, minutes=46), episode_length=timedelta(minutes=15), per_step_reward_function=E.PnL(), terminal_reward_function=E.PnL())  # fmt: skip
-    v = E.HistoricalOrderbookVectorEnv(8, E.StreamCatalog().add(ps), max_levels=128, **kw)
+    v = E.HistoricalOrderbookVectorEnv(8, E.StreamCatalog().add(ps), max_levels=64, **kw)  # (the smallest budget: raised to 128 levels = 256 slabs)
     assert v.limits["level_slabs"] == 256 and "256 price levels" in repr(v)
     v.vector_reset()
     act = np.tile([1.0, 1.0, 1.0, 1.0], (8, 1))
