@@ -234,3 +234,38 @@ def test_array_path_outputs_stay_valid_while_referenced():
     assert a is b or np.shares_memory(a, b)
     assert not np.array_equal(a_then, b)
     v.close()
+
+
+def test_tensor_path_can_be_captured_in_a_hip_graph():
+    """A closed loop on the device - policy network, env step - is launch-bound on the host; the tensor path is capturable: one
+    `vector_step_tensors` call (bound to the capture stream beforehand) recorded in a torch.cuda.CUDAGraph and replayed with the
+    actions updated in place gives, step for step, what eager calls give on a twin env."""
+    import torch
+
+    n, steps = 256, 30
+    a, b = _venv(n, obs_dtype=np.float32), _venv(n, obs_dtype=np.float32)
+    np.random.seed(5)
+    a.vector_reset_tensors()
+    np.random.seed(5)
+    b.vector_reset_tensors()
+    rng = np.random.Generator(np.random.PCG64(6))
+    acts = torch.from_numpy(rng.uniform(0, 10, size=(steps + 1, n, 4))).cuda()
+    s = torch.cuda.Stream()
+    static_act = acts[0].clone()
+    with torch.cuda.stream(s):
+        b.vector_step_tensors(static_act)  # binds the handle to the stream (lobsim_set_stream synchronises: not allowed during capture)
+        a.vector_step_tensors(acts[0])
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        ob, rb, db = b.vector_step_tensors(static_act)
+    for t in range(1, steps + 1):
+        static_act.copy_(acts[t])
+        g.replay()
+        with torch.cuda.stream(s):
+            oa, ra, da = a.vector_step_tensors(acts[t])
+        torch.cuda.synchronize()
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db), t
+    assert float(ob.abs().max()) > 0
+    a.close()
+    b.close()
