@@ -813,7 +813,7 @@ class HistoricalOrderbookVectorEnv(_RayVectorEnv):
     def vector_reset_tensors(self):
         """env.reset() of every env -> obs tensor [N, D] (obs_dtype) on the device."""
         t = self._tensors()
-        cur, target = self._bind_stream(t)
+        self._bind_stream(t)  # (the reset below synchronises the stream it runs on)
         sids, starts = self._draw(self.num_envs)
         f32 = self.obs_dtype == np.float32
         self.sim.reset_device(starts, sids, None, 0 if f32 else t["obs"].data_ptr(), t["obs"].data_ptr() if f32 else 0, t["done"].data_ptr())
@@ -841,7 +841,7 @@ class HistoricalOrderbookVectorEnv(_RayVectorEnv):
         """Reset every env whose done flag is set (one launch; synchronises: the flags are read on the host).  Returns the indices
         reset; ``status`` then holds the error bits those envs had stopped with (0 = a normal episode end)."""
         t = self._tensors()
-        cur, target = self._bind_stream(t)
+        self._bind_stream(t)  # (the reset below synchronises the stream it runs on)
         self.sim.sync()
         ids = np.nonzero(t["done"].cpu().numpy())[0].astype(np.int32)
         if len(ids) == 0:

@@ -3,7 +3,6 @@ rl4mm_amd.simulator.OrderbookSimulator the way the reference writes them against
 under test (the HIP one on the GPU box; the oracle for the CPU test of the class's host logic)."""
 from datetime import datetime, timedelta
 
-import numpy as np
 
 import oracle_lib as ol
 from rl4mm_amd.simulator import Cancellation, LimitOrder, MarketOrder, OrderbookSimulator, convert_to_lobster_format, create_order
