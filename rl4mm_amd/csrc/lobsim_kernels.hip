@@ -159,6 +159,7 @@ template <int LVT, bool SPEC = false, bool LOG = false>
 struct Eng {
 static constexpr int LV = LVT;
 static constexpr int HALVES = LVT / 64;  // ladder entries per lane
+static constexpr int AE = NA / 64;       // agent entries per lane = words of the free masks
 #define CFG_Q(C) (SPEC ? 10 : (C).Q)
 #define CFG_TICK(C) (SPEC ? 100 : (C).c.tick_size)
 #define CFG_MINQ(C) (SPEC ? 0 : (C).c.min_quote_level)
@@ -180,7 +181,9 @@ struct Lds {
     AgentOrd agent[NA];
     Op8 ops[OPS_MAX];
     int32_t cur[2][QMAX];
-    double pdf[2][QMAX];
+    // (the Beta pdf values of a step - 2 x QMAX doubles, dead once the integer volumes are out - and, after them, the per-level
+    // candidate counters of build_agent_ops live in the LAST 64 entries of `ops`, which the op list only reaches when everything
+    // that used them is done: pdf_area())
     uint16_t apos[NA];             // slot index of each live agent order inside its level's slab
     union {
         // step kernel: the two ring words each feature lane will read, asked for right after the env state and parked here until
@@ -203,8 +206,10 @@ struct Lds {
     uint32_t agent_seq;
     uint16_t far_n[2], far_front[2];  // far levels per side, ring position of the best one (EnvHdr; invariant: far_n > 0 only while the near side is full)
 };
-static_assert(sizeof(Lds) <= (LVT == 64 ? 8192 : 10240), "LDS per env: 20 (16) envs per CU with the 64 (128)-level ladder");
+static_assert(sizeof(Lds) <= (NA == 128 ? (LVT == 64 ? 8192 : 10240) : (LVT == 64 ? 10240 : 13056)), "LDS per env: 16 envs per CU with the 64-level ladder (12 with the 128-level one); 20 / 16 with 128 agent entries");
 
+static_assert(OPS_MAX >= 128 && 64 * sizeof(Op8) == 2 * QMAX * sizeof(double), "pdf_area: the last 64 op entries hold 2 x QMAX doubles");
+SDI double* pdf_area(Lds& L) { return reinterpret_cast<double*>(&L.ops[OPS_MAX - 64]); }
 SDI uint64_t mk_meta(int slab, int head, int tail, int live) {
     return (uint64_t)(uint32_t)slab | ((uint64_t)(uint32_t)head << 16) | ((uint64_t)(uint32_t)tail << 32) | ((uint64_t)(uint32_t)live << 48);
 }
@@ -1206,15 +1211,15 @@ SDI int32_t beta_volumes(Lds& L, const DevCfg& C, const Act5& action, const Beta
         // behind every other load of the step's prologue.  The exp itself stays under the narrow mask - a wave's f64
         // instruction takes as many passes as it has active 16-lane groups, so 20 active lanes cost half of 64.
         asm volatile("" : "+v"(arg));
-        if (quoting) L.pdf[my_side][my_k] = exp(arg);
+        if (quoting) pdf_area(L)[my_side * QMAX + my_k] = exp(arg);
     }
     wsync();
     int32_t desired = 0;
     if (quoting) {
-        double s = np_pairwise_sum(L.pdf[my_side], Q);
-        desired = (int32_t)rint(L.pdf[my_side][my_k] / s * 100.0);  // np.round(dist * active_volume).astype(int)
+        double s = np_pairwise_sum(pdf_area(L) + my_side * QMAX, Q);
+        desired = (int32_t)rint(pdf_area(L)[my_side * QMAX + my_k] / s * 100.0);  // np.round(dist * active_volume).astype(int)
     }
-    wsync();  // (L.pdf is reused by build_agent_ops)
+    wsync();  // (the pdf area is reused by build_agent_ops)
     return desired;
 }
 
@@ -1250,9 +1255,9 @@ SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, i
     SUBSTAMP(3);
     // ---- current agent volume per quoted level (_get_current_internal_order_volumes, :291-296); each agent entry
     // finds its quote level (or "wide")
-    int ek[2];
+    int ek[AE];
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
+    for (int r = 0; r < AE; r++) {
         AgentOrd o = L.agent[ln + 64 * r];
         ek[r] = -2;  // free entry
         if (o.vol > 0) {
@@ -1280,11 +1285,13 @@ SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, i
     // a level with diff < 0 is cancelled from its NEWEST order backwards (:240-249), an order at a price no longer
     // quoted is cancelled in full (:250-257).  Within one side the order of ops at different prices is unobservable
     // (no crossing is possible among them); buy ops stay before sell ops and the clearing order stays last.
-    AgentOrd ao[2] = {L.agent[ln], L.agent[ln + 64]};
-    int32_t need[2], newer[2] = {0, 0}, code[2];
-    bool cand[2];
+    AgentOrd ao[AE];
+    int32_t need[AE], newer[AE], code[AE];
+    bool cand[AE];
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
+    for (int r = 0; r < AE; r++) {
+        ao[r] = L.agent[ln + 64 * r];
+        newer[r] = 0;
         const int sd = (int)(ao[r].seq_side >> 31);
         need[r] = ek[r] >= 0 ? -L.cur[sd][ek[r]] : 0;
         cand[r] = ek[r] >= 0 && need[r] > 0;
@@ -1295,30 +1302,34 @@ SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, i
         // its level's list in LDS (the op list's storage, not yet written; counters in the pdf storage, already
         // consumed), then reads its own level's list: a handful of entries per lane instead of one wave-wide
         // broadcast turn per candidate.  A level with more candidates than a list holds takes the broadcast loop.
-        const uint32_t q0 = ao[0].seq_side & 0x7fffffffu, q1 = ao[1].seq_side & 0x7fffffffu;
-        int32_t* cntr = reinterpret_cast<int32_t*>(&L.pdf[0][0]);
+        uint32_t q[AE];
+#pragma unroll
+        for (int r = 0; r < AE; r++) q[r] = ao[r].seq_side & 0x7fffffffu;
+        int32_t* cntr = reinterpret_cast<int32_t*>(pdf_area(L));
         unsigned long long* lists = reinterpret_cast<unsigned long long*>(&L.ops[0]);
-        const int cap = OPS_MAX / (2 * Q);
+        const int cap = (OPS_MAX - 64) / (2 * Q);  // (the lists stop in front of the counters)
         if (ln < 2 * Q) cntr[ln] = 0;
         wsync();
-        int lvl[2], at[2];
+        int lvl[AE], at[AE];
+        bool over = false;
 #pragma unroll
-        for (int r = 0; r < 2; r++) {
+        for (int r = 0; r < AE; r++) {
             lvl[r] = (code[r] >> 8) * Q + (code[r] & 0xff);
             at[r] = 0;
             if (cand[r]) {
                 at[r] = atomicAdd(&cntr[lvl[r]], 1);
-                if (at[r] < cap) lists[lvl[r] * cap + at[r]] = ((unsigned long long)(r ? q1 : q0) << 32) | (uint32_t)ao[r].vol;
+                if (at[r] < cap) lists[lvl[r] * cap + at[r]] = ((unsigned long long)q[r] << 32) | (uint32_t)ao[r].vol;
+                over = over || at[r] >= cap;
             }
         }
         wsync();
-        const bool overflow = ballot((cand[0] && at[0] >= cap) || (cand[1] && at[1] >= cap)) != 0;
+        const bool overflow = ballot(over) != 0;
         if (!overflow) {
 #pragma unroll
-            for (int r = 0; r < 2; r++) {
+            for (int r = 0; r < AE; r++) {
                 if (!cand[r]) continue;
                 const int n = cntr[lvl[r]];
-                const uint32_t mine = r ? q1 : q0;
+                const uint32_t mine = q[r];
                 for (int i = 0; i < n; i++) {
                     const unsigned long long e = lists[lvl[r] * cap + i];
                     newer[r] += (uint32_t)(e >> 32) > mine ? (int32_t)(uint32_t)e : 0;
@@ -1327,23 +1338,23 @@ SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, i
         }
         wsync();
 #pragma unroll
-        for (int r = 0; r < 2 && overflow; r++) {  // broadcast every candidate once: volume of same-level orders newer than mine
+        for (int r = 0; r < AE && overflow; r++) {  // broadcast every candidate once: volume of same-level orders newer than mine
             uint64_t bb = ballot(cand[r]);
             while (bb) {
                 const int t = ffs64(bb);
                 bb &= bb - 1;
                 const int tc = rl32(code[r], t);
-                const uint32_t tq = (uint32_t)rl32((int32_t)(r ? q1 : q0), t);
+                const uint32_t tq = (uint32_t)rl32((int32_t)q[r], t);
                 const int32_t tv = rl32(ao[r].vol, t);
-                newer[0] += (tc == code[0] && tq > q0) ? tv : 0;
-                newer[1] += (tc == code[1] && tq > q1) ? tv : 0;
+#pragma unroll
+                for (int k = 0; k < AE; k++) newer[k] += (tc == code[k] && tq > q[k]) ? tv : 0;
             }
         }
     }
     SUBSTAMP(5);
-    int32_t cvol[2];
+    int32_t cvol[AE];
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
+    for (int r = 0; r < AE; r++) {
         cvol[r] = 0;
         if (cand[r] && need[r] > newer[r]) cvol[r] = min(ao[r].vol, need[r] - newer[r]);
         if (ek[r] == -1) cvol[r] = ao[r].vol;  // wide
@@ -1356,7 +1367,7 @@ SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, i
         if (lim) { const int at = base + popc64(lm & below); if (at < OPS_MAX) { Op8 op; op.vol = diff; op.code = LOBSIM_LIMIT | (side << 4) | (my_k << 8); L.ops[at] = op; } }
         base += popc64(lm);
 #pragma unroll
-        for (int r = 0; r < 2; r++) {
+        for (int r = 0; r < AE; r++) {
             const bool cn = cvol[r] > 0 && (int)(ao[r].seq_side >> 31) == side;
             const uint64_t cm = ballot(cn);
             if (cn) { const int at = base + popc64(cm & below); if (at < OPS_MAX) { Op8 op; op.vol = cvol[r]; op.code = LOBSIM_CANCELLATION | (side << 4) | ((ln + 64 * r) << 8); L.ops[at] = op; } }
@@ -1451,17 +1462,35 @@ SDI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
     bool lim_ok = is_limit && li >= 0 && m_tail(m) < SLOTS && m_tail(m) - m_head(m) - m_live(m) < LOBSIM_TOMB;
     uint64_t lim_mask = ballot(lim_ok);
     int R = popc64(lim_mask);
-    uint64_t free0 = lds_u64(L.agent_free[0]), free1 = lds_u64(L.agent_free[1]);
+    uint64_t fw[AE];
+    int n_free = 0;
+#pragma unroll
+    for (int k = 0; k < AE; k++) { fw[k] = lds_u64(L.agent_free[k]); n_free += popc64(fw[k]); }
     const uint32_t seq0 = (uint32_t)uni((int32_t)L.agent_seq);
-    if (R > popc64(free0) + popc64(free1)) { lim_ok = false; lim_mask = 0; R = 0; }  // sequential path reports the overflow
+    if (R > n_free) { lim_ok = false; lim_mask = 0; R = 0; }  // sequential path reports the overflow
     if (lim_ok) {
         int r = popc64(lim_mask & below);  // my rank among the appenders -> the r-th free agent entry
-        // (the r-th set bit of the 128-bit free mask, by popcounts - a loop clearing r bits ran up to 20 turns per lane)
-        const uint32_t q0 = (uint32_t)free0, q1 = (uint32_t)(free0 >> 32), q2 = (uint32_t)free1, q3 = (uint32_t)(free1 >> 32);
-        const int c0 = __popc(q0), c1 = c0 + __popc(q1), c2 = c1 + __popc(q2);
-        const int word = (r >= c0) + (r >= c1) + (r >= c2);
-        const uint32_t qw = word == 0 ? q0 : word == 1 ? q1 : word == 2 ? q2 : q3;
-        const int aidx = 32 * word + nth_set_bit32(qw, r - (word == 0 ? 0 : word == 1 ? c0 : word == 2 ? c1 : c2));
+        // (the r-th set bit of the free mask, by popcounts over its 32-bit words - a loop clearing r bits ran up to 20 turns per lane)
+        int word = 0, before = 0;
+        uint32_t qw = (uint32_t)fw[0];
+        if constexpr (AE == 2) {  // (the shipped build: four words, straight-line)
+            const uint32_t q0 = (uint32_t)fw[0], q1 = (uint32_t)(fw[0] >> 32), q2 = (uint32_t)fw[1], q3 = (uint32_t)(fw[1] >> 32);
+            const int c0 = __popc(q0), c1 = c0 + __popc(q1), c2 = c1 + __popc(q2);
+            word = (r >= c0) + (r >= c1) + (r >= c2);
+            qw = word == 0 ? q0 : word == 1 ? q1 : word == 2 ? q2 : q3;
+            before = word == 0 ? 0 : word == 1 ? c0 : word == 2 ? c1 : c2;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2 * AE - 1; k++) {  // (uniform words, per-lane rank: selects on values)
+                const uint32_t wk = (uint32_t)(fw[k >> 1] >> (32 * (k & 1))), wn = (uint32_t)(fw[(k + 1) >> 1] >> (32 * ((k + 1) & 1)));
+                const int ck = __popc(wk);
+                const bool past = word == k && r >= before + ck;
+                before += past ? ck : 0;
+                qw = past ? wn : qw;
+                word += past ? 1 : 0;
+            }
+        }
+        const int aidx = 32 * word + nth_set_bit32(qw, r - before);
         const int tail = m_tail(m), live = m_live(m);
         Slot w; w.id = aidx; w.vol = op.vol; w.kind = K_AGENT;
         slot_store<1>(&sl[tail], w);
@@ -1528,10 +1557,8 @@ SDI void ladder_clear(Lds& L, Scal& S, int n_slab) {
     hi_free_words(S.slots)[lane()] = lane() < (n_slab - NSLAB) / 64 ? ~0ull : 0ull;  // slabs beyond the first NSLAB
     if (lane() < NSLAB / 64) L.slab_free[lane()] = ~0ull;
     if (lane() < NA / 64) { L.agent_free[lane()] = ~0ull; L.agent_pending[lane()] = 0; }
-    L.agent[lane()].vol = 0;
-    L.agent[lane() + 64].vol = 0;
-    L.apos[lane()] = 0;
-    L.apos[lane() + 64] = 0;
+#pragma unroll
+    for (int r = 0; r < AE; r++) { L.agent[lane() + 64 * r].vol = 0; L.apos[lane() + 64 * r] = 0; }
     if (lane() == 0) L.agent_seq = 0;
     wsync();
 }
@@ -1615,7 +1642,7 @@ SDI void resync_outer_levels(Lds& L, Scal& S, const DevCfg& C, const StreamDev& 
                     int64_t price = rl64(p, j);
                     int32_t vol = (int32_t)rl64(v, j);
                     // agent orders at this level: cancel them now, re-submit them at the back afterwards (:114-129)
-                    for (int r = 0; r < 2 && !S.status; r++) {
+                    for (int r = 0; r < AE && !S.status; r++) {
                         AgentOrd o = L.agent[ln + 64 * r];
                         bool hit = o.vol > 0 && (int)(o.seq_side >> 31) == side && o.price == price;
                         uint64_t hm = ballot(hit);
@@ -2300,26 +2327,29 @@ SDI void write_info(const Lds& L, const Scal& S, const DevCfg& C, EnvHdr& H, con
 // ---------------------------------------------------------------------------------------------------------------
 struct EnvRegs {  // the env state between its loads and its LDS stores
     int64_t pb, psl; uint64_t mb, ms; int32_t vb, vs;
-    AgentOrd a0, a1;
-    uint16_t q0, q1;
+    AgentOrd a[NA / 64];
+    uint16_t q[NA / 64];
 };
 
 // What load_env needs of the header, read as one cluster of scalar loads (one wait) by whoever knows the header address
 // first - read field by field where it is used, every use was a round trip of its own.
 struct HdrRegs {
-    uint64_t sf0, sf1, sf2, sf3, af0, af1;
+    uint64_t sf0, sf1, sf2, sf3, af[NA / 64];
     int64_t inventory, cash;
     uint32_t agent_seq;
     int32_t status, n_lv0, n_lv1;
     uint32_t far_n, far_front;  // two 16-bit halves each (buy | sell << 16)
 };
-static_assert(NSLAB == 256 && NA == 128, "HdrRegs holds the free masks as scalars");
+static_assert(NSLAB == 256, "HdrRegs holds the slab free mask as four scalars");
 
 SDI HdrRegs read_hdr(const EnvHdr& H) {
     const uint64_t farw = *reinterpret_cast<const uint64_t*>(&H.far_n[0]);  // far_n[2], far_front[2]: one 8-byte word
-    HdrRegs h = {H.slab_free[0], H.slab_free[1], H.slab_free[2], H.slab_free[3], H.agent_free[0], H.agent_free[1],
-                 H.inventory, H.cash, H.agent_seq, H.status, H.n_lv[0], H.n_lv[1],
-                 (uint32_t)farw, (uint32_t)(farw >> 32)};
+    HdrRegs h;
+    h.sf0 = H.slab_free[0]; h.sf1 = H.slab_free[1]; h.sf2 = H.slab_free[2]; h.sf3 = H.slab_free[3];
+#pragma unroll
+    for (int k = 0; k < NA / 64; k++) h.af[k] = H.agent_free[k];
+    h.inventory = H.inventory; h.cash = H.cash; h.agent_seq = H.agent_seq; h.status = H.status; h.n_lv0 = H.n_lv[0]; h.n_lv1 = H.n_lv[1];
+    h.far_n = (uint32_t)farw; h.far_front = (uint32_t)(farw >> 32);
     return h;
 }
 
@@ -2338,13 +2368,14 @@ SDI EnvRegs load_env_issue(Scal& S, const DevPtrs& P, int env, const HdrRegs& H)
     if (hs) { psl = G.price[1][ln]; ms = G.meta[1][ln]; vs = G.vol[1][ln]; }
     const AgentOrd* A = P.agent + (size_t)env * NA;
     const uint16_t* AP = P.apos + (size_t)env * NA;
-    const uint64_t af0 = H.af0, af1 = H.af1;
-    AgentOrd a0, a1;
-    a0.price = 0; a0.vol = 0; a0.seq_side = 0; a1 = a0;
-    uint16_t q0 = 0, q1 = 0;
-    if (!((af0 >> ln) & 1)) { a0 = A[ln]; q0 = AP[ln]; }
-    if (af1 != ~0ull && !((af1 >> ln) & 1)) { a1 = A[ln + 64]; q1 = AP[ln + 64]; }
-    EnvRegs r = {pb, psl, mb, ms, vb, vs, a0, a1, q0, q1};
+    EnvRegs r;
+    r.pb = pb; r.psl = psl; r.mb = mb; r.ms = ms; r.vb = vb; r.vs = vs;
+#pragma unroll
+    for (int k = 0; k < AE; k++) {  // (live entries only; a word with no live entry at all - the usual state of the upper ones - costs no load)
+        r.a[k].price = 0; r.a[k].vol = 0; r.a[k].seq_side = 0; r.q[k] = 0;
+        const uint64_t af = H.af[k];
+        if ((k == 0 || af != ~0ull) && !((af >> ln) & 1)) { r.a[k] = A[ln + 64 * k]; r.q[k] = AP[ln + 64 * k]; }
+    }
     return r;
 }
 
@@ -2354,8 +2385,8 @@ SDI void load_env_commit(Lds& L, Scal& S, const DevPtrs& P, int env, const HdrRe
     const bool hb = ln < S.n_lv[0], hs = ln < S.n_lv[1];
     if (hb) { L.price[0][ln] = r.pb; L.meta[0][ln] = r.mb; L.vol[0][ln] = r.vb; }
     if (hs) { L.price[1][ln] = r.psl; L.meta[1][ln] = r.ms; L.vol[1][ln] = r.vs; }
-    L.agent[ln] = r.a0; L.agent[ln + 64] = r.a1;
-    L.apos[ln] = r.q0; L.apos[ln + 64] = r.q1;
+#pragma unroll
+    for (int k = 0; k < AE; k++) { L.agent[ln + 64 * k] = r.a[k]; L.apos[ln + 64 * k] = r.q[k]; }
 #pragma unroll
     for (int s = 0; s < 2; s++)
         for (int i = ln + 64; i < S.n_lv[s]; i += 64) {
@@ -2363,7 +2394,8 @@ SDI void load_env_commit(Lds& L, Scal& S, const DevPtrs& P, int env, const HdrRe
         }
     S.status = H.status; S.n_ops = 0; S.ladder_ver = 0; S.msgs_step = 0;
     if (ln < NSLAB / 64) L.slab_free[ln] = ln == 0 ? H.sf0 : ln == 1 ? H.sf1 : ln == 2 ? H.sf2 : H.sf3;
-    if (ln < NA / 64) { L.agent_free[ln] = ln == 0 ? H.af0 : H.af1; L.agent_pending[ln] = 0; }
+#pragma unroll
+    for (int k = 0; k < AE; k++) if (ln == k) { L.agent_free[k] = H.af[k]; L.agent_pending[k] = 0; }
     if (ln < 2) { L.far_n[ln] = (uint16_t)(H.far_n >> (16 * ln)); L.far_front[ln] = (uint16_t)(H.far_front >> (16 * ln)); }
     if (ln == 0) {
         L.inv = H.inventory; L.cash = H.cash; L.agent_seq = H.agent_seq;
@@ -2397,9 +2429,11 @@ SDI void store_env(const Lds& L, const Scal& S, const DevPtrs& P, int env, EnvHd
         }
     AgentOrd* A = P.agent + (size_t)env * NA;
     uint16_t* AP = P.apos + (size_t)env * NA;
-    const uint64_t af0 = lds_u64(L.agent_free[0]) | lds_u64(L.agent_pending[0]), af1 = lds_u64(L.agent_free[1]) | lds_u64(L.agent_pending[1]);
-    if (!((af0 >> ln) & 1)) { A[ln] = L.agent[ln]; AP[ln] = L.apos[ln]; }  // live entries only (see load_env)
-    if (af1 != ~0ull && !((af1 >> ln) & 1)) { A[ln + 64] = L.agent[ln + 64]; AP[ln + 64] = L.apos[ln + 64]; }
+#pragma unroll
+    for (int k = 0; k < AE; k++) {  // live entries only (see load_env)
+        const uint64_t af = lds_u64(L.agent_free[k]) | lds_u64(L.agent_pending[k]);
+        if ((k == 0 || af != ~0ull) && !((af >> ln) & 1)) { A[ln + 64 * k] = L.agent[ln + 64 * k]; AP[ln + 64 * k] = L.apos[ln + 64 * k]; }
+    }
     if (ln < NSLAB / 64) H.slab_free[ln] = L.slab_free[ln];
     if (ln < NA / 64) H.agent_free[ln] = L.agent_free[ln] | L.agent_pending[ln];
     if (ln == 0) { H.n_lv[0] = S.n_lv[0]; H.n_lv[1] = S.n_lv[1]; H.agent_seq = L.agent_seq; }
@@ -2945,24 +2979,30 @@ SDI void process_raw_order(Lds& L, Scal& S, const int64_t* r) {
     else if (type == LOBSIM_MARKET) execute(L, S, side, true, true, 0, (int32_t)vol);
     else {
         // rank -> agent index: the id-th oldest live agent order at (side, price)
-        AgentOrd o0 = L.agent[ln], o1 = L.agent[ln + 64];
-        bool m0 = o0.vol > 0 && (int)(o0.seq_side >> 31) == side && o0.price == price;
-        bool m1 = o1.vol > 0 && (int)(o1.seq_side >> 31) == side && o1.price == price;
-        uint32_t q0 = o0.seq_side & 0x7fffffffu, q1 = o1.seq_side & 0x7fffffffu;
-        uint64_t b0 = ballot(m0), b1 = ballot(m1);
-        int older0 = 0, older1 = 0;
-        for (int rr = 0; rr < 2; rr++) {
-            uint64_t bb = rr ? b1 : b0;
+        bool mt[AE];
+        uint32_t q[AE];
+        int older[AE];
+#pragma unroll
+        for (int k = 0; k < AE; k++) {
+            const AgentOrd o = L.agent[ln + 64 * k];
+            mt[k] = o.vol > 0 && (int)(o.seq_side >> 31) == side && o.price == price;
+            q[k] = o.seq_side & 0x7fffffffu;
+            older[k] = 0;
+        }
+#pragma unroll
+        for (int rr = 0; rr < AE; rr++) {
+            uint64_t bb = ballot(mt[rr]);
             while (bb) {
                 int t = ffs64(bb);
                 bb &= bb - 1;
-                uint32_t tq = (uint32_t)rl32((int32_t)(rr ? q1 : q0), t);
-                if (tq < q0) older0++;
-                if (tq < q1) older1++;
+                uint32_t tq = (uint32_t)rl32((int32_t)q[rr], t);
+#pragma unroll
+                for (int k = 0; k < AE; k++) older[k] += tq < q[k] ? 1 : 0;
             }
         }
-        uint64_t h0 = ballot(m0 && older0 == id), h1 = ballot(m1 && older1 == id);
-        int aidx = h0 ? ffs64(h0) : (h1 ? 64 + ffs64(h1) : NA + 1000);
+        int aidx = NA + 1000;
+#pragma unroll
+        for (int k = AE - 1; k >= 0; k--) { const uint64_t hk = ballot(mt[k] && older[k] == id); if (hk) aidx = 64 * k + ffs64(hk); }
         remove_order(L, S, side, price, K_AGENT, aidx, (int32_t)vol);
     }
 }
@@ -3126,12 +3166,15 @@ SDI void features_reset_body(const DevCfg& C, const DevPtrs& P, const int32_t* e
 #ifndef LOBSIM_ROLLOUT_WAVES
 #define LOBSIM_ROLLOUT_WAVES 4
 #endif
+// (the budget must be one the LDS allows - 16 envs per CU = 4 waves per SIMD with the 64-level ladder and 256 agent entries, 12 = 3 with
+// the 128-level one: asked for more, the compiler drops the constraint altogether and takes 148 registers)
+constexpr int STEP_WAVES_64 = NA == 128 ? LOBSIM_STEP_WAVES : 4, STEP_WAVES_128 = NA == 128 ? LOBSIM_STEP_WAVES_DEEP : 3;
 template <bool EXTRAS, int LVT, bool SPEC = false>
-__global__ __launch_bounds__(64, (LVT == 64 && !EXTRAS) ? LOBSIM_STEP_WAVES : LOBSIM_STEP_WAVES_DEEP) void lob_step_kernel(DevCfg C, DevPtrs P, StepArgs A) { Eng<LVT, SPEC>::template step_body<EXTRAS>(C, P, A); }
+__global__ __launch_bounds__(64, LVT == 64 ? (EXTRAS ? 4 : STEP_WAVES_64) : STEP_WAVES_128) void lob_step_kernel(DevCfg C, DevPtrs P, StepArgs A) { Eng<LVT, SPEC>::template step_body<EXTRAS>(C, P, A); }
 template <bool EXTRAS, int LVT, bool SPEC = false>
-__global__ __launch_bounds__(64, LOBSIM_ROLLOUT_WAVES) void lob_rollout_kernel(DevCfg C, DevPtrs P, RolloutArgs A) { Eng<LVT, SPEC>::template rollout_body<EXTRAS>(C, P, A); }
+__global__ __launch_bounds__(64, LVT == 64 ? LOBSIM_ROLLOUT_WAVES : STEP_WAVES_128) void lob_rollout_kernel(DevCfg C, DevPtrs P, RolloutArgs A) { Eng<LVT, SPEC>::template rollout_body<EXTRAS>(C, P, A); }
 template <bool EXTRAS, int LVT>
-__global__ __launch_bounds__(64, 4) void lob_reset_kernel(DevCfg C, DevPtrs P, ResetArgs A) { Eng<LVT>::template reset_body<EXTRAS>(C, P, A); }
+__global__ __launch_bounds__(64, LVT == 64 ? 4 : STEP_WAVES_128) void lob_reset_kernel(DevCfg C, DevPtrs P, ResetArgs A) { Eng<LVT>::template reset_body<EXTRAS>(C, P, A); }
 template <int LVT>
 __global__ __launch_bounds__(64) void lob_set_book_kernel(DevCfg C, DevPtrs P, int env, const int64_t* row, int64_t now_us) { Eng<LVT>::set_book_body(C, P, env, row, now_us); }
 template <int LVT>

@@ -44,14 +44,27 @@ static_assert(sizeof(FarLevel) == 32, "");
 constexpr size_t FAR_BYTES = 2 * (size_t)FAR_CAP * sizeof(FarLevel);
 constexpr size_t HI_BYTES = 1024;                  // hi_free[64] u64 + padding (slabs stay 1 KiB-aligned)
 constexpr size_t AUX_BYTES = FAR_BYTES + HI_BYTES;  // per env, in front of its slabs: far rings, then hi_free
-constexpr int NA = 128;          // live agent orders per env (2 per lane)
+#ifndef LOBSIM_NA
+#define LOBSIM_NA 128
+#endif
+constexpr int NA = LOBSIM_NA;    // agent orders per env (live ones + those freed in the current step), NA / 64 per lane: 128, or 256 with -DLOBSIM_NA=256.
+                                 // What bounds the reference's internal book is VOLUME - a side quotes sum(round(100 pdf)) <= 100 + Q/2 shares, so at
+                                 // most ~105 one-share orders per side - and 2 x 105 live entries + the ~20 a step adds fit into 256: under the default
+                                 // configuration LOBSIM_ST_AGENT_OVERFLOW then cannot happen.  That build keeps 16 instead of 20 envs per CU resident
+                                 // (2.5 KB more LDS per env) and loops over four instead of two entries per lane: measured -4.4 % per step at 4096
+                                 // envs (136.2 vs 142.3 M env-steps/s), -10 % on the multi-step launch, -12 % on the 8192-env deep-book shard - so the
+                                 // default stays 128, which random and rule-based policies fill to 53 - 67
+static_assert(NA % 64 == 0 && NA >= 128 && NA <= 256, "agent entries: whole lanes' worth, the index travels in 8 bits of an op code");
 #ifndef LOBSIM_IDC_N
 #define LOBSIM_IDC_N 32768
 #endif
 constexpr int IDC_N = LOBSIM_IDC_N;    // entries of the per-env external-order position cache (256 KiB; a cache: every hit is
                                  // verified against the slot it points to, misses take the queue scan)
 constexpr int QMAX = 32;         // quote levels per side (2 * QMAX <= 64 lanes)
-constexpr int OPS_MAX = 2 * QMAX + NA + 8;  // agent op list: limits + cancels + market order (resync re-adds reuse it)
+constexpr int OPS_MAX = NA == 128 ? 2 * QMAX + NA + 8 : 288;  // agent op list of a step: limits + cancellations + the clearing market order (resync
+                                 // re-adds reuse it; its last 64 entries double as the Beta-pdf scratch).  With NA = 256 the list is sized by the LDS
+                                 // budget of 16 envs per CU; the volume bound (<= ~210 cancellations + 2Q limits) fits for up to 39 quote levels.
+                                 // Beyond: LOBSIM_ST_AGENT_OVERFLOW
 
 constexpr int64_t DUMMY_PRICE = 9999999999ll;
 

@@ -137,7 +137,7 @@ def test_forward_argument_errors_and_fill_log_overflow():
     assert sim.env_state(0)["status"] & _capi.ST_ASSERT
     sim.reset_episode(36_000_000_000, sid)
     lim = sim.limits()
-    assert lim["fill_log_rows"] >= 256 and lim["level_slabs"] >= 256 and lim["queue_slots"] == 1024 and lim["agent_orders"] == 128
+    assert lim["fill_log_rows"] >= 256 and lim["level_slabs"] >= 256 and lim["queue_slots"] == 1024 and lim["agent_orders"] in (128, 256)
     # one agent market order per resting order: more fills than the log holds is reported, not silently truncated
     book = sim.queues(0)
     asks = book[book[:, 0] == 1]
