@@ -57,6 +57,9 @@ namespace lobk {
 #ifndef LOBSIM_FEAT_PF
 #define LOBSIM_FEAT_PF 1      // step kernel: feature scalars and the ring words they name are asked for at the top of the step
 #endif
+#ifndef LOBSIM_LAZY_LDS
+#define LOBSIM_LAZY_LDS 1     // step kernel: the resync bookkeeping of the header is read with the header and parked in LDS (one trip to memory less on the steps that end a second)
+#endif
 #ifndef LOBSIM_DEDUPE_HASH
 #define LOBSIM_DEDUPE_HASH 1  // lane-parallel cancellations: duplicates are looked for exactly only when a hash test says there may be one
 #endif
@@ -193,6 +196,9 @@ struct Lds {
         struct { int64_t* rows; uint32_t n[2]; uint32_t cap; } flog;  // forward kernel (LOG): this env's fill log [2][cap][4] and the rows written per list
     };
     int32_t info_q[4];  // SimpleInfoCalculator: first quoted level and volume-weighted level sum per side of this step's action
+#if LOBSIM_LAZY_LDS
+    int64_t lz[5];      // step kernel: the header's resync bookkeeping (price ranges, count), read with the header and parked here for the once-a-second test
+#endif
     // Wave-uniform state that is touched rarely (a level opens or empties, the agent trades, an execution is counted).
     // It lives here and not in scalar registers: the replay loop would otherwise carry ~35 SGPRs through every one of
     // its merge points (copies and spills on the scalar unit, which is what bounds this kernel at 16 waves per CU).
@@ -2495,7 +2501,7 @@ SDI void run_agent_ops(Lds& L, Scal& S, const DevCfg& C) {
 // on its own, lobsim_forward: the simulator has no notion of a step size or of the env's microprice).
 SDI void advance_one_step(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, int stream_id, int64_t& cursor, int64_t& now_us,
                          Ranges& R, int& n_resyncs, double& price, bool with_ops, const MsgBatch& first, int64_t n_msgs, uint64_t ce_first = 0, bool have_ce = false,
-                         EnvHdr* lazy = nullptr, int64_t until_us = -1) {
+                         EnvHdr* lazy = nullptr, int64_t until_us = -1, bool lazy_parked = false) {
     if (with_ops) run_agent_ops(L, S, C);
     int64_t until = until_us >= 0 ? until_us : now_us + CFG_STEP_US(C);
     if (stream_id >= 0 && !S.status) replay_messages(L, S, P.streams[stream_id], cursor, until, first, ce_first, have_ce);
@@ -2519,6 +2525,13 @@ SDI void advance_one_step(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, in
         // (`lazy`, the step kernel: the price ranges and the resync count are read from the header here, once a second, and
         // written back at once.  Carried through the whole step in scalar registers, those ten registers pushed the
         // allocator over a cliff: 1009 instead of 417 spill reloads in the kernel, +24 % VALU instructions per step.)
+#if LOBSIM_LAZY_LDS
+        if (lazy && lazy_parked) {  // (the step kernel parked them in LDS with the header: no trip to memory here)
+            R.min_buy = __longlong_as_double(uni64(L.lz[0])); R.max_sell = __longlong_as_double(uni64(L.lz[1]));
+            R.init_buy = __longlong_as_double(uni64(L.lz[2])); R.init_sell = __longlong_as_double(uni64(L.lz[3]));
+            n_resyncs = (int)uni64(L.lz[4]);
+        } else
+#endif
         if (lazy) {
             R.min_buy = rld(lazy->min_buy, 0); R.max_sell = rld(lazy->max_sell, 0);
             R.init_buy = rld(lazy->init_buy_range, 0); R.init_sell = rld(lazy->init_sell_range, 0);
@@ -2613,6 +2626,10 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
     const int fkind = C.c.features[lf].kind, flb = C.c.features[lf].lookback, froff = C.ring_off[lf];
     const FeatState& g0 = P.feat[(size_t)env * LOBSIM_MAX_FEATURES + lf];
     const int fcount = g0.count, fpos = g0.pos;
+#if LOBSIM_LAZY_LDS
+    // (lanes 0..3: the four price-range doubles, lane 4: the resync count - the header's lines are on their way anyway)
+    const int64_t lzv = ln == 4 ? (int64_t)H.n_resyncs : reinterpret_cast<const int64_t*>(&H.min_buy)[ln & 3];
+#endif
     const EnvRegs er = load_env_issue(S, P, env, hr);
     const int32_t desired = beta_volumes(L, C, act, bl);  // needs the action only
     load_env_commit(L, S, P, env, hr, er);
@@ -2646,13 +2663,16 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
         const double p0 = price;
         build_agent_ops(L, S, C, act, desired, A.info != nullptr);  // convert_action_to_orders on the pre-step state
         if (ln < F) { L.rstash[ln][0] = rw0; L.rstash[ln][1] = rw1; }
+#if LOBSIM_LAZY_LDS
+        if (ln < 5) L.lz[ln] = lzv;
+#endif
         STAMP(2);
 #ifdef LOBSIM_PROFILE
         if (!S.status) run_agent_ops(L, S, C);
         STAMP(3);
-        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, false, first, n_msgs0, ce_first, have_ce, &H);
+        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, false, first, n_msgs0, ce_first, have_ce, &H, -1, LOBSIM_LAZY_LDS != 0);
 #else
-        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true, first, n_msgs0, ce_first, have_ce, &H);
+        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true, first, n_msgs0, ce_first, have_ce, &H, -1, LOBSIM_LAZY_LDS != 0);
 #endif
         STAMP(4);
         SUBSTAMP(7);

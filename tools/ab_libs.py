@@ -30,7 +30,7 @@ for arg in sys.argv[1:]:
 obs = torch.zeros((N, 16), dtype=torch.float64, device=dev)
 reward = torch.zeros(N, dtype=torch.float64, device=dev); done = torch.zeros(N, dtype=torch.uint8, device=dev)
 steps_taken = torch.zeros(N, dtype=torch.int32, device=dev)
-for rep in range(3):
+for rep in range(int(os.environ.get("AB_REPS", 3))):
     for name, sim in sims.items():
         tt = 20 * rep
         for i in range(5): sim.step_device(acts[(tt + i) % K].data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr(), 0)
