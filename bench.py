@@ -580,7 +580,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "int64+f64", "data": "synthetic",
             "config": {
                 "workload": WORKLOADS[wl], "envs_per_gpu": N, "global_envs": world * N, "features": "full_state (10 default features, 5 min warm-up)",
-                "step_size_s": 0.1, "reward": "AD" if wl == "ad" else "PnL", "messages_per_env_step": round(m_bar, 2), "parallelism": f"env-sharded x{world}",
+                "step_size_s": 0.1, "reward": "AD" if wl == "ad" else "PnL", "messages_per_env_step": round(m_bar, 2), "messages_per_s": round(world * N * K / elapsed * m_bar), "parallelism": f"env-sharded x{world}",
                 "reset_seconds": round(reset_s, 3), "envs_in_error_state_sampled": int(st_bad), "nan_returns": n_bad,
                 "ranks": world, "ms_per_step_per_rank": [round(x, 5) for x in per_rank_ms], "gathered_returns": int(all_returns.numel()),
             },
