@@ -2584,6 +2584,9 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
     uint64_t prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     STAMP(0);
+#ifdef LOBSIM_PROFILE_SKEW
+    const uint64_t skew_t0 = __builtin_amdgcn_s_memrealtime();  // (100 MHz, one clock for the whole device: when was this wave dispatched?)
+#endif
     Scal S;
 #ifdef LOBSIM_PROFILE
     S.ev_chunks = S.ev_compact = S.ev_ladder = S.ev_exec_levels = S.ev_rare = S.ev_serial_ops = 0;
@@ -2736,6 +2739,15 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
     }
 #ifdef LOBSIM_PROFILE
     STAMP(6);
+#ifdef LOBSIM_PROFILE_SKEW
+    if (ln == 0 && P.prof) {  // tools/dispatch_skew.py: start / end on the device-wide clock, where the wave ran, its cycles
+        __builtin_amdgcn_s_waitcnt(0);
+        P.prof[(size_t)env * 8 + 0] = skew_t0;
+        P.prof[(size_t)env * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+        P.prof[(size_t)env * 8 + 2] = (uint64_t)__builtin_amdgcn_s_getreg(63492) | ((uint64_t)__builtin_amdgcn_s_getreg(63508) << 32);  // HW_ID | XCC_ID << 32
+        P.prof[(size_t)env * 8 + 3] = prof_t[6] - prof_t[0];
+    }
+#else
     if (ln == 0 && P.prof) {
         for (int k = 0; k < 6; k++) P.prof[(size_t)env * 8 + k] += prof_t[k + 1] - prof_t[k];
         P.prof[(size_t)env * 8 + 6] += S.n_ops;
@@ -2750,6 +2762,7 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
         for (int k = 0; k < 8; k++) { pm[k] += S.pm_cycles[k]; pm[8 + k] += S.pm_count[k]; }  // (in the place of the event counts)
 #endif
     }
+#endif
 #endif
 }
 
