@@ -43,6 +43,12 @@ for t in range(K):
     rows.append(dict(launch=en.max(), start_p50=np.median(st), start_p99=np.percentile(st, 99), start_max=st.max(), last_start=st[last], last_dur=en[last] - st[last],
                      dur_max=(en - st).max(), dur_mean=(en - st).mean(), simd_used=len(per_simd), simd_max=per_simd.max(), cu_used=len(per_cu), cu_max=per_cu.max(), cu_min=per_cu.min(),
                      order_corr=np.corrcoef(np.arange(N), st)[0, 1], xccs=len(np.unique(xcc))))
+    # does a wave run longer when its SIMD-mates are heavy?  (duration of the other waves of the same SIMD, for all waves and for the longest 1 %)
+    dur = en - st
+    simd_sum = np.bincount(place, weights=dur)[place]
+    mates = (simd_sum - dur) / np.maximum(np.bincount(place)[place] - 1, 1)
+    top = dur >= np.percentile(dur, 99)
+    rows[-1].update(mates_all=mates.mean(), mates_top=mates[top].mean(), corr_mates=np.corrcoef(dur, mates)[0, 1], simd_sum_max=simd_sum.max(), simd_sum_mean=simd_sum.mean())
     if t == 20:
         print("first measured launch: start time (us) of env 0, 1, 2, 3, 255, 256, 1023, 1024, 4095:", np.round(st[[0, 1, 2, 3, 255, 256, 1023, 1024, N - 1]], 2).tolist())
         print("  xcc of env 0..15:", xcc[:16].tolist(), " cu:", cu[:16].tolist(), " simd:", simd[:16].tolist())
@@ -50,3 +56,4 @@ A = lambda k: np.array([r[k] for r in rows], dtype=np.float64)
 print(f"{N} envs, {len(rows)} launches (us): launch (first start -> last end) {A('launch').mean():.2f}; wave start p50 {A('start_p50').mean():.2f} p99 {A('start_p99').mean():.2f} max {A('start_max').mean():.2f}")
 print(f"  the wave that ends last: starts at {A('last_start').mean():.2f}, runs {A('last_dur').mean():.2f}; longest wave {A('dur_max').mean():.2f}, mean wave {A('dur_mean').mean():.2f}")
 print(f"  placement: {A('xccs').mean():.0f} XCCs, {A('cu_used').mean():.0f} CUs used, waves per CU {A('cu_min').mean():.1f} .. {A('cu_max').mean():.1f}, SIMDs used {A('simd_used').mean():.0f}, most waves on one SIMD {A('simd_max').mean():.1f}; corr(env index, start time) {A('order_corr').mean():.2f}")
+print(f"  SIMD-mates: mean duration of the other waves on a wave's SIMD {A('mates_all').mean():.2f} us over all waves, {A('mates_top').mean():.2f} us for the longest 1 % of waves; corr(duration, mates' mean duration) {A('corr_mates').mean():.2f}; wave-time per SIMD mean {A('simd_sum_mean').mean():.1f} us, busiest SIMD {A('simd_sum_max').mean():.1f} us")
