@@ -3,7 +3,7 @@ the HIP library against the CPU oracle, EVERY env compared every `chunk` steps (
 observations to 1e-12, the fill counters and resync counts at the end).  The suite's full-size test covers 300 steps; this
 covers minutes of market time, per-step launches and multi-step launches alternating, so that rare paths (compactions of
 deep queues, position-cache aliasing, outer-level resyncs, far levels) get thousands of chances.
-usage: python tests/diag/soak.py [steps=6000] [chunk=250] [envs=4096]"""
+usage: python tests/diag/soak.py [steps=6000] [chunk=250] [envs=4096] [workload=random|ad|deep50]"""
 import sys
 from pathlib import Path
 
@@ -20,15 +20,17 @@ from rl4mm_amd import _capi, _lib
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 6000
 chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 250
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
-cfg = _capi.make_cfg(n, 10, bench.default_features(_capi), step_us=100_000, episode_us=(steps + 10) * 100_000)
-stream = bench.build_stream(steps // 10 + 20)
+wl = sys.argv[4] if len(sys.argv) > 4 else "random"
+cfg = bench.workload_cfg(_capi, wl, n)  # (the bench's configuration of that workload; its episode is the 30 min default)
+streams = bench.build_streams(wl, steps // 10 + 20)
 rng = np.random.Generator(np.random.PCG64(4242))
-starts = (36_000 + rng.integers(0, 60, size=n)) * 1_000_000
+starts, sids = bench.workload_starts(wl, n, len(streams), 4242)
 gpu, cpu = _lib.new_sim(cfg), ol.oracle_sim(cfg)
 for s in (gpu, cpu):
-    s.add_stream(stream)
+    for st in streams:
+        s.add_stream(st)
     s.set_portfolio(0, 10**12)
-o_g, o_c = gpu.reset(starts, 0), cpu.reset(starts, 0)
+o_g, o_c = gpu.reset(starts, sids), cpu.reset(starts, sids)
 assert np.allclose(o_g, o_c, rtol=1e-12, atol=1e-9)
 dev = torch.device("cuda", 0)
 D = gpu.obs_dim
@@ -66,4 +68,4 @@ for e in range(n):
     n_res += sg["n_resyncs"]
 for e in (0, n // 3, n - 1):
     assert np.array_equal(gpu.queues(e), cpu.queues(e)), f"env {e}: per-order book contents differ"
-print(f"soak ok: {n} envs x {steps} steps, every env equal to the oracle at every chunk boundary; {n_res} outer-level resyncs in total; high water (orders at one price, live agent orders, buy levels, sell levels) {ol.oracle_high_water(cpu).max(axis=0).tolist()}")
+print(f"soak ok ({wl}): {n} envs x {steps} steps, every env equal to the oracle at every chunk boundary; {n_res} outer-level resyncs in total; high water (orders at one price, live agent orders, buy levels, sell levels) {ol.oracle_high_water(cpu).max(axis=0).tolist()}")
