@@ -3,7 +3,7 @@ the HIP library against the CPU oracle, EVERY env compared every `chunk` steps (
 observations to 1e-12, the fill counters and resync counts at the end).  The suite's full-size test covers 300 steps; this
 covers minutes of market time, per-step launches and multi-step launches alternating, so that rare paths (compactions of
 deep queues, position-cache aliasing, outer-level resyncs, far levels) get thousands of chances.
-usage: python tests/diag/soak.py [steps=6000] [chunk=250] [envs=4096] [workload=random|ad|deep50]"""
+usage: python tests/diag/soak.py [steps=6000] [chunk=250] [envs=4096] [workload=random|ad|deep50|teradactyl]"""
 import sys
 from pathlib import Path
 
@@ -40,16 +40,19 @@ done = torch.zeros(n, dtype=torch.uint8, device=dev)
 ret = torch.zeros(n, dtype=torch.float64, device=dev)
 taken = torch.zeros(n, dtype=torch.int32, device=dev)
 ret_c = np.zeros(n)
+tera = wl == "teradactyl"  # (the rule-based agent on the device: its action is worked out from the env's own observation, so a difference compounds)
+policy, params = (_capi.POLICY_TERADACTYL, bench.TERADACTYL_PARAMS) if tera else (_capi.POLICY_GIVEN, [])
 for c in range(steps // chunk):
-    acts = rng.uniform(0, 10, size=(chunk, n, 4))
-    d_acts = torch.from_numpy(acts).to(dev)
+    acts = None if tera else rng.uniform(0, 10, size=(chunk, n, 4))
+    d_acts = None if tera else torch.from_numpy(acts).to(dev)
     if c % 2 == 0:  # per-step launches
         for t in range(chunk):
-            gpu.step_device(d_acts[t].data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr(), ret.data_ptr())
+            if tera: gpu.rollout_device(policy, params, 1, 0, 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr(), ret.data_ptr(), 0)
+            else: gpu.step_device(d_acts[t].data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr(), ret.data_ptr())
     else:  # one multi-step launch
-        gpu.rollout_device(_capi.POLICY_GIVEN, [], chunk, d_acts.data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr(), ret.data_ptr(), taken.data_ptr())
+        gpu.rollout_device(policy, params, chunk, 0 if tera else d_acts.data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr(), ret.data_ptr(), taken.data_ptr())
     gpu.sync()
-    out = ol.oracle_rollout(cpu, _capi.POLICY_GIVEN, [], chunk, acts, want_actions=False)
+    out = ol.oracle_rollout(cpu, policy, params, chunk, acts, want_actions=False)
     ret_c += out["ret"]
     for a, b, what in zip(gpu.portfolios(), cpu.portfolios(), ("inventory", "cash", "price")):
         assert np.array_equal(a, b), f"chunk {c}: {what} differs in envs {np.nonzero(a != b)[0][:8]}"
