@@ -21,8 +21,19 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 6000
 chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 250
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 wl = sys.argv[4] if len(sys.argv) > 4 else "random"
-cfg = bench.workload_cfg(_capi, wl, n)  # (the bench's configuration of that workload; its episode is the 30 min default)
-streams = bench.build_streams(wl, steps // 10 + 20)
+import os
+
+# SOAK_LADDER=128: the 128-level kernels on a book that would fit 64; SOAK_STEP_US=50000: another step size (the generic, not the
+# specialised kernels; the default features allow any step <= 0.1 s, HistoricalOrderbookEnvironment.py:398)
+step_us = int(os.environ.get("SOAK_STEP_US", 100_000))
+cfg = bench.workload_cfg(_capi, wl, n, ladder_levels=int(os.environ.get("SOAK_LADDER", 0)))  # (the bench's configuration of that workload; its episode is the 30 min default)
+if step_us != 100_000:
+    kw = dict(step_us=step_us, episode_us=bench.EPISODE_US, ladder_levels=int(os.environ.get("SOAK_LADDER", 0)))
+    feats = bench.default_features(_capi)
+    for k in (0, 5, 6): feats[k].update_us = step_us  # Spread, Inventory, EpisodeProportion tick with the step (get_default_features(step_size))
+    feats[6].dparam = step_us / bench.EPISODE_US
+    cfg = _capi.make_cfg(n, 10, feats, **kw)
+streams = bench.build_streams(wl, steps * step_us // 1_000_000 + 20)
 rng = np.random.Generator(np.random.PCG64(4242))
 starts, sids = bench.workload_starts(wl, n, len(streams), 4242)
 gpu, cpu = _lib.new_sim(cfg), ol.oracle_sim(cfg)
