@@ -60,6 +60,9 @@ namespace lobk {
 #ifndef LOBSIM_LAZY_LDS
 #define LOBSIM_LAZY_LDS 1     // step kernel: the resync bookkeeping of the header is read with the header and parked in LDS (one trip to memory less on the steps that end a second)
 #endif
+#ifndef LOBSIM_PASS_NO_REM
+#define LOBSIM_PASS_NO_REM 1  // lane-parallel pass: a segment without removals books its appends and returns - no slot load to wait for
+#endif
 #ifndef LOBSIM_DEDUPE_HASH
 #define LOBSIM_DEDUPE_HASH 1  // lane-parallel cancellations: duplicates are looked for exactly only when a hash test says there may be one
 #endif
@@ -1741,27 +1744,36 @@ SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt,
     const int cslab = (int)((ce >> 16) & 0xffff), cpos = (int)(ce & 0xffff);
     // (range check against the level's meta word as it is BEFORE this segment's appends: they only move the tail up)
     bool rem = is_rem && ln < seg_end && li >= 0 && (uint32_t)(ce >> 32) == idc_tag(b.eid) && cslab == m_slab(m) && cpos >= m_head(m) && cpos < m_tail(m);
+#endif
+    const int key = (side << 8) | li;
+    auto book_appends = [&]() {
+        int rank = 0;
+        for (uint64_t todo = ballot(app); todo;) {  // one turn per distinct level hit
+            const int k = rl32(key, ffs64(todo));
+            const uint64_t grp = ballot(app && key == k);
+            if (app && key == k) rank = popc64(grp & below);
+            todo &= ~grp;
+        }
+        if (app) {
+            Slot w; w.id = b.eid; w.vol = (int32_t)vol64; w.kind = K_EXT;
+            const int pos = m_tail(m) + rank;
+            slot_store<2>(&S.slots[(size_t)m_slab(m) * SLOTS + pos], w);
+            idc_put(S, b.eid, m_slab(m), pos);
+            atomicAdd(reinterpret_cast<unsigned long long*>(&L.meta[side][li]), (1ull << 32) + (1ull << 48));  // tail += 1, live += 1
+            atomicAdd(&L.vol[side][li], (int32_t)vol64);
+        }
+        wsync();
+    };
+#if LOBSIM_SLOT_EARLY && LOBSIM_PASS_NO_REM
+    // a segment without a single removal the position cache can place (short segments behind a cut, mostly): no slot to wait for
+    if (!ballot(rem)) { book_appends(); return ballot(app); }
+#endif
+#if LOBSIM_SLOT_EARLY
     // (no branch around the load: the compiler would wait for it at the end of the branch, i.e. before the appends instead
     // of behind them; a lane without a removal reads slot 0 of slab 0 and ignores it)
     const Slot cs = slot_load<8>(&S.slots[rem ? (size_t)cslab * SLOTS + cpos : (size_t)0]);
 #endif
-    const int key = (side << 8) | li;
-    int rank = 0;
-    for (uint64_t todo = ballot(app); todo;) {  // one turn per distinct level hit
-        const int k = rl32(key, ffs64(todo));
-        const uint64_t grp = ballot(app && key == k);
-        if (app && key == k) rank = popc64(grp & below);
-        todo &= ~grp;
-    }
-    if (app) {
-        Slot w; w.id = b.eid; w.vol = (int32_t)vol64; w.kind = K_EXT;
-        const int pos = m_tail(m) + rank;
-        slot_store<2>(&S.slots[(size_t)m_slab(m) * SLOTS + pos], w);
-        idc_put(S, b.eid, m_slab(m), pos);
-        atomicAdd(reinterpret_cast<unsigned long long*>(&L.meta[side][li]), (1ull << 32) + (1ull << 48));  // tail += 1, live += 1
-        atomicAdd(&L.vol[side][li], (int32_t)vol64);
-    }
-    wsync();
+    book_appends();
     // ---- cancellations / deletions whose order the position cache still knows: straight to the slot, no queue scan.
     // A lane takes this path only when its entry points into the live range [head, tail) of the slab of the level its
     // price names and that slot holds exactly this external order; the first lane wins when two messages of the
