@@ -160,8 +160,8 @@ def region_summary(job_times, K):
                  "ms_per_step_regions": [round(x / K * 1e3, 5) for x in job_times]}  # fmt: skip
 
 
-def workload_cfg(capi, workload, n_envs, device_id=0, ladder_levels=0):
-    kw = dict(step_us=STEP_US, episode_us=EPISODE_US, device_id=device_id, ladder_levels=ladder_levels)
+def workload_cfg(capi, workload, n_envs, device_id=0, ladder_levels=0, agent_orders=0):
+    kw = dict(step_us=STEP_US, episode_us=EPISODE_US, device_id=device_id, ladder_levels=ladder_levels, agent_orders=agent_orders)
     if workload == "ad":  # get_reward_function("AD"), rl4mm/gym/utils.py:29-39
         kw.update(per_step_reward=(capi.R_INVENTORY_ADJUSTED, 1, 0.1), terminal_reward=(capi.R_INVENTORY_ADJUSTED, 1, 0.1))
     return capi.make_cfg(n_envs, 50 if workload == "deep50" else 10, default_features(capi), **kw)
@@ -426,6 +426,7 @@ def main():
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # CPU test of the launcher (gloo, no lobsim)
     ap.add_argument("--repeats", type=int, default=REPEATS, help="timed regions of --steps steps; `value` is the median region")
     ap.add_argument("--ladder-levels", type=int, default=0, help="price levels per side kept on chip (0 = the library's choice: 64 for books of <= 56 visible levels, else 128)")
+    ap.add_argument("--agent-orders", type=int, default=0, help="the env's table of live agent orders: 0 = the library's default (256: cannot overflow), 128 = the smaller, faster table (cfg.agent_orders)")
     ap.add_argument("--no-facade", action="store_true", help="skip the Python-boundary leg (VectorEnv.vector_step_arrays, host-pointer lobsim_step)")
     # multi-rank readiness on a ONE-GPU box (tests/test_gpu_multirank.py): every rank uses device 0; RCCL refuses two ranks on one
     # device, so the collectives of that mode run over gloo on host copies - the rank body, sharding, seeding, timing harness and
@@ -474,7 +475,7 @@ def main():
 
     sim_seconds = ((R + 1) * K + W) * STEP_US // 1_000_000 + 8  # the timed regions, the open-loop rollout leg's K more, the facade leg
     streams = shared_streams(wl, sim_seconds, rank, dist)
-    cfg = workload_cfg(_capi, wl, N, device_id=local_rank, ladder_levels=args.ladder_levels)
+    cfg = workload_cfg(_capi, wl, N, device_id=local_rank, ladder_levels=args.ladder_levels, agent_orders=args.agent_orders)
     sim = _lib.new_sim(cfg)
     # kernels run on a torch-owned (non-default) stream so the torch.cuda.Event pairs below time exactly them
     torch.cuda.set_stream(torch.cuda.Stream(device=dev))
@@ -580,7 +581,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "int64+f64", "data": "synthetic",
             "config": {
                 "workload": WORKLOADS[wl], "envs_per_gpu": N, "global_envs": world * N, "features": "full_state (10 default features, 5 min warm-up)",
-                "step_size_s": 0.1, "reward": "AD" if wl == "ad" else "PnL", "messages_per_env_step": round(m_bar, 2), "messages_per_s": round(world * N * K / elapsed * m_bar), "parallelism": f"env-sharded x{world}",
+                "agent_orders": sim.limits()["agent_orders"], "step_size_s": 0.1, "reward": "AD" if wl == "ad" else "PnL", "messages_per_env_step": round(m_bar, 2), "messages_per_s": round(world * N * K / elapsed * m_bar), "parallelism": f"env-sharded x{world}",
                 "reset_seconds": round(reset_s, 3), "envs_in_error_state_sampled": int(st_bad), "nan_returns": n_bad,
                 "ranks": world, "ms_per_step_per_rank": [round(x, 5) for x in per_rank_ms], "gathered_returns": int(all_returns.numel()),
             },

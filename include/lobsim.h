@@ -137,7 +137,12 @@ typedef struct lobsim_cfg {
                               to 128 at least and rounded up to a multiple of 32.  If the pool cannot be allocated, lobsim_create
                               retries with half (down to 128): lobsim_get_limits reports what the handle really has.  The operation
                               that needs one level more sets LOBSIM_ST_LEVEL_OVERFLOW on that env (ignored by the oracle) */
-    int32_t reserved0;
+    int32_t agent_orders;  /* the env's table of live agent orders (the reference's internal book, rl4mm/orderbook/models.py:64-69, is
+                              unbounded): 0 = 256, the size that CANNOT overflow under the reference's action interpretation for up to 18
+                              quote levels - a side quotes at most 100 + Q/2 shares (OrderDistributors.py:39-56), every share its own order
+                              at worst, plus the <= 2Q orders of the step: 2 x (100 + Q/2) + 2Q <= 256.  128 = the smaller table (2.5 KB less
+                              on-chip memory per env: 20 instead of 16 envs resident per CU, a few per cent faster); an env that outgrows
+                              it stops with LOBSIM_ST_AGENT_OVERFLOW.  lobsim_get_limits reports it (ignored by the oracle) */
     int64_t step_us;    /* step_size */
     int64_t episode_us; /* episode_length */
     int64_t warmup_us;  /* max feature window (whole seconds) */
@@ -181,7 +186,7 @@ typedef struct lobsim lobsim_t;
 /* Bumped whenever a struct of this header changes layout or an entry point changes meaning: a binding compares it with the
  * LOBSIM_ABI_VERSION it was written against before it passes a config struct: a stale prebuilt library would otherwise
  * read the struct at the wrong offsets and still produce plausible numbers. */
-#define LOBSIM_ABI_VERSION 4
+#define LOBSIM_ABI_VERSION 5
 int lobsim_abi_version(void);
 
 int lobsim_create(const lobsim_cfg* cfg, lobsim_t** out);
@@ -280,7 +285,7 @@ typedef struct lobsim_limits {
     int32_t ladder_levels;   /* levels per side kept on chip (64 / 128); a performance property, bounds nothing */
     int32_t far_levels;      /* levels per side beyond the on-chip ladder (2048) */
     int32_t queue_slots;     /* live orders + tombstones at one price (1024) */
-    int32_t agent_orders;    /* live agent orders (128) */
+    int32_t agent_orders;    /* live agent orders (cfg.agent_orders: 256 or 128) */
     int32_t fill_log_rows;   /* rows per list of the fill log of lobsim_forward */
     int64_t bytes_per_env;   /* device memory per env */
 } lobsim_limits;

@@ -14,7 +14,7 @@ import numpy as np
 
 MAX_FEATURES = 16
 MAX_ACTION_DIM = 5
-ABI_VERSION = 4  # LOBSIM_ABI_VERSION of the include/lobsim.h this file mirrors
+ABI_VERSION = 5  # LOBSIM_ABI_VERSION of the include/lobsim.h this file mirrors
 FWD_UPDATE_FEATURES = 1  # enum lobsim_forward_flags
 
 # status bits (include/lobsim.h: enum lobsim_status)
@@ -66,7 +66,7 @@ class Cfg(C.Structure):
         ("device_id", C.c_int32),
         ("ladder_levels", C.c_int32),
         ("max_levels", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("agent_orders", C.c_int32),
         ("step_us", C.c_int64),
         ("episode_us", C.c_int64),
         ("warmup_us", C.c_int64),
@@ -185,7 +185,7 @@ class LobsimError(RuntimeError):
 class Binding:
     """Function table of one shared library."""
 
-    def __init__(self, path: str, prefix: str = "lobsim_", skip: Sequence[str] = ()):
+    def __init__(self, path: str, prefix: str = "lobsim_", skip: Sequence[str] = (), check_abi: bool = True):
         self.path = str(path)
         self.prefix = prefix
         self.lib = C.CDLL(self.path)
@@ -198,7 +198,7 @@ class Binding:
             f.argtypes = args
             self.fn[name] = f
         got = self.fn["abi_version"]()
-        if got != ABI_VERSION:  # (a prebuilt library from before a struct changed would read lobsim_cfg at the wrong offsets)
+        if got != ABI_VERSION and check_abi:  # (a prebuilt library from before a struct changed would read lobsim_cfg at the wrong offsets)
             raise LobsimError(f"{self.path}: {prefix}abi_version() = {got}, this binding mirrors include/lobsim.h at version {ABI_VERSION}: rebuild the library")
 
 
@@ -227,6 +227,7 @@ def make_cfg(
     device_id: int = 0,
     ladder_levels: int = 0,
     max_levels: int = 0,
+    agent_orders: int = 0,
 ) -> Cfg:
     cfg = Cfg()
     cfg.n_envs, cfg.n_levels, cfg.tick_size, cfg.outer_levels = n_envs, n_levels, tick_size, outer_levels
@@ -255,6 +256,7 @@ def make_cfg(
     cfg.device_id = device_id
     cfg.ladder_levels = ladder_levels
     cfg.max_levels = max_levels
+    cfg.agent_orders = agent_orders
     return cfg
 
 

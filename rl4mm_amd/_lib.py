@@ -22,6 +22,9 @@ SOURCES = [CSRC / "lobsim_kernels.hip", CSRC / "lobsim_host.inc", CSRC / "lobsim
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
                "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
                "-Wno-pass-failed"]  # (the 128-level kernels are LDS-limited below their register budget's occupancy: expected)
+# The kernel file is compiled as N_PARTS translation units in parallel (-DLOBSIM_PART=k: 0 = the C-ABI host side, 1 .. 4 = the engine
+# kernels of one (on-chip ladder width, agent table) combination) and linked into one library; as one unit the 52 kernels take minutes.
+N_PARTS = 5
 
 _binding = None
 
@@ -33,6 +36,31 @@ def _stale() -> bool:
     return any(s.exists() and s.stat().st_mtime > t for s in SOURCES)
 
 
+def compile_library(out: Path, extra_flags=(), source: Path = None, verbose: bool = False, jobs: int = None) -> None:
+    """hipcc --offload-arch=gfx950: the parts of lobsim_kernels.hip -> objects (in parallel) -> one shared library at `out`."""
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc was not found: cannot build the HIP library")
+    src = (Path(source) if source else SOURCES[0]).resolve()
+    out = Path(out).resolve()
+    compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags)
+    with tempfile.TemporaryDirectory(prefix="lobsim_build_") as td:
+        objs = [Path(td) / f"part{k}.o" for k in range(N_PARTS)]
+
+        def one(k):
+            cmd = [hipcc, *compile_flags, f"-DLOBSIM_PART={k}", "-c", "-o", str(objs[k]), str(src)]
+            if verbose:
+                cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+            subprocess.check_call(cmd, cwd=str(src.parent))
+
+        with ThreadPoolExecutor(max_workers=jobs or min(N_PARTS, os.cpu_count() or 1)) as ex:
+            list(ex.map(one, range(N_PARTS)))
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", str(out), *map(str, objs)], cwd=str(src.parent))
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
     """hipcc --offload-arch=gfx950 -> liblobsim.so (in-tree, so it travels with the repo snapshot).  Safe when several
     ranks import at once: the build is serialised by a file lock and the library is replaced atomically."""
@@ -41,20 +69,14 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     import fcntl
     import tempfile
 
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        raise RuntimeError("liblobsim.so is missing or stale and hipcc was not found: cannot build the HIP library")
     with open(CSRC / ".build.lock", "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
             if force or _stale():  # another process may have built it while we waited
                 fd, tmp = tempfile.mkstemp(suffix=".so", dir=str(CSRC))
                 os.close(fd)
-                cmd = [hipcc, *HIPCC_FLAGS, "-o", tmp, str(SOURCES[0])]
-                if verbose:
-                    cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
                 try:
-                    subprocess.check_call(cmd, cwd=str(CSRC))
+                    compile_library(Path(tmp), verbose=verbose)
                     os.replace(tmp, LIB_PATH)
                 finally:
                     if os.path.exists(tmp):

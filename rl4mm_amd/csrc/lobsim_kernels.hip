@@ -23,6 +23,19 @@
 
 #include "lobsim_layout.h"
 
+// Parts of the build (rl4mm_amd/_lib.py compiles them in parallel and links them into one library): LOBSIM_PART 0 = the C-ABI host
+// side + the small gather kernels, 1 .. 4 = the engine kernels of one (on-chip ladder width, agent table) combination.  Undefined:
+// everything in this one translation unit.
+#ifndef LOBSIM_PART
+#define LOBSIM_BUILD_HOST 1
+#define LOBSIM_BUILD_ENG(lvt, na) 1
+#define LOBSIM_BUILD_ANY_ENGINE 1
+#else
+#define LOBSIM_BUILD_HOST (LOBSIM_PART == 0)
+#define LOBSIM_BUILD_ENG(lvt, na) (LOBSIM_PART == ((lvt) == 64 ? 1 : 2) + ((na) == 128 ? 0 : 2))
+#define LOBSIM_BUILD_ANY_ENGINE (LOBSIM_PART != 0)
+#endif
+
 namespace lobk {
 
 #define DI __device__ __forceinline__
@@ -149,6 +162,7 @@ struct ForwardArgs {  // lobsim_forward: OrderbookSimulator.forward_step for the
     int32_t flog_cap;
 };
 
+#if LOBSIM_BUILD_ANY_ENGINE
 typedef long long ll2_t __attribute__((ext_vector_type(2)));
 struct alignas(16) I64x2 { int64_t x, y; };
 
@@ -161,10 +175,14 @@ struct alignas(16) I64x2 { int64_t x, y; };
 // that).  Measured +3 % per step; every other configuration reads the same values from the kernel arguments.
 // LOG = the simulator-level kernels (lobsim_forward): every fill is written to a per-env fill log, the FilledOrders lists that
 // OrderbookSimulator.forward_step returns (OrderbookSimulator.py:70-88).  A separate instantiation: the env-step kernels carry none of it.
-template <int LVT, bool SPEC = false, bool LOG = false>
+// NAT = agent entries per env (128 or 256, cfg.agent_orders: lobsim_layout.h), NAT / 64 per lane.
+template <int LVT, bool SPEC = false, bool LOG = false, int NAT = 128>
 struct Eng {
+static_assert(NAT % 64 == 0 && NAT >= 128 && NAT <= NA_MAX, "agent entries: whole lanes' worth, the index travels in 8 bits of an op code");
 static constexpr int LV = LVT;
 static constexpr int HALVES = LVT / 64;  // ladder entries per lane
+static constexpr int NA = NAT;
+static constexpr int OPS_MAX = na_ops_max(NAT);
 static constexpr int AE = NA / 64;       // agent entries per lane = words of the free masks
 #define CFG_Q(C) (SPEC ? 10 : (C).Q)
 #define CFG_TICK(C) (SPEC ? 100 : (C).c.tick_size)
@@ -1232,7 +1250,10 @@ SDI int32_t beta_volumes(Lds& L, const DevCfg& C, const Act5& action, const Beta
     return desired;
 }
 
-SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, int32_t desired, bool want_info = false) {
+// R = agent entries per lane this pass looks at: all of them (AE), or - the table of 256 whose upper half holds no live order, which
+// is its usual state: entries are handed out lowest-first - only the first two (the registers and instructions of the 128-entry build).
+template <int R>
+SDI void build_agent_ops_r(Lds& L, Scal& S, const DevCfg& C, const Act5& action, int32_t desired, bool want_info) {
     const lobsim_cfg& c = C.c;
     const int Q = CFG_Q(C), ln = lane();
     const int64_t tick = CFG_TICK(C);
@@ -1264,9 +1285,9 @@ SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, i
     SUBSTAMP(3);
     // ---- current agent volume per quoted level (_get_current_internal_order_volumes, :291-296); each agent entry
     // finds its quote level (or "wide")
-    int ek[AE];
+    int ek[R];
 #pragma unroll
-    for (int r = 0; r < AE; r++) {
+    for (int r = 0; r < R; r++) {
         AgentOrd o = L.agent[ln + 64 * r];
         ek[r] = -2;  // free entry
         if (o.vol > 0) {
@@ -1294,11 +1315,11 @@ SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, i
     // a level with diff < 0 is cancelled from its NEWEST order backwards (:240-249), an order at a price no longer
     // quoted is cancelled in full (:250-257).  Within one side the order of ops at different prices is unobservable
     // (no crossing is possible among them); buy ops stay before sell ops and the clearing order stays last.
-    AgentOrd ao[AE];
-    int32_t need[AE], newer[AE], code[AE];
-    bool cand[AE];
+    AgentOrd ao[R];
+    int32_t need[R], newer[R], code[R];
+    bool cand[R];
 #pragma unroll
-    for (int r = 0; r < AE; r++) {
+    for (int r = 0; r < R; r++) {
         ao[r] = L.agent[ln + 64 * r];
         newer[r] = 0;
         const int sd = (int)(ao[r].seq_side >> 31);
@@ -1311,18 +1332,18 @@ SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, i
         // its level's list in LDS (the op list's storage, not yet written; counters in the pdf storage, already
         // consumed), then reads its own level's list: a handful of entries per lane instead of one wave-wide
         // broadcast turn per candidate.  A level with more candidates than a list holds takes the broadcast loop.
-        uint32_t q[AE];
+        uint32_t q[R];
 #pragma unroll
-        for (int r = 0; r < AE; r++) q[r] = ao[r].seq_side & 0x7fffffffu;
+        for (int r = 0; r < R; r++) q[r] = ao[r].seq_side & 0x7fffffffu;
         int32_t* cntr = reinterpret_cast<int32_t*>(pdf_area(L));
         unsigned long long* lists = reinterpret_cast<unsigned long long*>(&L.ops[0]);
         const int cap = (OPS_MAX - 64) / (2 * Q);  // (the lists stop in front of the counters)
         if (ln < 2 * Q) cntr[ln] = 0;
         wsync();
-        int lvl[AE], at[AE];
+        int lvl[R], at[R];
         bool over = false;
 #pragma unroll
-        for (int r = 0; r < AE; r++) {
+        for (int r = 0; r < R; r++) {
             lvl[r] = (code[r] >> 8) * Q + (code[r] & 0xff);
             at[r] = 0;
             if (cand[r]) {
@@ -1335,7 +1356,7 @@ SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, i
         const bool overflow = ballot(over) != 0;
         if (!overflow) {
 #pragma unroll
-            for (int r = 0; r < AE; r++) {
+            for (int r = 0; r < R; r++) {
                 if (!cand[r]) continue;
                 const int n = cntr[lvl[r]];
                 const uint32_t mine = q[r];
@@ -1347,7 +1368,7 @@ SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, i
         }
         wsync();
 #pragma unroll
-        for (int r = 0; r < AE && overflow; r++) {  // broadcast every candidate once: volume of same-level orders newer than mine
+        for (int r = 0; r < R && overflow; r++) {  // broadcast every candidate once: volume of same-level orders newer than mine
             uint64_t bb = ballot(cand[r]);
             while (bb) {
                 const int t = ffs64(bb);
@@ -1356,14 +1377,14 @@ SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, i
                 const uint32_t tq = (uint32_t)rl32((int32_t)q[r], t);
                 const int32_t tv = rl32(ao[r].vol, t);
 #pragma unroll
-                for (int k = 0; k < AE; k++) newer[k] += (tc == code[k] && tq > q[k]) ? tv : 0;
+                for (int k = 0; k < R; k++) newer[k] += (tc == code[k] && tq > q[k]) ? tv : 0;
             }
         }
     }
     SUBSTAMP(5);
-    int32_t cvol[AE];
+    int32_t cvol[R];
 #pragma unroll
-    for (int r = 0; r < AE; r++) {
+    for (int r = 0; r < R; r++) {
         cvol[r] = 0;
         if (cand[r] && need[r] > newer[r]) cvol[r] = min(ao[r].vol, need[r] - newer[r]);
         if (ek[r] == -1) cvol[r] = ao[r].vol;  // wide
@@ -1376,7 +1397,7 @@ SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, i
         if (lim) { const int at = base + popc64(lm & below); if (at < OPS_MAX) { Op8 op; op.vol = diff; op.code = LOBSIM_LIMIT | (side << 4) | (my_k << 8); L.ops[at] = op; } }
         base += popc64(lm);
 #pragma unroll
-        for (int r = 0; r < AE; r++) {
+        for (int r = 0; r < R; r++) {
             const bool cn = cvol[r] > 0 && (int)(ao[r].seq_side >> 31) == side;
             const uint64_t cm = ballot(cn);
             if (cn) { const int at = base + popc64(cm & below); if (at < OPS_MAX) { Op8 op; op.vol = cvol[r]; op.code = LOBSIM_CANCELLATION | (side << 4) | ((ln + 64 * r) << 8); L.ops[at] = op; } }
@@ -1391,6 +1412,15 @@ SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, i
     if (S.n_ops > OPS_MAX) S.status |= LOBSIM_ST_AGENT_OVERFLOW;
     wsync();
     SUBSTAMP(6);
+}
+
+SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, int32_t desired, bool want_info = false) {
+    if constexpr (AE > 2) {
+        static_assert(AE == 4, "the upper half of the agent table = words 2 and 3 of its free mask");
+        const bool upper_free = (lds_u64(L.agent_free[2]) & lds_u64(L.agent_free[3])) == ~0ull;  // (an entry freed in this step keeps its bit clear until the step ends: conservative)
+        if (UNLIKELY(!upper_free)) { build_agent_ops_r<AE>(L, S, C, action, desired, want_info); return; }
+    }
+    build_agent_ops_r<2>(L, S, C, action, desired, want_info);
 }
 
 // per-lane binary search of a price in the sorted ladder of one side; -1 if there is no such level
@@ -1482,7 +1512,8 @@ SDI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
         // (the r-th set bit of the free mask, by popcounts over its 32-bit words - a loop clearing r bits ran up to 20 turns per lane)
         int word = 0, before = 0;
         uint32_t qw = (uint32_t)fw[0];
-        if constexpr (AE == 2) {  // (the shipped build: four words, straight-line)
+        const int c01 = popc64(fw[0]) + popc64(fw[1]);
+        if (AE == 2 || R <= c01) {  // (the usual case of the larger table too: every new order finds its entry in the first two words - four 32-bit halves, straight-line)
             const uint32_t q0 = (uint32_t)fw[0], q1 = (uint32_t)(fw[0] >> 32), q2 = (uint32_t)fw[1], q3 = (uint32_t)(fw[1] >> 32);
             const int c0 = __popc(q0), c1 = c0 + __popc(q1), c2 = c1 + __popc(q2);
             word = (r >= c0) + (r >= c1) + (r >= c2);
@@ -1650,24 +1681,41 @@ SDI void resync_outer_levels(Lds& L, Scal& S, const DevCfg& C, const StreamDev& 
                     pm &= pm - 1;
                     int64_t price = rl64(p, j);
                     int32_t vol = (int32_t)rl64(v, j);
-                    // agent orders at this level: cancel them now, re-submit them at the back afterwards (:114-129)
-                    for (int r = 0; r < AE && !S.status; r++) {
-                        AgentOrd o = L.agent[ln + 64 * r];
-                        bool hit = o.vol > 0 && (int)(o.seq_side >> 31) == side && o.price == price;
-                        uint64_t hm = ballot(hit);
-                        // process in submission order
-                        while (hm && !S.status) {
-                            uint32_t myq = hit ? (o.seq_side & 0x7fffffffu) : 0xffffffffu;
-                            // lane holding the smallest seq among remaining hits
-                            uint32_t best = 0xffffffffu; int bl = -1;
-                            uint64_t t = hm;
-                            while (t) { int b = ffs64(t); t &= t - 1; uint32_t q = (uint32_t)rl32((int32_t)myq, b); if (q < best) { best = q; bl = b; } }
-                            hm &= ~(1ull << bl);
-                            int32_t ov = rl32(o.vol, bl);
-                            int aidx = bl + 64 * r;
-                            if (ln == 0 && n_readd < OPS_MAX) { Op8 op; op.vol = ov; op.code = LOBSIM_LIMIT | (side << 4) | (1 << 5) | (aidx << 8); L.ops[n_readd] = op; }
-                            n_readd++;
-                            remove_order(L, S, side, price, K_AGENT, aidx, ov);
+                    // agent orders at this level: cancel them now, re-submit them at the back afterwards (:114-129), both in the order
+                    // of the internal book's deque at this price = submission order over ALL of the agent's entries (an entry's index
+                    // says nothing about its age once entries have been freed and reused): every hit ranks itself among the hits
+                    // and writes its re-add op at that place of the list, the cancellations then walk the list
+                    {
+                        bool hit[AE]; uint32_t q[AE]; int32_t ov[AE]; int rank[AE]; uint64_t hm[AE];
+                        int total = 0;
+#pragma unroll
+                        for (int r = 0; r < AE; r++) {
+                            const AgentOrd o = L.agent[ln + 64 * r];
+                            hit[r] = o.vol > 0 && (int)(o.seq_side >> 31) == side && o.price == price;
+                            q[r] = o.seq_side & 0x7fffffffu; ov[r] = o.vol; rank[r] = 0;
+                            hm[r] = ballot(hit[r]);
+                            total += popc64(hm[r]);
+                        }
+                        if (total) {
+#pragma unroll
+                            for (int r2 = 0; r2 < AE; r2++)
+                                for (uint64_t t = hm[r2]; t; t &= t - 1) {
+                                    const uint32_t tq = (uint32_t)rl32((int32_t)q[r2], ffs64(t));
+#pragma unroll
+                                    for (int r = 0; r < AE; r++) rank[r] += tq < q[r] ? 1 : 0;
+                                }
+#pragma unroll
+                            for (int r = 0; r < AE; r++)
+                                if (hit[r] && n_readd + rank[r] < OPS_MAX) {
+                                    Op8 op; op.vol = ov[r]; op.code = LOBSIM_LIMIT | (side << 4) | (1 << 5) | ((ln + 64 * r) << 8);
+                                    L.ops[n_readd + rank[r]] = op;
+                                }
+                            wsync();
+                            for (int k = 0; k < total && n_readd + k < OPS_MAX && !S.status; k++) {
+                                const int32_t code = uni(L.ops[n_readd + k].code), cv = uni(L.ops[n_readd + k].vol);
+                                remove_order(L, S, side, price, K_AGENT, code >> 8, cv);
+                            }
+                            n_readd += total;
                         }
                     }
                     if (!S.status) set_level_to_snapshot(L, S, side, price, vol);
@@ -2345,8 +2393,8 @@ SDI void write_info(const Lds& L, const Scal& S, const DevCfg& C, EnvHdr& H, con
 // ---------------------------------------------------------------------------------------------------------------
 struct EnvRegs {  // the env state between its loads and its LDS stores
     int64_t pb, psl; uint64_t mb, ms; int32_t vb, vs;
-    AgentOrd a[NA / 64];
-    uint16_t q[NA / 64];
+    AgentOrd a[2];  // the first 128 agent entries; the upper half of a 256-entry table (no live entry there, as a rule) is fetched
+    uint16_t q[2];  // by load_env_commit itself when it has one: no registers held for it across the prologue
 };
 
 // What load_env needs of the header, read as one cluster of scalar loads (one wait) by whoever knows the header address
@@ -2389,7 +2437,7 @@ SDI EnvRegs load_env_issue(Scal& S, const DevPtrs& P, int env, const HdrRegs& H)
     EnvRegs r;
     r.pb = pb; r.psl = psl; r.mb = mb; r.ms = ms; r.vb = vb; r.vs = vs;
 #pragma unroll
-    for (int k = 0; k < AE; k++) {  // (live entries only; a word with no live entry at all - the usual state of the upper ones - costs no load)
+    for (int k = 0; k < 2; k++) {  // (live entries only; a word with no live entry at all - the usual state of the second one - costs no load)
         r.a[k].price = 0; r.a[k].vol = 0; r.a[k].seq_side = 0; r.q[k] = 0;
         const uint64_t af = H.af[k];
         if ((k == 0 || af != ~0ull) && !((af >> ln) & 1)) { r.a[k] = A[ln + 64 * k]; r.q[k] = AP[ln + 64 * k]; }
@@ -2404,7 +2452,15 @@ SDI void load_env_commit(Lds& L, Scal& S, const DevPtrs& P, int env, const HdrRe
     if (hb) { L.price[0][ln] = r.pb; L.meta[0][ln] = r.mb; L.vol[0][ln] = r.vb; }
     if (hs) { L.price[1][ln] = r.psl; L.meta[1][ln] = r.ms; L.vol[1][ln] = r.vs; }
 #pragma unroll
-    for (int k = 0; k < AE; k++) { L.agent[ln + 64 * k] = r.a[k]; L.apos[ln + 64 * k] = r.q[k]; }
+    for (int k = 0; k < 2; k++) { L.agent[ln + 64 * k] = r.a[k]; L.apos[ln + 64 * k] = r.q[k]; }
+#pragma unroll
+    for (int k = 2; k < AE; k++) {  // the upper half of the larger table: zeros, unless it holds live orders (a round trip of its own, then)
+        AgentOrd o; o.price = 0; o.vol = 0; o.seq_side = 0;
+        uint16_t q = 0;
+        const uint64_t af = H.af[k];
+        if (UNLIKELY(af != ~0ull) && !((af >> ln) & 1)) { o = (P.agent + (size_t)env * NA)[ln + 64 * k]; q = (P.apos + (size_t)env * NA)[ln + 64 * k]; }
+        L.agent[ln + 64 * k] = o; L.apos[ln + 64 * k] = q;
+    }
 #pragma unroll
     for (int s = 0; s < 2; s++)
         for (int i = ln + 64; i < S.n_lv[s]; i += 64) {
@@ -3198,7 +3254,7 @@ SDI void features_reset_body(const DevCfg& C, const DevPtrs& P, const int32_t* e
 
 };  // struct Eng
 
-// kernels: one wave per env; LVT selects the LDS ladder capacity (lobsim_host.inc picks it per handle)
+// kernels: one wave per env; LVT selects the LDS ladder capacity, NAT the agent-order table (lobsim_host.inc picks both per handle)
 #ifndef LOBSIM_STEP_WAVES
 #define LOBSIM_STEP_WAVES 5  // waves per SIMD the step kernel is register-budgeted for.  Measured (tools/ab_libs.py, w4 / w5): the 80-VGPR
                              // build that a budget of 5 gives is as fast per wave as the 126-VGPR one (4096 envs: 108.5 vs 106.7 M
@@ -3213,25 +3269,103 @@ SDI void features_reset_body(const DevCfg& C, const DevPtrs& P, const int32_t* e
 #endif
 // (the budget must be one the LDS allows - 16 envs per CU = 4 waves per SIMD with the 64-level ladder and 256 agent entries, 12 = 3 with
 // the 128-level one: asked for more, the compiler drops the constraint altogether and takes 148 registers)
-constexpr int STEP_WAVES_64 = NA == 128 ? LOBSIM_STEP_WAVES : 4, STEP_WAVES_128 = NA == 128 ? LOBSIM_STEP_WAVES_DEEP : 3;
-template <bool EXTRAS, int LVT, bool SPEC = false>
-__global__ __launch_bounds__(64, LVT == 64 ? (EXTRAS ? 4 : STEP_WAVES_64) : STEP_WAVES_128) void lob_step_kernel(DevCfg C, DevPtrs P, StepArgs A) { Eng<LVT, SPEC>::template step_body<EXTRAS>(C, P, A); }
-template <bool EXTRAS, int LVT, bool SPEC = false>
-__global__ __launch_bounds__(64, LVT == 64 ? LOBSIM_ROLLOUT_WAVES : STEP_WAVES_128) void lob_rollout_kernel(DevCfg C, DevPtrs P, RolloutArgs A) { Eng<LVT, SPEC>::template rollout_body<EXTRAS>(C, P, A); }
-template <bool EXTRAS, int LVT>
-__global__ __launch_bounds__(64, LVT == 64 ? 4 : STEP_WAVES_128) void lob_reset_kernel(DevCfg C, DevPtrs P, ResetArgs A) { Eng<LVT>::template reset_body<EXTRAS>(C, P, A); }
-template <int LVT>
-__global__ __launch_bounds__(64) void lob_set_book_kernel(DevCfg C, DevPtrs P, int env, const int64_t* row, int64_t now_us) { Eng<LVT>::set_book_body(C, P, env, row, now_us); }
-template <int LVT>
-__global__ __launch_bounds__(64) void lob_process_orders_kernel(DevCfg C, DevPtrs P, int env, const int64_t* orders, int n, int64_t* fills_out) { Eng<LVT>::process_orders_body(C, P, env, orders, n, fills_out); }
+constexpr int step_waves(int lvt, int na, bool extras) { return lvt == 64 ? (extras || na != 128 ? 4 : LOBSIM_STEP_WAVES) : (na == 128 ? LOBSIM_STEP_WAVES_DEEP : 3); }
+constexpr int other_waves(int lvt, int na) { return lvt == 64 ? 4 : (na == 128 ? LOBSIM_STEP_WAVES_DEEP : 3); }
+template <bool EXTRAS, int LVT, int NAT, bool SPEC = false>
+__global__ __launch_bounds__(64, step_waves(LVT, NAT, EXTRAS)) void lob_step_kernel(DevCfg C, DevPtrs P, StepArgs A) { Eng<LVT, SPEC, false, NAT>::template step_body<EXTRAS>(C, P, A); }
+template <bool EXTRAS, int LVT, int NAT, bool SPEC = false>
+__global__ __launch_bounds__(64, LVT == 64 ? LOBSIM_ROLLOUT_WAVES : other_waves(LVT, NAT)) void lob_rollout_kernel(DevCfg C, DevPtrs P, RolloutArgs A) { Eng<LVT, SPEC, false, NAT>::template rollout_body<EXTRAS>(C, P, A); }
+template <bool EXTRAS, int LVT, int NAT>
+__global__ __launch_bounds__(64, other_waves(LVT, NAT)) void lob_reset_kernel(DevCfg C, DevPtrs P, ResetArgs A) { Eng<LVT, false, false, NAT>::template reset_body<EXTRAS>(C, P, A); }
+template <int LVT, int NAT>
+__global__ __launch_bounds__(64) void lob_set_book_kernel(DevCfg C, DevPtrs P, int env, const int64_t* row, int64_t now_us) { Eng<LVT, false, false, NAT>::set_book_body(C, P, env, row, now_us); }
+template <int LVT, int NAT>
+__global__ __launch_bounds__(64) void lob_process_orders_kernel(DevCfg C, DevPtrs P, int env, const int64_t* orders, int n, int64_t* fills_out) { Eng<LVT, false, false, NAT>::process_orders_body(C, P, env, orders, n, fills_out); }
 
-template <int LVT>
-__global__ __launch_bounds__(64) void lob_sim_reset_kernel(DevCfg C, DevPtrs P, ResetArgs A) { Eng<LVT>::sim_reset_body(C, P, A); }
-template <int LVT>
-__global__ __launch_bounds__(64) void lob_forward_kernel(DevCfg C, DevPtrs P, ForwardArgs A) { Eng<LVT, false, true>::forward_body(C, P, A); }
-template <int LVT>
-__global__ __launch_bounds__(64) void lob_features_reset_kernel(DevCfg C, DevPtrs P, const int32_t* env_ids) { Eng<LVT>::features_reset_body(C, P, env_ids); }
+template <int LVT, int NAT>
+__global__ __launch_bounds__(64) void lob_sim_reset_kernel(DevCfg C, DevPtrs P, ResetArgs A) { Eng<LVT, false, false, NAT>::sim_reset_body(C, P, A); }
+template <int LVT, int NAT>
+__global__ __launch_bounds__(64) void lob_forward_kernel(DevCfg C, DevPtrs P, ForwardArgs A) { Eng<LVT, false, true, NAT>::forward_body(C, P, A); }
+template <int LVT, int NAT>
+__global__ __launch_bounds__(64) void lob_features_reset_kernel(DevCfg C, DevPtrs P, const int32_t* env_ids) { Eng<LVT, false, false, NAT>::features_reset_body(C, P, env_ids); }
 
+#endif  // LOBSIM_BUILD_ANY_ENGINE
+
+// What the host side needs to launch the kernels of one (ladder width, agent table) combination.  The library is built from several
+// translation units in parallel (rl4mm_amd/_lib.py: -DLOBSIM_PART=k), one per combination plus the host part; each defines the
+// launch table of its combination, the host part only sees the declarations.  Compiled without LOBSIM_PART this file is the
+// whole library in one unit (tools/build_variant.sh and the diagnostic builds do that).
+struct LaunchCtx {
+    const DevCfg* cfg; const DevPtrs* ptrs; hipStream_t stream;
+    bool spec;          // the cfg is the reference's default configuration: kernels with its constants folded (Eng<LVT, true>)
+    bool extras_step;   // RollingSharpe and / or normalisation: the EXTRAS variants of step / rollout
+    bool extras_reset;  // normalisation: the EXTRAS variant of reset
+};
+struct LaunchTable {
+    void (*step)(const LaunchCtx& x, unsigned n, const StepArgs& a);
+    void (*rollout)(const LaunchCtx& x, unsigned n, const RolloutArgs& a);
+    void (*reset)(const LaunchCtx& x, unsigned n, const ResetArgs& a);
+    void (*set_book)(const LaunchCtx& x, int env, const int64_t* row, int64_t now_us);
+    void (*process_orders)(const LaunchCtx& x, int env, const int64_t* orders, int n, int64_t* fills_out);
+    void (*sim_reset)(const LaunchCtx& x, unsigned n, const ResetArgs& a);
+    void (*forward)(const LaunchCtx& x, unsigned n, const ForwardArgs& a);
+    void (*features_reset)(const LaunchCtx& x, unsigned n, const int32_t* env_ids);
+};
+const LaunchTable* launch_table_64_128();
+const LaunchTable* launch_table_128_128();
+const LaunchTable* launch_table_64_256();
+const LaunchTable* launch_table_128_256();
+#define LOBSIM_DEFINE_LAUNCH(LVT, NAT)                                                                                                   \
+    namespace launch_##LVT##_##NAT {                                                                                                     \
+    static void step(const LaunchCtx& x, unsigned n, const StepArgs& a) {                                                                \
+        if (x.extras_step) lob_step_kernel<true, LVT, NAT><<<n, WAVE, 0, x.stream>>>(*x.cfg, *x.ptrs, a);                                 \
+        else if (x.spec) lob_step_kernel<false, LVT, NAT, true><<<n, WAVE, 0, x.stream>>>(*x.cfg, *x.ptrs, a);                            \
+        else lob_step_kernel<false, LVT, NAT><<<n, WAVE, 0, x.stream>>>(*x.cfg, *x.ptrs, a);                                              \
+    }                                                                                                                                    \
+    static void rollout(const LaunchCtx& x, unsigned n, const RolloutArgs& a) {                                                          \
+        if (x.extras_step) lob_rollout_kernel<true, LVT, NAT><<<n, WAVE, 0, x.stream>>>(*x.cfg, *x.ptrs, a);                              \
+        else if (x.spec) lob_rollout_kernel<false, LVT, NAT, true><<<n, WAVE, 0, x.stream>>>(*x.cfg, *x.ptrs, a);                         \
+        else lob_rollout_kernel<false, LVT, NAT><<<n, WAVE, 0, x.stream>>>(*x.cfg, *x.ptrs, a);                                           \
+    }                                                                                                                                    \
+    static void reset(const LaunchCtx& x, unsigned n, const ResetArgs& a) {                                                              \
+        if (x.extras_reset) lob_reset_kernel<true, LVT, NAT><<<n, WAVE, 0, x.stream>>>(*x.cfg, *x.ptrs, a);                               \
+        else lob_reset_kernel<false, LVT, NAT><<<n, WAVE, 0, x.stream>>>(*x.cfg, *x.ptrs, a);                                             \
+    }                                                                                                                                    \
+    static void set_book(const LaunchCtx& x, int env, const int64_t* row, int64_t now_us) {                                              \
+        lob_set_book_kernel<LVT, NAT><<<1, WAVE, 0, x.stream>>>(*x.cfg, *x.ptrs, env, row, now_us);                                      \
+    }                                                                                                                                    \
+    static void process_orders(const LaunchCtx& x, int env, const int64_t* orders, int n, int64_t* fills_out) {                          \
+        lob_process_orders_kernel<LVT, NAT><<<1, WAVE, 0, x.stream>>>(*x.cfg, *x.ptrs, env, orders, n, fills_out);                       \
+    }                                                                                                                                    \
+    static void sim_reset(const LaunchCtx& x, unsigned n, const ResetArgs& a) {                                                          \
+        lob_sim_reset_kernel<LVT, NAT><<<n, WAVE, 0, x.stream>>>(*x.cfg, *x.ptrs, a);                                                    \
+    }                                                                                                                                    \
+    static void forward(const LaunchCtx& x, unsigned n, const ForwardArgs& a) {                                                          \
+        lob_forward_kernel<LVT, NAT><<<n, WAVE, 0, x.stream>>>(*x.cfg, *x.ptrs, a);                                                      \
+    }                                                                                                                                    \
+    static void features_reset(const LaunchCtx& x, unsigned n, const int32_t* env_ids) {                                                 \
+        lob_features_reset_kernel<LVT, NAT><<<n, WAVE, 0, x.stream>>>(*x.cfg, *x.ptrs, env_ids);                                         \
+    }                                                                                                                                    \
+    }                                                                                                                                    \
+    const LaunchTable* launch_table_##LVT##_##NAT() {                                                                                    \
+        namespace L_ = launch_##LVT##_##NAT;                                                                                             \
+        static const LaunchTable t = {L_::step, L_::rollout, L_::reset, L_::set_book, L_::process_orders, L_::sim_reset, L_::forward, L_::features_reset}; \
+        return &t;                                                                                                                       \
+    }
+#if LOBSIM_BUILD_ENG(64, 128)
+LOBSIM_DEFINE_LAUNCH(64, 128)
+#endif
+#if LOBSIM_BUILD_ENG(128, 128)
+LOBSIM_DEFINE_LAUNCH(128, 128)
+#endif
+#if LOBSIM_BUILD_ENG(64, 256)
+LOBSIM_DEFINE_LAUNCH(64, 256)
+#endif
+#if LOBSIM_BUILD_ENG(128, 256)
+LOBSIM_DEFINE_LAUNCH(128, 256)
+#endif
+
+#if LOBSIM_BUILD_HOST
 __global__ void lob_gather_status_kernel(DevPtrs P, int n, int32_t* status) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) status[i] = P.hdr[i].status;
@@ -3261,7 +3395,7 @@ __global__ void lob_init_hdr_kernel(DevPtrs P, int n) {
     h.stream_id = -1;
     h.cash = 1000;  // Portfolio(inventory=0, cash=1000), HistoricalOrderbookEnvironment.py:104
     for (int w = 0; w < NSLAB / 64; w++) h.slab_free[w] = ~0ull;
-    for (int w = 0; w < NA / 64; w++) h.agent_free[w] = ~0ull;
+    for (int w = 0; w < NA_MAX / 64; w++) h.agent_free[w] = ~0ull;
     h.min_buy = (double)INFINITY; h.init_buy_range = (double)INFINITY; h.init_sell_range = (double)INFINITY;
     h.msgs = P.streams[0].msgs; h.n_msgs = 0;  // (the handle's empty stream: a step before any reset still reads a batch from a valid address)
     P.hdr[i] = h;
@@ -3274,6 +3408,11 @@ __global__ void lob_set_portfolio_kernel(DevPtrs P, const int32_t* ids, int n, c
     P.hdr[ids[i]].cash = cash[i];
 }
 
+#endif  // LOBSIM_BUILD_HOST
+
 }  // namespace lobk
 
+#if LOBSIM_BUILD_HOST
 #include "lobsim_host.inc"
+#endif
+

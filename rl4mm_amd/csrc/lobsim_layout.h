@@ -12,7 +12,7 @@
 //   Slot slabs[n_slab][SLOTS]   one fixed slab per price level = that level's FIFO queue; slot index = time
 //                               priority; removed orders leave tombstones, squeezed out once LOBSIM_TOMB of them
 //                               have piled up, so a scan touches ceil((live+tombstones)/64) chunks
-//   AgentOrd agent[NA]          the agent's own live orders (the reference's "internal orderbook")
+//   AgentOrd agent[na]          the agent's own live orders (the reference's "internal orderbook")
 //   feature scalars + rings     rolling windows of the observation features
 // During a launch the ladder, the agent orders and the op list live in LDS; slabs stay in HBM/L2 and are read
 // 1 KiB per wave-instruction (16 B per lane), so "find order by id", "volume ahead" and "sweep the level" are
@@ -44,27 +44,24 @@ static_assert(sizeof(FarLevel) == 32, "");
 constexpr size_t FAR_BYTES = 2 * (size_t)FAR_CAP * sizeof(FarLevel);
 constexpr size_t HI_BYTES = 1024;                  // hi_free[64] u64 + padding (slabs stay 1 KiB-aligned)
 constexpr size_t AUX_BYTES = FAR_BYTES + HI_BYTES;  // per env, in front of its slabs: far rings, then hi_free
-#ifndef LOBSIM_NA
-#define LOBSIM_NA 128
-#endif
-constexpr int NA = LOBSIM_NA;    // agent orders per env (live ones + those freed in the current step), NA / 64 per lane: 128, or 256 with -DLOBSIM_NA=256.
-                                 // What bounds the reference's internal book is VOLUME - a side quotes sum(round(100 pdf)) <= 100 + Q/2 shares, so at
-                                 // most ~105 one-share orders per side - and 2 x 105 live entries + the ~20 a step adds fit into 256: under the default
-                                 // configuration LOBSIM_ST_AGENT_OVERFLOW then cannot happen.  That build keeps 16 instead of 20 envs per CU resident
-                                 // (2.5 KB more LDS per env) and loops over four instead of two entries per lane: measured -4.4 % per step at 4096
-                                 // envs (136.2 vs 142.3 M env-steps/s), -10 % on the multi-step launch, -12 % on the 8192-env deep-book shard - so the
-                                 // default stays 128, which random and rule-based policies fill to 53 - 67
-static_assert(NA % 64 == 0 && NA >= 128 && NA <= 256, "agent entries: whole lanes' worth, the index travels in 8 bits of an op code");
+// Agent orders per env (live ones + those freed in the current step): a property of the HANDLE since round 5 (cfg.agent_orders), the
+// engine is a template on it (Eng<.., NAT>: NAT / 64 entries per lane).  What bounds the reference's internal book is VOLUME - a side
+// quotes sum(round(100 pdf)) <= 100 + Q/2 shares, so at most ~105 one-share orders per side - and 2 x 105 live entries + the <= 2Q a
+// step adds fit into 256: with 256 entries LOBSIM_ST_AGENT_OVERFLOW cannot happen under the default configuration, which is why 256 is
+// what lobsim_create picks unless told otherwise.  128 is the faster table (7.2 instead of 10.2 KB of LDS per env: 20 instead of 16
+// envs per CU) that random and rule-based policies fill to 53 - 67; an env that outgrows it says so.
+constexpr int NA_MAX = 256;      // the header's free mask and the op code's index field are sized for this
 #ifndef LOBSIM_IDC_N
 #define LOBSIM_IDC_N 32768
 #endif
 constexpr int IDC_N = LOBSIM_IDC_N;    // entries of the per-env external-order position cache (256 KiB; a cache: every hit is
                                  // verified against the slot it points to, misses take the queue scan)
 constexpr int QMAX = 32;         // quote levels per side (2 * QMAX <= 64 lanes)
-constexpr int OPS_MAX = NA == 128 ? 2 * QMAX + NA + 8 : 288;  // agent op list of a step: limits + cancellations + the clearing market order (resync
-                                 // re-adds reuse it; its last 64 entries double as the Beta-pdf scratch).  With NA = 256 the list is sized by the LDS
-                                 // budget of 16 envs per CU; the volume bound (<= ~210 cancellations + 2Q limits) fits for up to 39 quote levels.
-                                 // Beyond: LOBSIM_ST_AGENT_OVERFLOW
+// agent op list of a step: limits + cancellations + the clearing market order (resync re-adds reuse it; its last 64 entries double as
+// the Beta-pdf scratch).  With 256 agent entries the list is sized by the LDS budget of 16 envs per CU (10 240 B): 286 ops hold the
+// <= 2 x (100 + Q/2) cancellations of one-share orders + 2Q limits + the clearing order for up to 28 quote levels (the default has 10; the
+// table itself is provably large enough for up to 18).  Beyond: LOBSIM_ST_AGENT_OVERFLOW
+constexpr int na_ops_max(int na) { return na == 128 ? 2 * QMAX + 128 + 8 : 286; }
 
 constexpr int64_t DUMMY_PRICE = 9999999999ll;
 
@@ -102,7 +99,7 @@ struct alignas(16) EnvHdr {
     int32_t n_resyncs;
     uint32_t agent_seq;
     uint64_t slab_free[NSLAB / 64];  // bit set = slab free
-    uint64_t agent_free[NA / 64];    // bit set = agent entry free
+    uint64_t agent_free[NA_MAX / 64];  // bit set = agent entry free (the words beyond the handle's table: all set)
     // fills of the last step
     int64_t agent_fill_count, agent_vol[2], ext_count[2], ext_vol[2];
     int64_t cash_delta;
@@ -160,9 +157,9 @@ struct DevPtrs {
     uint8_t* pool;     // [env]{FarLevel far[2][FAR_CAP]; u64 hi_free[64] (+pad); Slot slabs[n_slab][SLOTS]}
     int64_t pool_stride;  // bytes per env
     int32_t n_slab;    // slabs per env (NSLAB .. NSLAB_MAX, a multiple of 64)
-    int32_t pad0;
-    AgentOrd* agent;   // [env][NA]
-    uint16_t* apos;    // [env][NA] slot index of each live agent order inside its level's slab
+    int32_t na;        // agent entries per env (128 or 256: the NAT of the kernels this handle launches)
+    AgentOrd* agent;   // [env][na]
+    uint16_t* apos;    // [env][na] slot index of each live agent order inside its level's slab
     uint64_t* idc;     // [env][IDC_N] position cache of external orders: tag(id) << 32 | slab << 16 | slot, direct-mapped by id
     FeatState* feat;   // [env][LOBSIM_MAX_FEATURES]
     int64_t* rings;    // [env][ring_words]

@@ -18,12 +18,16 @@ acts = torch.from_numpy(np.random.default_rng(2).uniform(0, 10, size=(K + 20, N,
 sims, res = {}, {}
 for arg in sys.argv[1:]:
     name, path = arg.split("=")
+    na = 0
+    if "@" in path: path, na = path.split("@")[0], int(path.split("@")[1])  # name=lib.so@128: cfg.agent_orders
     kw = dict(per_step_reward=(_capi.R_ROLLING_SHARPE, 0, 0.0, 120, 60)) if os.environ.get("AB_REWARD") == "RS" else {}  # (RS: the EXTRAS kernel variants)
     if os.environ.get("AB_MAX_LEVELS"): kw["max_levels"] = int(os.environ["AB_MAX_LEVELS"])  # (slab pool size: 2 x 8 KiB per level and env)
+    if na: kw["agent_orders"] = na
     cfg = _capi.make_cfg(N, 10, bench.default_features(_capi), step_us=100_000, episode_us=1_800_000_000, **kw)
     import subprocess
     missing = [n for n in _capi.PROTOTYPES if ("lobsim_" + n).encode() not in subprocess.run(["nm", "-D", str(ROOT / path)], capture_output=True).stdout]
-    sim = _capi.Sim(_capi.Binding(ROOT / path, skip=missing), cfg)  # (older builds lack the newest entry points)
+    # (older builds lack the newest entry points; a library of round 4 is ABI 4: the cfg struct only renamed a reserved field since)
+    sim = _capi.Sim(_capi.Binding(ROOT / path, skip=missing, check_abi=False), cfg)
     sim.add_stream(stream); sim.set_portfolio(0, 10**12)
     sim.reset(starts, 0)
     sims[name] = sim; res[name] = {"step": [], "roll": []}

@@ -1,9 +1,10 @@
 #!/bin/bash
 # Build a variant of the library in the build container: tools/build_variant.sh NAME [-DFLAG=..] ... -> build/variants/NAME.so
-# (travels with the gpurun snapshot; tools/ab_libs.py compares prebuilt variants on the GPU box)
+# (travels with the gpurun snapshot; tools/ab_libs.py compares prebuilt variants on the GPU box).  Same flags and the same parallel
+# part build as the product library (rl4mm_amd/_lib.py:compile_library).
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; shift
 mkdir -p $ROOT/build/variants
-cd $ROOT/rl4mm_amd/csrc
-hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -std=c++17 -mllvm -amdgpu-atomic-optimizer-strategy=None -mllvm -amdgpu-sched-strategy=max-ilp "$@" -o $ROOT/build/variants/$NAME.so lobsim_kernels.hip
+cd $ROOT
+python -c 'import sys; from pathlib import Path; from rl4mm_amd import _lib; _lib.compile_library(Path("build/variants") / (sys.argv[1] + ".so"), sys.argv[2:])' "$NAME" "$@"

@@ -11,7 +11,7 @@ from rl4mm_amd import _capi, _lib
 
 so = ROOT / "gpurun_out" / "liblobsim_prof.so"
 so.parent.mkdir(exist_ok=True)
-subprocess.check_call(["hipcc", *_lib.HIPCC_FLAGS, "-DLOBSIM_PROFILE", "-o", str(so), str(_lib.SOURCES[0])])
+_lib.compile_library(so, ["-DLOBSIM_PROFILE"])
 b = _capi.Binding(so)
 N = 4096
 fixed = len(sys.argv) > 1 and sys.argv[1] == "fixed"

@@ -17,7 +17,7 @@ for arg in sys.argv[1:] or ["default:"]:
     name, flags = (arg.split(":", 1) + [""])[:2]
     so = ROOT / "gpurun_out" / f"liblobsim_{name}.so"
     so.parent.mkdir(exist_ok=True)
-    subprocess.check_call(["hipcc", *_lib.HIPCC_FLAGS, *flags.split(), "-o", str(so), str(_lib.SOURCES[0])])
+    _lib.compile_library(so, flags.split())
     cfg = _capi.make_cfg(N, 10, bench.default_features(_capi), step_us=100_000, episode_us=1_800_000_000)
     sim = _capi.Sim(_capi.Binding(so), cfg)
     sim.add_stream(stream); sim.set_portfolio(0, 10**12)

@@ -12,7 +12,7 @@ import os
 so = ROOT / "gpurun_out" / "liblobsim_prof.so"
 so.parent.mkdir(exist_ok=True)
 if os.environ.get("PROF_LIB"): so = ROOT / os.environ["PROF_LIB"]  # prebuilt in the build container: tools/build_variant.sh prof -DLOBSIM_PROFILE
-else: subprocess.check_call(["hipcc", *_lib.HIPCC_FLAGS, "-DLOBSIM_PROFILE", *(["-DLOBSIM_PROFILE_MSG"] if "msg" in sys.argv else []), "-o", str(so), str(_lib.SOURCES[0])])
+else: _lib.compile_library(so, ["-DLOBSIM_PROFILE", *(["-DLOBSIM_PROFILE_MSG"] if "msg" in sys.argv else [])])
 b = _capi.Binding(so)
 N = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 4096
 K = 120
