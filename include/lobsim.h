@@ -129,12 +129,13 @@ typedef struct lobsim_cfg {
     int32_t device_id; /* HIP device ordinal (ignored by the oracle) */
     int32_t ladder_levels; /* price levels per side an env keeps ON CHIP (LDS): 0 = auto (64 for n_levels <= 56, else 128), 64 or
                               128.  A performance knob only: levels beyond it live in HBM (ignored by the oracle) */
-    int32_t max_levels;    /* the env's budget of price levels: its slab pool holds 2 x max_levels levels in all, shared by the two
+    int32_t max_levels;    /* the env's budget of price levels: 2 x max_levels levels in all, shared by the two
                               sides (a side can take nearly all of it, up to ladder_levels + 2048).  The reference's book is an
                               unbounded SortedDict (rl4mm/orderbook/models.py:64-69) that keeps every level that left LOBSTER's visible
                               range, so a drifting price piles up stale levels on the side it leaves (10 + one per tick of net excursion).
-                              0 = the default, 512 (16 MiB of slabs per env, whatever else is on the GPU); otherwise 64 .. 2048, raised
-                              to 128 at least and rounded up to a multiple of 32.  If the pool cannot be allocated, lobsim_create
+                              0 = the default, 512 (1.75 MiB of order queues per env - a level takes 1 KiB, 4 KiB or 16 KiB by the
+                              orders it holds -, whatever else is on the GPU); otherwise 64 .. 2048, raised to 128 at least and
+                              rounded up to a multiple of 32.  If the pool cannot be allocated, lobsim_create
                               retries with half (down to 128): lobsim_get_limits reports what the handle really has.  The operation
                               that needs one level more sets LOBSIM_ST_LEVEL_OVERFLOW on that env (ignored by the oracle) */
     int32_t agent_orders;  /* the env's table of live agent orders (the reference's internal book, rl4mm/orderbook/models.py:64-69, is
@@ -200,6 +201,11 @@ int lobsim_set_stream(lobsim_t* h, void* hip_stream);
 /* Upload one packed (ticker, day) stream (host pointers; copied to HBM).  Returns the stream id >= 0.
  * Replaces HistoricalDatabase.get_messages / get_last_snapshot (rl4mm/database/HistoricalDatabase.py:46,103). */
 int lobsim_add_stream(lobsim_t* h, const int64_t* msgs, int64_t n_msgs, const int64_t* snaps, int64_t n_snaps);
+/* Free the device copy of a stream (a (ticker, day) no env replays any more: the reference reads its days from a database on demand,
+ * rl4mm/database/HistoricalDatabase.py:46-62,103-135, and holds none of them).  Its id is handed out again by a later
+ * lobsim_add_stream.  LOBSIM_ERR_STATE while an env's last reset named this stream - also an env that has finished: reset it onto
+ * another stream first. */
+int lobsim_drop_stream(lobsim_t* h, int32_t stream_id);
 
 /* Portfolio carried by each env (HistoricalOrderbookEnvironment.initial_portfolio, :104).  The reference does NOT
  * reset it between episodes; neither does lobsim_reset. */
@@ -288,6 +294,11 @@ typedef struct lobsim_limits {
     int32_t agent_orders;    /* live agent orders (cfg.agent_orders: 256 or 128) */
     int32_t fill_log_rows;   /* rows per list of the fill log of lobsim_forward */
     int64_t bytes_per_env;   /* device memory per env */
+    int32_t queue_pages;     /* 1 KiB pages (64 order slots) of queue memory per env.  A level's queue is 1, 4 or 16 pages - it moves up when
+                                it fills its pages before 128 tombstones have piled up - cut from this pool; with no larger piece left a
+                                level stays where it is (and squeezes its tombstones out more often): LOBSIM_ST_QUEUE_OVERFLOW only when its
+                                pages are full of LIVE orders, LOBSIM_ST_LEVEL_OVERFLOW when a new level finds no page */
+    int32_t reserved;
 } lobsim_limits;
 int lobsim_get_limits(const lobsim_t* h, lobsim_limits* out);
 
@@ -360,7 +371,8 @@ enum lobsim_forward_flags {
 /* OrderbookSimulator.forward_step(until, internal_orders) (:70-88) for n envs: env i first processes its n_orders[i] internal
  * orders - rows orders[i][0 .. n_orders[i]) of [max_orders][6], the row format of lobsim_debug_process_orders - then the
  * messages of (now, until_us[i]], sets its clock to until_us[i] and, on a whole second and near the edge of its initial price
- * range, runs update_outer_levels (:99-135).  until <= now is the reference's assert: LOBSIM_ST_ASSERT.  Every fill of the call
+ * range, runs update_outer_levels (:99-135).  until <= now is the reference's assert (:71-73), an exception that leaves the simulator as it
+ * was: the call returns LOBSIM_ERR_ARG, that env is untouched (the other envs of the call have stepped).  Every fill of the call
  * goes to the env's fill log (lobsim_get_fills).  orders / n_orders may be NULL (no internal orders); obs (host, [n][obs_dim])
  * may be NULL. */
 int lobsim_forward(lobsim_t* h, const int32_t* env_ids, int32_t n, const int64_t* until_us, const int64_t* orders,

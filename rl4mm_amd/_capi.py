@@ -116,7 +116,7 @@ class OrderView(C.Structure):
 
 class Limits(C.Structure):
     _fields_ = [("level_slabs", C.c_int32), ("ladder_levels", C.c_int32), ("far_levels", C.c_int32), ("queue_slots", C.c_int32),
-                ("agent_orders", C.c_int32), ("fill_log_rows", C.c_int32), ("bytes_per_env", C.c_int64)]
+                ("agent_orders", C.c_int32), ("fill_log_rows", C.c_int32), ("bytes_per_env", C.c_int64), ("queue_pages", C.c_int32), ("reserved", C.c_int32)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -142,6 +142,7 @@ PROTOTYPES = {
     "last_error": (C.c_char_p, [C.c_void_p]),
     "set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "add_stream": (C.c_int, [C.c_void_p, _P64, C.c_int64, _P64, C.c_int64]),
+    "drop_stream": (C.c_int, [C.c_void_p, C.c_int32]),
     "set_portfolio": (C.c_int, [C.c_void_p, _P32, C.c_int32, _P64, _P64]),
     "reset": (C.c_int, [C.c_void_p, _P32, C.c_int32, _P32, _P64, _PD]),
     "step": (C.c_int, [C.c_void_p, _PD, _PU8, _PD, _PD, _PU8]),
@@ -170,7 +171,7 @@ PROTOTYPES = {
     "debug_process_orders": (C.c_int, [C.c_void_p, C.c_int32, _P64, C.c_int32, _P64]),
 }
 # the oracle has no device entry points
-ORACLE_SKIP = {"set_stream", "step_device", "sync", "rollout_device", "set_info_buffer", "set_trace_buffer", "host_io_buffers", "step_host_io",
+ORACLE_SKIP = {"drop_stream", "set_stream", "step_device", "sync", "rollout_device", "set_info_buffer", "set_trace_buffer", "host_io_buffers", "step_host_io",
                "step_device_skip", "reset_device"}
 
 
@@ -299,8 +300,16 @@ class Sim:
         sid = self.b.fn["add_stream"](self.h, _ptr(msgs, _P64), msgs.shape[0], _ptr(snaps, _P64), snaps.shape[0])
         if sid < 0:
             self._check(sid, "add_stream")
-        self._streams.append(stream)
+        if sid < len(self._streams):
+            self._streams[sid] = stream  # (a slot lobsim_drop_stream gave back)
+        else:
+            self._streams.append(stream)
         return sid
+
+    def drop_stream(self, sid: int):
+        """lobsim_drop_stream: frees the device copy; the id is handed out again by a later add_stream"""
+        self._check(self.b.fn["drop_stream"](self.h, int(sid)), "drop_stream")
+        self._streams[sid] = None
 
     def set_portfolio(self, inventory, cash, env_ids=None):
         ids = np.arange(self.n_envs, dtype=np.int32) if env_ids is None else np.ascontiguousarray(env_ids, dtype=np.int32)

@@ -244,6 +244,10 @@ SDI int m_slab(uint64_t m) { return (int)(m & 0xffff); }
 SDI int m_head(uint64_t m) { return (int)((m >> 16) & 0xffff); }
 SDI int m_tail(uint64_t m) { return (int)((m >> 32) & 0xffff); }
 SDI int m_live(uint64_t m) { return (int)(m >> 48); }
+// the slab a meta word (or a position-cache entry) names: class << 14 | first page (lobsim_layout.h)
+SDI int slab_cap(int slab) { return PAGE_SLOTS << (2 * (slab >> SLAB_CLASS_SHIFT)); }  // 64 / 256 / 1024 slots
+SDI int m_cap(uint64_t m) { return slab_cap(m_slab(m)); }
+template <typename T> SDI T* slab_ptr(T* slots, int slab) { return slots + (size_t)(slab & SLAB_PAGE_MASK) * PAGE_SLOTS; }
 
 // wave-uniform scalars of the env being advanced (kept in registers)
 template <typename T>
@@ -437,29 +441,91 @@ SDI void far_st(FarLevel* e, int64_t price, uint64_t meta, int64_t vol) {
 }
 
 #define UNLIKELY(x) __builtin_expect(!!(x), 0)  // the far branches: laid out away from the hot path, spills kept inside them
-// a free slab beyond the first NSLAB: their mask lives in HBM, one word per lane.  -1: none left
-SDI int slab_alloc_hi(Slot* slots) {
-    uint64_t* w = hi_free_words(slots);
-    const uint64_t v = w[lane()];
+// Slabs beyond the first NSLAB pages come from a BUDDY pool (pages NSLAB .. NSLAB + 16 n_big of the env): blocks of 1, 4 and 16
+// pages, a free mask per size in the env's aux block (HBM; all of this is rare and serial).  A block of 4 or 16 pages that is asked for
+// and not free is split off the next size up - three quarters go to the smaller size's mask -, four free siblings merge back when the
+// last of them is released: a drifting day's hundreds of thin stale levels and a thick book's few hundred-order queues draw on the
+// same pages.  -1: nothing left.
+SDI int buddy_take(uint64_t* w, int w0, int nw) {  // the first set bit of the mask words [w0, w0 + nw); -1: none
+    const int ln = lane();
+    const uint64_t v = ln < nw ? w[w0 + ln] : 0;
     const uint64_t b = ballot(v != 0);
     if (!b) return -1;
     const int wl = ffs64(b);
     const int bit = ffs64((uint64_t)rl64((int64_t)v, wl));
-    if (lane() == wl) w[wl] = v & (v - 1);
+    if (ln == wl) w[w0 + wl] = v & (v - 1);
     wsync();
-    return NSLAB + wl * 64 + bit;
+    return wl * 64 + bit;
+}
+SDI void buddy_put3(uint64_t* w, int w0, int b) {  // blocks b + 1 .. b + 3 (b a multiple of 4) become free
+    if (lane() == 0) w[w0 + (b >> 6)] |= 0xEull << (b & 63);
+    wsync();
+}
+constexpr int hi_w0(int cls) { return cls == 0 ? HI_W0 : cls == 1 ? HI_W1 : HI_W2; }
+constexpr int hi_nw(int cls) { return cls == 0 ? 64 : cls == 1 ? NMID_MAX / 64 : NBIG_MAX / 64; }
+SDI int slab_alloc_cls(Slot* slots, int cls) {
+    uint64_t* w = hi_free_words(slots);
+    cls = uni(cls);
+    int b = -1;
+    if (cls == 0) {
+        b = buddy_take(w, HI_W0, 64);
+        if (b < 0) {
+            int p = buddy_take(w, HI_W1, NMID_MAX / 64);
+            if (p < 0) {
+                const int g = buddy_take(w, HI_W2, NBIG_MAX / 64);
+                if (g < 0) return -1;
+                p = 4 * g; buddy_put3(w, HI_W1, p);
+            }
+            b = 4 * p; buddy_put3(w, HI_W0, b);
+        }
+        return NSLAB + b;
+    }
+    if (cls == 1) {
+        b = buddy_take(w, HI_W1, NMID_MAX / 64);
+        if (b < 0) {
+            const int g = buddy_take(w, HI_W2, NBIG_MAX / 64);
+            if (g < 0) return -1;
+            b = 4 * g; buddy_put3(w, HI_W1, b);
+        }
+        return (1 << SLAB_CLASS_SHIFT) | (NSLAB + 4 * b);
+    }
+    b = buddy_take(w, HI_W2, NBIG_MAX / 64);
+    return b < 0 ? -1 : (2 << SLAB_CLASS_SHIFT) | (NSLAB + 16 * b);
+}
+SDI int slab_alloc_hi(Slot* slots) { return slab_alloc_cls(slots, 0); }
+// the smallest free slab of a class above `cls` (a level that has outgrown its slab); -1: none
+SDI int slab_alloc_larger(Slot* slots, int cls) {
+    int s = -1;
+    if (cls < 1) s = slab_alloc_cls(slots, 1);
+    if (s < 0) s = slab_alloc_cls(slots, 2);
+    return s;
 }
 SDI void slab_release(Lds& L, Slot* slots, int slab) {  // (inside the cold routines)
     if (slab < NSLAB) { mask_set(L.slab_free, slab); return; }
-    uint64_t* w = hi_free_words(slots) + ((slab - NSLAB) >> 6);
-    if (lane() == 0) *w = *w | (1ull << ((slab - NSLAB) & 63));
-    wsync();
+    uint64_t* w = hi_free_words(slots);
+    int cls = uni(slab >> SLAB_CLASS_SHIFT);
+    int b = ((slab & SLAB_PAGE_MASK) - NSLAB) >> (2 * cls);
+    for (;;) {  // free block b of size class cls; four free siblings merge into their parent
+        const int wi = (cls == 0 ? HI_W0 : cls == 1 ? HI_W1 : HI_W2) + (b >> 6), sh = b & 60;  // (a group of four never straddles a word)
+        const uint64_t v = (uint64_t)uni64((int64_t)w[wi]) | (1ull << (b & 63));
+        const bool merge = cls < 2 && ((v >> sh) & 0xF) == 0xF;
+        if (lane() == 0) w[wi] = merge ? v & ~(0xFull << sh) : v;
+        wsync();
+        if (!merge) break;
+        b >>= 2; cls++;
+    }
 }
 // The rare part of ladder_insert: a full near side evicts its worst level (index LV - 1) to the front of the far ring,
 // and / or the slab comes from the mask in HBM because the one in LDS is used up (`slab` < 0).
 // Returns the slab (or 0xffff) | status bits << 16.
-COLD int ladder_insert_cold(Lds& L, Slot* slots, int side, int evict, int slab) {
-    side = uni(side); evict = uni(evict); slab = uni(slab);
+COLD int ladder_insert_cold(Lds& L, Slot* slots, int side, int evict, int slab, int n_levels) {
+    side = uni(side); evict = uni(evict); slab = uni(slab); n_levels = uni(n_levels);
+    // the env's budget of price levels = its class-0 slabs (a level that moved to a larger slab gave its page back, so the masks
+    // alone do not say): n_levels = levels of both near sides, the far ones are counted here
+    if (n_levels + far_count(L, 0) + far_count(L, 1) >= (int)(uni64((int64_t)hi_free_words(slots)[HI_COUNTS]) & 0xffff)) {
+        if (slab >= 0) slab_release(L, slots, slab);
+        return 0xffff | (LOBSIM_ST_LEVEL_OVERFLOW << 16);
+    }
     if (evict) {
         const int n = far_count(L, side);
         if (n >= FAR_CAP) return 0xffff | (LOBSIM_ST_LEVEL_OVERFLOW << 16);
@@ -563,8 +629,8 @@ SDI bool far_domain(const Lds& L, const Scal& S, int side, int64_t price) {
 // a level address it like any other.  With `create` a level that does not exist is staged empty, with a fresh slab; it
 // enters the ring when the operation ends (far_finish).  Returns k | exists << 16 (k = the level's logical ring index, or
 // where the new level will go), -1 when there is no such level and none is to be created, -2 when no slab is left.
-COLD int far_lookup(Lds& L, Slot* slots, int side, int64_t price, int create) {
-    side = uni(side); price = uni64(price); create = uni(create);
+COLD int far_lookup(Lds& L, Slot* slots, int side, int64_t price, int create, int n_levels) {
+    side = uni(side); price = uni64(price); create = uni(create); n_levels = uni(n_levels);
     int ins;
     const int k = far_find(L, slots, side, price, ins);
     if (k >= 0) {
@@ -574,6 +640,7 @@ COLD int far_lookup(Lds& L, Slot* slots, int side, int64_t price, int create) {
         return k | (1 << 16);
     }
     if (!create) return -1;
+    if (n_levels + far_count(L, 0) + far_count(L, 1) >= (int)(uni64((int64_t)hi_free_words(slots)[HI_COUNTS]) & 0xffff)) return -2;  // the level budget (ladder_insert_cold)
     int slab = mask_take_first(L.slab_free);
     if (slab < 0) slab = slab_alloc_hi(slots);
     if (slab < 0) return -2;
@@ -622,7 +689,7 @@ COLD I64x2 far_worst_prices(Lds& L, Slot* slots, int sides) {
 struct FarOp { int k; bool exists; };
 // -> LV (the staging slot) or -1
 SDI int far_open(Lds& L, Scal& S, int side, int64_t price, bool create, FarOp& op, uint64_t& meta) {
-    const int r = far_lookup(L, S.slots, side, price, create ? 1 : 0);
+    const int r = far_lookup(L, S.slots, side, price, create ? 1 : 0, S.n_lv[0] + S.n_lv[1]);
     if (r < 0) { if (r == -2) S.status |= LOBSIM_ST_LEVEL_OVERFLOW; op.k = -1; return -1; }
     op.k = r & 0xffff; op.exists = (r >> 16) & 1;
     wsync();
@@ -640,9 +707,9 @@ SDI bool ladder_insert(Lds& L, Scal& S, int side, int pos, int64_t price) {
     EVENT(ev_ladder);
     if (!(LOBSIM_FAR && LOBSIM_FAR_EVICT) && n >= LV) { S.status |= LOBSIM_ST_LEVEL_OVERFLOW; return false; }
     int slab = mask_take_first(L.slab_free);
-    if (UNLIKELY(n >= LV || slab < 0)) {
+    if (UNLIKELY(n >= LV || slab < 0 || S.n_lv[side ^ 1] >= LV)) {  // (either side full: far levels may exist, the level budget is checked)
         int r = LOBSIM_ST_LEVEL_OVERFLOW << 16;
-        if (LOBSIM_FAR && LOBSIM_FAR_EVICT) r = ladder_insert_cold(L, S.slots, side, n >= LV ? 1 : 0, slab);
+        if (LOBSIM_FAR && LOBSIM_FAR_EVICT) r = ladder_insert_cold(L, S.slots, side, n >= LV ? 1 : 0, slab, S.n_lv[0] + S.n_lv[1]);
         if (r >> 16) { S.status |= r >> 16; return false; }
         slab = r & 0xffff;
     }
@@ -754,11 +821,13 @@ SDI uint64_t idc_get(const Scal& S, int64_t id) {
 
 // squeeze tombstones out of a slab (FIFO order kept); chunk by chunk, in place: a chunk's survivors always land
 // at or below the chunk's own first slot, so nothing unread is overwritten.  Returns the new meta word.
-SDI uint64_t compact_level(Lds& L, Scal& S, int side, int idx, uint64_t m) {
+SDI uint64_t compact_level(Lds& L, Scal& S, int side, int idx, uint64_t m, int dst = -1) {
     int ln = lane();
     EVENT(ev_compact);
     int slab = m_slab(m), head = m_head(m), tail = m_tail(m);
-    Slot* sl = S.slots + (size_t)slab * SLOTS;
+    if (dst < 0) dst = slab;  // in place; else: into another (larger) slab, the level moves
+    Slot* sl = slab_ptr(S.slots, slab);
+    Slot* dl = slab_ptr(S.slots, dst);
     uint64_t below = (1ull << ln) - 1;
     int out = 0;
 #ifndef LOBSIM_COMPACT_WIDTH
@@ -777,26 +846,41 @@ SDI uint64_t compact_level(Lds& L, Scal& S, int side, int idx, uint64_t m) {
             const uint64_t b = ballot(s[k].kind != K_DEAD);
             if (s[k].kind != K_DEAD) {
                 int np = out + popc64(b & below);
-                sl[np] = s[k];
+                dl[np] = s[k];
                 if (s[k].kind == K_AGENT) L.apos[s[k].id] = (uint16_t)np;
-                if (s[k].kind == K_EXT) idc_put(S, s[k].id, slab, np);
+                if (s[k].kind == K_EXT) idc_put(S, s[k].id, dst, np);
             }
             out += popc64(b);
         }
         wsync();
     }
-    return mk_meta(slab, 0, out, m_live(m));
+    return mk_meta(dst, 0, out, m_live(m));
+}
+
+// A level whose slab holds LOBSIM_TOMB tombstones, or is full, is squeezed.  In the same pass it moves into a larger slab - if the env's
+// pool has one - when it has outgrown its own: a one-page level (64 slots) that filled its page (appends outran the tombstones: a busy
+// level; the stale levels a drifting price leaves behind never do), a four-page level (256 slots) of which three quarters are LIVE
+// orders.  A thick book's levels of ~180 orders stay in four pages (squeezed every ~75 removals instead of every 128) - sixteen pages
+// each would exhaust the pool on a day that leaves hundreds of them behind.  Returns the new meta word (the caller stores it).
+SDI uint64_t make_room(Lds& L, Scal& S, int side, int idx, uint64_t m) {
+    const int slab = m_slab(m), cap = slab_cap(slab), cls = slab >> SLAB_CLASS_SHIFT;
+    int dst = -1;
+    const bool grow = cls == 0 ? m_tail(m) >= cap - 1 : m_live(m) * 4 > cap * 3;
+    if (UNLIKELY(cls < 2 && grow)) dst = slab_alloc_larger(S.slots, cls);
+    const uint64_t nm = compact_level(L, S, side, idx, m, dst);
+    if (UNLIKELY(dst >= 0)) slab_release(L, S.slots, slab);
+    return nm;
 }
 
 SDI void level_append(Lds& L, Scal& S, int side, int idx, int64_t id, int32_t vol, int32_t kind, uint64_t m) {
-    if (m_tail(m) == SLOTS || m_tail(m) - m_head(m) - m_live(m) >= LOBSIM_TOMB) {  // full, or a chunk's worth of tombstones
-        m = compact_level(L, S, side, idx, m);
-        if (m_tail(m) == SLOTS) { S.status |= LOBSIM_ST_QUEUE_OVERFLOW; return; }
+    if (m_tail(m) == m_cap(m) || m_tail(m) - m_head(m) - m_live(m) >= LOBSIM_TOMB) {  // full, or two chunks' worth of tombstones
+        m = make_room(L, S, side, idx, m);
+        if (m_tail(m) == m_cap(m)) { S.status |= LOBSIM_ST_QUEUE_OVERFLOW; return; }
     }
     int tail = m_tail(m), live = m_live(m);
     if (lane() == 0) {
         Slot s; s.id = id; s.vol = vol; s.kind = kind;
-        S.slots[(size_t)m_slab(m) * SLOTS + tail] = s;
+        slab_ptr(S.slots, m_slab(m))[tail] = s;
         if (kind == K_AGENT) L.apos[id] = (uint16_t)tail;
         if (kind == K_EXT) idc_put(S, id, m_slab(m), tail);
         L.meta[side][idx] = mk_meta(m_slab(m), live == 0 ? tail : m_head(m), tail + 1, live + 1);
@@ -829,14 +913,14 @@ SDI void squeeze_ahead(Lds& L, Scal& S) {
             if (i < S.n_lv[sd]) {
                 const uint64_t m = L.meta[sd][i];
                 const int t = m_tail(m) - m_head(m) - m_live(m);
-                due = t >= LOBSIM_TOMB_AHEAD || (t > 0 && m_tail(m) > SLOTS - 2 * WAVE);
+                due = t >= LOBSIM_TOMB_AHEAD || (t >= 16 && m_tail(m) > m_cap(m) - 32);  // (or its slab is nearly full and a squeeze would make room)
             }
             const uint64_t b = ballot(due);
             if (b && side < 0) { side = sd; idx = 64 * r + ffs64(b); }
         }
     if (side < 0) return;
     const uint64_t m = (uint64_t)uni64((int64_t)L.meta[side][idx]);
-    const uint64_t nm = compact_level(L, S, side, idx, m);
+    const uint64_t nm = make_room(L, S, side, idx, m);
     if (ln == 0) L.meta[side][idx] = nm;
     wsync();
 }
@@ -852,7 +936,7 @@ SDI int alloc_agent(Lds& L, Scal& S) {
 SDI void reduce_slot(Lds& L, Scal& S, int side, int idx, uint64_t m, int pos, int32_t rv, int32_t pv, int32_t pk, int64_t pid) {
     int ln = lane();
     int head = m_head(m), tail = m_tail(m);
-    Slot* sl = S.slots + (size_t)m_slab(m) * SLOTS;
+    Slot* sl = slab_ptr(S.slots, m_slab(m));
     int32_t nv = pv - rv;
     bool gone = nv == 0;
     if (ln == 0) {
@@ -883,7 +967,7 @@ SDI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, in
     }
     int ln = lane();
     int head = m_head(m), tail = m_tail(m);
-    const Slot* sl = S.slots + (size_t)m_slab(m) * SLOTS;
+    const Slot* sl = slab_ptr(S.slots, m_slab(m));
     int pos = -1;
     int32_t pv = 0;
 #ifdef LOBSIM_PROFILE
@@ -1031,7 +1115,7 @@ SDI int32_t execute(Lds& L, Scal& S, int side, bool is_agent, bool is_market, in
         if (!is_market && !(side == LOBSIM_BUY ? le64(bp, price) : le64(price, bp))) break;
         uint64_t m = (uint64_t)uni64((int64_t)L.meta[opp][0]);
         int head = m_head(m), tail = m_tail(m);
-        Slot* sl = S.slots + (size_t)m_slab(m) * SLOTS;
+        Slot* sl = slab_ptr(S.slots, m_slab(m));
         int32_t carry = 0, exec_agent = 0, deleted_agent_vol = 0, n_ext = 0, n_agent = 0, n_removed = 0;
         int first_survivor = tail;
         EVENT(ev_exec_levels);
@@ -1496,9 +1580,9 @@ SDI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
     const int nlv = S.n_lv[side];
     const int li = (is_limit || is_cancel) ? lane_find_level(L, side, nlv, price) : -1;
     const uint64_t m = li >= 0 ? L.meta[side][li] : 0;
-    Slot* sl = S.slots + (size_t)m_slab(m) * SLOTS;
+    Slot* sl = slab_ptr(S.slots, m_slab(m));
     // ---- new orders: append at the tail of an existing level that has room
-    bool lim_ok = is_limit && li >= 0 && m_tail(m) < SLOTS && m_tail(m) - m_head(m) - m_live(m) < LOBSIM_TOMB;
+    bool lim_ok = is_limit && li >= 0 && m_tail(m) < m_cap(m) && m_tail(m) - m_head(m) - m_live(m) < LOBSIM_TOMB;
     uint64_t lim_mask = ballot(lim_ok);
     int R = popc64(lim_mask);
     uint64_t fw[AE];
@@ -1590,11 +1674,17 @@ SDI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
 // ---------------------------------------------------------------------------------------------------------------
 SDI Slot* env_slabs(const DevPtrs& P, int env) { return reinterpret_cast<Slot*>(P.pool + (size_t)env * (size_t)P.pool_stride + AUX_BYTES); }
 
-SDI void ladder_clear(Lds& L, Scal& S, int n_slab) {
+// the first n bits of a mask of 64-bit words, word w
+SDI uint64_t mask_word(int n, int w) { const int k = n - 64 * w; return k >= 64 ? ~0ull : k > 0 ? (1ull << k) - 1 : 0ull; }
+SDI void ladder_clear(Lds& L, Scal& S, const DevPtrs& P) {
     S.n_lv.v = 0;
     S.ladder_ver = 0;
     if (lane() < 2) { L.far_n[lane()] = 0; L.far_front[lane()] = 0; }
-    hi_free_words(S.slots)[lane()] = lane() < (n_slab - NSLAB) / 64 ? ~0ull : 0ull;  // slabs beyond the first NSLAB
+    uint64_t* hw = hi_free_words(S.slots);
+    hw[HI_W0 + lane()] = 0;  // the buddy pool (slab_alloc_cls): all of it free as 16-page blocks, none split yet
+    if (lane() < NMID_MAX / 64) hw[HI_W1 + lane()] = 0;
+    if (lane() < NBIG_MAX / 64) hw[HI_W2 + lane()] = mask_word(P.n_big, lane());
+    if (lane() == 0) hw[HI_COUNTS] = (uint64_t)P.n_slab | ((uint64_t)P.n_big << 32);  // (n_slab: the env's budget of price levels, ladder_insert_cold)
     if (lane() < NSLAB / 64) L.slab_free[lane()] = ~0ull;
     if (lane() < NA / 64) { L.agent_free[lane()] = ~0ull; L.agent_pending[lane()] = 0; }
 #pragma unroll
@@ -1620,7 +1710,7 @@ SDI void set_level_to_snapshot(Lds& L, Scal& S, int side, int64_t price, int32_t
     if (lane() == 0) {
         int slab = m_slab(L.meta[side][idx]);
         Slot s; s.id = -1; s.vol = vol; s.kind = K_SNAP;
-        S.slots[(size_t)slab * SLOTS] = s;
+        slab_ptr(S.slots, slab)[0] = s;
         L.meta[side][idx] = mk_meta(slab, 0, 1, 1); L.vol[side][idx] = vol;
     }
     wsync();
@@ -1782,8 +1872,10 @@ SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt,
 #endif
     bool cross = false;
     if (is_lim && S.n_lv[side ^ 1] > 0) { const int64_t bp = L.price[side ^ 1][0]; cross = side == LOBSIM_BUY ? b.price >= bp : b.price <= bp; }
+    // (room: every limit order of the pass could land on this lane's level)
+    const int n_lim = popc64(ballot(is_lim));
     const bool plain = is_lim && vol64 > 0 && vol64 < (1ll << 31) && li >= 0 && !cross && m_live(m) > 0 &&
-                       m_tail(m) <= SLOTS - WAVE && m_tail(m) - m_head(m) - m_live(m) < LOBSIM_TOMB;
+                       m_tail(m) + n_lim <= m_cap(m) && m_tail(m) - m_head(m) - m_live(m) < LOBSIM_TOMB;
     const uint64_t stop = ballot(in && !(plain || is_rem));
     seg_end = stop ? ffs64(stop) : cnt;
     const bool app = plain && ln < seg_end;
@@ -1805,7 +1897,7 @@ SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt,
         if (app) {
             Slot w; w.id = b.eid; w.vol = (int32_t)vol64; w.kind = K_EXT;
             const int pos = m_tail(m) + rank;
-            slot_store<2>(&S.slots[(size_t)m_slab(m) * SLOTS + pos], w);
+            slot_store<2>(&slab_ptr(S.slots, m_slab(m))[pos], w);
             idc_put(S, b.eid, m_slab(m), pos);
             atomicAdd(reinterpret_cast<unsigned long long*>(&L.meta[side][li]), (1ull << 32) + (1ull << 48));  // tail += 1, live += 1
             atomicAdd(&L.vol[side][li], (int32_t)vol64);
@@ -1819,7 +1911,7 @@ SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt,
 #if LOBSIM_SLOT_EARLY
     // (no branch around the load: the compiler would wait for it at the end of the branch, i.e. before the appends instead
     // of behind them; a lane without a removal reads slot 0 of slab 0 and ignores it)
-    const Slot cs = slot_load<8>(&S.slots[rem ? (size_t)cslab * SLOTS + cpos : (size_t)0]);
+    const Slot cs = slot_load<8>(&slab_ptr(S.slots, rem ? cslab : 0)[rem ? cpos : 0]);
 #endif
     book_appends();
     // ---- cancellations / deletions whose order the position cache still knows: straight to the slot, no queue scan.
@@ -1832,7 +1924,7 @@ SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt,
     const uint64_t m2 = rem ? L.meta[side][li] : 0;  // after the appends of this segment
     rem = rem && cslab == m_slab(m2) && cpos >= m_head(m2) && cpos < m_tail(m2);
     Slot cs = dead_slot();
-    if (rem) cs = S.slots[(size_t)cslab * SLOTS + cpos];
+    if (rem) cs = slab_ptr(S.slots, cslab)[cpos];
 #endif
     rem = rem && cs.kind == K_EXT && cs.id == b.eid;
     const int rkey = (cslab << 16) | cpos;
@@ -1866,7 +1958,7 @@ SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt,
         const int32_t rv = v > cs.vol ? cs.vol : v, nv = cs.vol - rv;  // CancellationVolumeExceededError -> whole remainder
         gone = nv == 0;
         Slot w = cs; w.vol = nv; if (gone) w.kind = K_DEAD;
-        slot_store<4>(&S.slots[(size_t)cslab * SLOTS + cpos], w);
+        slot_store<4>(&slab_ptr(S.slots, cslab)[cpos], w);
         atomicAdd(&L.vol[side][li], -rv);
         if (gone) atomicAdd(reinterpret_cast<unsigned long long*>(&L.meta[side][li]), (unsigned long long)(-(1ll << 48)));  // live -= 1
     }
@@ -2981,7 +3073,7 @@ SDI void reset_body(const DevCfg& C, const DevPtrs& P, const ResetArgs& A) {
     S.idc = P.idc + (size_t)env * IDC_N;
     S.status = 0; S.n_ops = 0;
     if (ln == 0) { L.inv = H.inventory; L.cash = H.cash; }  // the portfolio is NOT reset (Q7)
-    ladder_clear(L, S, P.n_slab);
+    ladder_clear(L, S, P);
     clear_step_fills(L);
     const int stream_id = A.stream_ids[k];
     const StreamDev& st = P.streams[stream_id];
@@ -3052,7 +3144,7 @@ SDI void set_book_body(const DevCfg& C, const DevPtrs& P, int env, const int64_t
     S.idc = P.idc + (size_t)env * IDC_N;
     S.status = 0; S.n_ops = 0;
     if (lane() == 0) { L.inv = H.inventory; L.cash = H.cash; }
-    ladder_clear(L, S, P.n_slab);
+    ladder_clear(L, S, P);
     clear_step_fills(L);
     if (row) load_snapshot_book(L, S, row, C.c.n_levels, true);
     store_env(L, S, P, env, H);
@@ -3143,7 +3235,7 @@ SDI void sim_reset_body(const DevCfg& C, const DevPtrs& P, const ResetArgs& A) {
     S.idc = P.idc + (size_t)env * IDC_N;
     S.status = 0; S.n_ops = 0;
     if (ln == 0) { L.inv = H.inventory; L.cash = H.cash; }
-    ladder_clear(L, S, P.n_slab);
+    ladder_clear(L, S, P);
     clear_step_fills(L);
     const int stream_id = A.stream_ids[k];
     const StreamDev& st = P.streams[stream_id];
@@ -3198,7 +3290,10 @@ SDI void forward_body(const DevCfg& C, const DevPtrs& P, const ForwardArgs& A) {
     int n_resyncs = 0;
     double price = H.price;
     const int entry_status = S.status;
-    if (!S.status && !lt64(now, until)) S.status |= LOBSIM_ST_ASSERT;  // assert until > self.now_is (:71-73)
+    if (!S.status && !lt64(now, until)) {  // assert until > self.now_is (:71-73): an exception that leaves the simulator as it was - the
+        if (ln == 0) A.flog_n[(size_t)env * 2] = -1;  // host reports it (lobsim_forward) and the env is not touched
+        return;
+    }
     const int n_int = A.n_orders ? A.n_orders[k] : 0;
     for (int i = 0; i < n_int && !S.status; i++) process_raw_order(L, S, A.orders + ((size_t)k * A.max_orders + i) * 6);
     if (!S.status) {

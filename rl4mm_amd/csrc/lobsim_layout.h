@@ -8,10 +8,12 @@
 //   Ladder                      per side LV price levels, sorted best-first (SoA: price, packed slab/head/tail/live, volume)
 //   FarLevel far[2][FAR_CAP]    price levels beyond the best LVT of a side (the reference's SortedDict is unbounded and keeps
 //                               every level that left LOBSTER's visible range): a ring per side, best-first from its front
-//   hi_free[64]                 free mask of the slabs beyond the first NSLAB_LO
-//   Slot slabs[n_slab][SLOTS]   one fixed slab per price level = that level's FIFO queue; slot index = time
-//                               priority; removed orders leave tombstones, squeezed out once LOBSIM_TOMB of them
-//                               have piled up, so a scan touches ceil((live+tombstones)/64) chunks
+//   hi_free[..]                 free masks of the slabs whose mask is not in the header (lobsim_layout.h: HiWords)
+//   Slot pages[n_pages][64]     the slab pool in 1 KiB pages.  One slab per price level = that level's FIFO queue, CONTIGUOUS, in one
+//                               of three sizes - 1, 4 or 16 pages = 64 / 256 / 1024 slots; a level starts in the smallest and moves
+//                               to a larger one when it outgrows its slab (rare: make_room).  Slot index = time priority; removed
+//                               orders leave tombstones, squeezed out once LOBSIM_TOMB of them have piled up (or the slab is
+//                               full), so a scan touches ceil((live+tombstones)/64) chunks
 //   AgentOrd agent[na]          the agent's own live orders (the reference's "internal orderbook")
 //   feature scalars + rings     rolling windows of the observation features
 // During a launch the ladder, the agent orders and the op list live in LDS; slabs stay in HBM/L2 and are read
@@ -26,23 +28,32 @@ namespace lobk {
 
 constexpr int WAVE = 64;
 constexpr int LV = 128;          // price levels per side of the NEAR ladder (the part of a side an env keeps in LDS; 2 per lane)
-#ifndef LOBSIM_SLOTS
-#define LOBSIM_SLOTS 1024  // (512 until round 4: 367 live orders at one price were seen on the synthetic day, ~200 on a constructed thick-book day; the slab is
-                           // 16 KiB, its size costs no step time - measured 139.8 vs 139 - 140 M env-steps/s - only address space)
-#endif
-constexpr int SLOTS = LOBSIM_SLOTS;  // order slots per price level (chunks of one wave-load each; 16 B per slot)
-constexpr int NSLAB = 2 * LV;    // slabs whose free mask lives in the header / in LDS (the first ones handed out)
+// The slab of a level: a contiguous run of 1 KiB pages (64 slots of 16 B: one wave-load) in the env's pool, in one of three size
+// classes.  Slab id (the 16-bit field of a level's meta word, of a position-cache entry) = class << 14 | first page: a slot's address
+// is a function of the meta word alone - no table in between - and the class says how many slots the level may use.  Until round 5
+// every level owned a fixed 16 KiB slab (16.5 MB of device memory per env at the default level budget, ~400 x what a day's live orders
+// take); now a level takes 1 KiB while it is thin - the hundreds of stale levels a drifting day leaves behind hold an order or two -
+// and only the levels that really hold hundreds of orders take 16 KiB.
+constexpr int PAGE_SLOTS = 64;
+constexpr int SLAB_CLASS_SHIFT = 14, SLAB_PAGE_MASK = (1 << SLAB_CLASS_SHIFT) - 1;
+constexpr int SLOTS = PAGE_SLOTS << 4;  // order slots of the largest class = the most live orders + tombstones one price can hold (1024)
+constexpr int NSLAB = 2 * LV;    // class-0 slabs whose free mask lives in the header / in LDS (the first ones handed out): slab id = page < NSLAB
 // Levels beyond the near ladder ("far" levels: the worse end of a side) live in HBM, one ring per side that is ordered
 // best-first from its front: the level next to the near ladder's worst is at `front`, the k-th best far level at
 // (front - k) mod FAR_CAP.  Both ends are O(1): the near ladder evicts to / refills from the front, the once-a-second
 // outer-level resync appends at the back.  The ring's capacity is fixed; how many levels an env can really hold is set
 // by its slab pool (cfg.max_levels -> DevPtrs.n_slab).
 constexpr int FAR_CAP = 2048;
-constexpr int NSLAB_MAX = NSLAB + 64 * 64;  // the free mask of the slabs beyond NSLAB is one 64-bit word per lane
+constexpr int NSLAB_MAX = NSLAB + 64 * 64;  // the free mask of the class-0 slabs beyond NSLAB is one 64-bit word per lane
+// free masks in HBM (u64 words of the env's aux block) of the buddy pool behind the first NSLAB pages: blocks of 1 page (class 0), 4
+// pages (class 1), 16 pages (class 2), bit b of a size's mask = block b of that size; and the env's counts (level budget | 16-page
+// blocks << 32: the cold routines read them here instead of carrying them in registers)
+constexpr int HI_W0 = 0, HI_W1 = 64, HI_W2 = 80, HI_COUNTS = 84;
+constexpr int NMID_MAX = 16 * 64, NBIG_MAX = 4 * 64;
 struct alignas(16) FarLevel { int64_t price; uint64_t meta; int64_t vol; int64_t pad; };  // meta as in Ladder
 static_assert(sizeof(FarLevel) == 32, "");
 constexpr size_t FAR_BYTES = 2 * (size_t)FAR_CAP * sizeof(FarLevel);
-constexpr size_t HI_BYTES = 1024;                  // hi_free[64] u64 + padding (slabs stay 1 KiB-aligned)
+constexpr size_t HI_BYTES = 1024;                  // hi_free[128] u64 (85 used; pages stay 1 KiB-aligned)
 constexpr size_t AUX_BYTES = FAR_BYTES + HI_BYTES;  // per env, in front of its slabs: far rings, then hi_free
 // Agent orders per env (live ones + those freed in the current step): a property of the HANDLE since round 5 (cfg.agent_orders), the
 // engine is a template on it (Eng<.., NAT>: NAT / 64 entries per lane).  What bounds the reference's internal book is VOLUME - a side
@@ -154,10 +165,11 @@ struct DevCfg {
 struct DevPtrs {
     EnvHdr* hdr;
     Ladder* ladder;
-    uint8_t* pool;     // [env]{FarLevel far[2][FAR_CAP]; u64 hi_free[64] (+pad); Slot slabs[n_slab][SLOTS]}
+    uint8_t* pool;     // [env]{FarLevel far[2][FAR_CAP]; u64 hi_free[128]; Slot pages[NSLAB + 16 n_big][64]}
     int64_t pool_stride;  // bytes per env
-    int32_t n_slab;    // slabs per env (NSLAB .. NSLAB_MAX, a multiple of 64)
+    int32_t n_slab;    // the env's budget of price levels (NSLAB .. NSLAB_MAX, a multiple of 64)
     int32_t na;        // agent entries per env (128 or 256: the NAT of the kernels this handle launches)
+    int32_t n_mid, n_big;  // n_big: 16-page blocks of the env's buddy pool (pages NSLAB .. NSLAB + 16 n_big; slabs of 1 / 4 / 16 pages are cut from it); n_mid = 4 n_big
     AgentOrd* agent;   // [env][na]
     uint16_t* apos;    // [env][na] slot index of each live agent order inside its level's slab
     uint64_t* idc;     // [env][IDC_N] position cache of external orders: tag(id) << 32 | slab << 16 | slot, direct-mapped by id

@@ -40,7 +40,7 @@ def test_header_struct_sizes_compile_time(tmp_path):
     offs = "\n".join(
         f'_Static_assert(offsetof({cname}, {f}) == {getattr(cls, f).offset}, "{cname}.{f}");'
         for cname, cls in (("lobsim_feature", _capi.FeatureDesc), ("lobsim_reward", _capi.RewardDesc), ("lobsim_cfg", _capi.Cfg),
-                           ("lobsim_env_state", _capi.EnvState), ("lobsim_order_view", _capi.OrderView))
+                           ("lobsim_env_state", _capi.EnvState), ("lobsim_order_view", _capi.OrderView), ("lobsim_limits", _capi.Limits))
         for f, _ in cls._fields_
     )  # fmt: skip
     src = tmp_path / "sizes.c"
@@ -51,6 +51,7 @@ def test_header_struct_sizes_compile_time(tmp_path):
         f'_Static_assert(sizeof(lobsim_cfg) == {C.sizeof(_capi.Cfg)}, "lobsim_cfg");\n'
         f'_Static_assert(sizeof(lobsim_env_state) == {C.sizeof(_capi.EnvState)}, "lobsim_env_state");\n'
         f'_Static_assert(sizeof(lobsim_order_view) == {C.sizeof(_capi.OrderView)}, "lobsim_order_view");\n'
+        f'_Static_assert(sizeof(lobsim_limits) == {C.sizeof(_capi.Limits)}, "lobsim_limits");\n'
         f'_Static_assert(sizeof(lobsim_feature) == 56, "documented size");\n{offs}\nint main(void) {{ return 0; }}\n'
     )
     subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", str(ROOT / "include"), "-c", str(src), "-o", str(tmp_path / "sizes.o")])

@@ -194,14 +194,17 @@ def test_batched_env_reports_why_an_env_stopped():
 
 
 def test_limits_and_default_level_budget():
-    """The default level budget is a fixed 512 per side (1024 slabs of 16 KiB per env) whatever else holds device memory, an explicit
+    """The default level budget is a fixed 512 per side (1024 levels per env) whatever else holds device memory, an explicit
     one is honoured, and lobsim_get_limits says what the handle has."""
     feats = [_capi.make_feature(_capi.F_INVENTORY, min_value=-1e6, max_value=1e6)]
     for max_levels, slabs in ((0, 1024), (64, 256), (200, 448), (2048, 4096)):
         s = _lib.new_sim(_capi.make_cfg(4, 10, feats, max_levels=max_levels))
         lim = s.limits()
         assert lim["level_slabs"] == slabs and lim["ladder_levels"] == 64 and lim["queue_slots"] == 1024 and lim["agent_orders"] in (128, 256) and lim["far_levels"] == 2048
-        assert lim["bytes_per_env"] > slabs * 16384
+        assert lim["queue_pages"] >= max(slabs, 1024 + 256)  # at least a page per level of the budget
+        assert lim["bytes_per_env"] > lim["queue_pages"] * 1024  # a level's queue: 1, 4 or 16 KiB by the orders it holds
+        if max_levels == 0:
+            assert lim["queue_pages"] == 256 + 2048 and lim["bytes_per_env"] < 2.8 * 2**20  # (16.5 MiB until round 5: every level owned 16 KiB)
         s.close()
     assert _lib.binding().fn["abi_version"]() == _capi.ABI_VERSION
 

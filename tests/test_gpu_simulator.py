@@ -133,8 +133,12 @@ def test_forward_argument_errors_and_fill_log_overflow():
     with pytest.raises(_capi.LobsimError):
         sim.reset_episode(36_000_000_001, sid)  # not on the second (OrderbookSimulator.py:61)
     sim.reset_episode(36_000_000_000, sid)
-    sim.forward(36_000_000_000)  # until == now: the reference's assert
-    assert sim.env_state(0)["status"] & _capi.ST_ASSERT
+    with pytest.raises(_capi.LobsimError, match="later than the env's clock"):
+        sim.forward(36_000_000_000)  # until == now: the reference's assert (OrderbookSimulator.py:71-73) - an exception that leaves the simulator usable
+    assert sim.env_state(0)["status"] == 0 and sim.env_state(0)["now_us"] == 36_000_000_000
+    assert len(sim.fills(0)) == 0
+    sim.forward(36_000_050_000)
+    assert sim.env_state(0)["status"] == 0 and sim.env_state(0)["now_us"] == 36_000_050_000
     sim.reset_episode(36_000_000_000, sid)
     lim = sim.limits()
     assert lim["fill_log_rows"] >= 256 and lim["level_slabs"] >= 256 and lim["queue_slots"] == 1024 and lim["agent_orders"] in (128, 256)

@@ -228,21 +228,34 @@ def test_id_suffix_order_equals_string_sort():
         assert np.array_equal(_id_suffix_order(t, ids), ref)
 
 
-def _bare_vector_env(min_date, max_date, episode_minutes, step_seconds):
+def _bare_vector_env(min_date, max_date, episode_minutes, step_seconds, n_envs=512, tickers=("SYN",)):
     """A HistoricalOrderbookVectorEnv without a device handle: enough of it for the start-time draw."""
     import pandas as pd
 
     from rl4mm_amd.env import HistoricalOrderbookVectorEnv as V
     from rl4mm_amd.trading_calendar import get_next_trading_dt
 
+    class AnyDayResidency:  # every (ticker, day) exists; ids in order of first use
+        def __init__(self):
+            self.sid = {}
+
+        def has(self, key):
+            return True
+
+        def ensure(self, keys):
+            for k in keys:
+                self.sid.setdefault(k, len(self.sid))
+            return self.sid
+
+        def trim(self, in_use):
+            pass
+
     env = V.__new__(V)
-    env.ticker, env._day_table = "SYN", None
+    env.ticker, env.tickers, env._day_table = "SYN", list(tickers), None
     env.min_date, env.max_date = min_date, max_date
     env.min_start_timedelta, env.max_end_timedelta = timedelta(hours=10), timedelta(hours=15, minutes=30)
     env.episode_length, env.step_size = timedelta(minutes=episode_minutes), timedelta(seconds=step_seconds)
-    env._stream_ids = {}
-    for d in pd.bdate_range(min_date, max_date):
-        env._stream_ids.setdefault(("SYN", get_next_trading_dt(pd.to_datetime(d).to_pydatetime()).strftime("%Y-%m-%d")), len(env._stream_ids))
+    env._residency, env._env_key, env._env_ticker = AnyDayResidency(), [None] * n_envs, np.arange(n_envs) % len(tickers)
     return env
 
 
@@ -260,7 +273,7 @@ def test_batched_start_draw_equals_per_env_reference_calls(case):
         slow = env._draw_slow(257)
         after_slow = np.random.randint(0, 1 << 30)
         np.random.seed(seed)
-        fast = env._draw(257)
+        fast = env._draw_days(257)
         assert np.array_equal(slow[0], fast[0]) and np.array_equal(slow[1], fast[1])
         assert np.random.randint(0, 1 << 30) == after_slow
     assert (fast[1] % 1_000_000 == 0).all()
@@ -431,7 +444,7 @@ def test_reset_at_resets_all_finished_envs_in_one_launch_and_keeps_the_rng_seque
             return np.zeros(16, dtype=np.int32)
 
     def fresh():
-        env = _bare_vector_env(datetime(2018, 2, 1), datetime(2018, 3, 15), 30, 0.1)
+        env = _bare_vector_env(datetime(2018, 2, 1), datetime(2018, 3, 15), 30, 0.1, n_envs=16)
         env.num_envs, env.sim, env.obs_dtype = 16, StubSim(), np.dtype(np.float64)
         env._dones, env._any_done, env._reset_cache, env.status = np.zeros(16, dtype=bool), False, {}, np.zeros(16, dtype=np.int32)
         return env
@@ -456,3 +469,127 @@ def test_reset_at_resets_all_finished_envs_in_one_launch_and_keeps_the_rng_seque
     batched.reset_at(3)
     batched.reset_at(5)
     assert [list(x) for x in batched.sim.launches[1:]] == [[3], [5]]
+
+
+def test_mixed_ticker_draw_and_stream_residency_lru():
+    """ticker=[...]: env i replays tickers[i mod T], every env draws its own day (np.random consumed in env order exactly as for one
+    ticker), and the day is looked up under the env's ticker.  Streams go to the device on first use; under a byte budget the least
+    recently drawn days that no env replays are dropped after the reset, never one an env still holds."""
+    from rl4mm_amd.env import _StreamResidency
+
+    tickers = ("AAA", "BBB", "CCC")
+    env = _bare_vector_env(datetime(2018, 2, 1), datetime(2018, 2, 14), 30, 0.1, n_envs=12, tickers=tickers)
+    np.random.seed(3)
+    day_ref, start_ref = env._draw_days(12)
+    np.random.seed(3)
+    sids, starts = env._draw(12)
+    assert np.array_equal(starts, start_ref)
+    dates = env._day_lookup()
+    ids, keys, st = env.last_draw
+    assert keys == [(tickers[i % 3], dates[int(d)]) for i, d in enumerate(day_ref)] and env._env_key == keys
+    assert [env._residency.sid[k] for k in keys] == sids.tolist()
+    # a partial reset: only those envs' keys move, np.random advances by their draws only
+    np.random.seed(9)
+    d2, _ = env._draw_days(2)
+    np.random.seed(9)
+    env._draw(2, env_ids=[4, 7])
+    assert env._env_key[4] == ("BBB", dates[int(d2[0])]) and env._env_key[7] == ("BBB", dates[int(d2[1])]) and env._env_key[5] == keys[5]
+
+    class Stream:  # what _StreamResidency touches of a PackedStream
+        def __init__(self, mb):
+            self.msgs, self.snaps = np.zeros(mb * 2**20 // 8, dtype=np.int64), np.zeros(0, dtype=np.int64)
+
+    class Catalog:
+        def get(self, ticker, date):
+            if ticker == "ZZZ":
+                raise KeyError(ticker)
+            return Stream(10)
+
+    class Sim:
+        def __init__(self):
+            self.live, self.log = {}, []
+
+        def add_stream(self, stream):
+            sid = min(set(range(len(self.live) + 1)) - set(self.live))  # the lowest free slot, like lobsim_add_stream
+            self.live[sid] = stream
+            self.log.append(("add", sid))
+            return sid
+
+        def drop_stream(self, sid):
+            del self.live[sid]
+            self.log.append(("drop", sid))
+
+    sim = Sim()
+    res = _StreamResidency(sim, Catalog(), budget_bytes=35 * 2**20)  # room for three 10 MB days
+    assert res.has(("AAA", "2018-02-01")) and not res.has(("ZZZ", "2018-02-01"))
+    a, b, c, d, e = [("AAA", f"2018-02-0{i}") for i in range(1, 6)]
+    assert res.ensure([a, b, c]) == {a: 0, b: 1, c: 2}
+    res.trim({a, b, c})
+    assert len(sim.live) == 3 and res.drops == 0
+    res.ensure([d, a])  # a fourth day: over budget until the trim
+    assert len(sim.live) == 4
+    res.trim({a, d, c})  # b is the only one nobody holds
+    assert sorted(res.sid) == sorted([a, c, d]) and ("drop", 1) in sim.log and res.resident_bytes == 30 * 2**20
+    assert res.ensure([e])[e] == 1  # the freed slot is handed out again
+    res.trim({a, c, d, e})  # all in use: the budget is exceeded rather than a stream pulled from under an env
+    assert len(sim.live) == 4 and res.drops == 1
+    res.trim({e})  # least recently used first: c (drawn at clock 1), then a and d (clock 2) until it fits
+    assert e in res.sid and len(res.sid) == 3 and c not in res.sid
+
+
+def test_default_device_id_spreads_rollout_workers_over_gpus(monkeypatch):
+    """env_creator's device: RLlib's EnvContext.worker_index (1 .. num_workers for remote workers) modulo the visible GPUs, else
+    LOCAL_RANK, else 0 (rl4mm/helpers/main_helper.py:262-263 sets num_workers; the reference's envs are CPU objects and need none)."""
+    import torch
+
+    from rl4mm_amd.env import default_device_id
+
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+
+    class Ctx(dict):
+        worker_index = 0
+
+    assert default_device_id({}) == 0 and default_device_id(None) == 0
+    ctx = Ctx()
+    assert default_device_id(ctx) == 0
+    for w, dev in ((1, 0), (2, 1), (8, 7), (9, 0), (12, 3)):
+        ctx.worker_index = w
+        assert default_device_id(ctx) == dev
+    assert default_device_id({"worker_index": 3}) == 2
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    assert default_device_id({}) == 5
+    ctx.worker_index = 2
+    assert default_device_id(ctx) == 1  # the worker index wins
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    assert default_device_id(ctx) == 0 and default_device_id({}) == 0
+
+
+def test_array_path_output_pool_never_reuses_memory_the_caller_still_holds():
+    """the output pool of vector_step_arrays(copy=True) decides by weak references to the arrays it handed out, not by
+    reference counts: while the caller holds an array - or any view, slice or reshape of one - its memory is not handed out again."""
+    from rl4mm_amd.env import HistoricalOrderbookVectorEnv as V
+
+    class S:
+        obs_dim = 3
+
+    env = V.__new__(V)
+    env.num_envs, env.sim, env._out_pool = 4, S(), []
+    o1, r1, d1 = env._out_buffers(np.dtype(np.float64))
+    o1[:] = 1.0
+    keep = o1[2]  # a view only
+    del o1, r1, d1
+    o2, r2, d2 = env._out_buffers(np.dtype(np.float64))
+    o2[:] = 2.0
+    assert keep.tolist() == [1.0, 1.0, 1.0] and len(env._out_pool) == 2  # the first buffer is still referenced through the view
+    del keep, o2, r2, d2
+    o3, _, _ = env._out_buffers(np.dtype(np.float64))
+    assert len(env._out_pool) == 2 and o3.shape == (4, 3)  # recycled
+    flat = o3.reshape(-1)
+    del o3
+    o4, _, _ = env._out_buffers(np.dtype(np.float64))
+    o4[:] = 4.0
+    flat[:] = 3.0
+    assert (o4 == 4.0).all()  # (a reshape kept o3's memory out of the pool)
+    o5, _, _ = env._out_buffers(np.dtype(np.float32))
+    assert o5.dtype == np.float32 and o5.shape == (4, 3)

@@ -15,15 +15,16 @@ if os.environ.get("PROF_LIB"): so = ROOT / os.environ["PROF_LIB"]  # prebuilt in
 else: _lib.compile_library(so, ["-DLOBSIM_PROFILE", *(["-DLOBSIM_PROFILE_MSG"] if "msg" in sys.argv else [])])
 b = _capi.Binding(so)
 N = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 4096
-K = 120
+K = int(os.environ.get("TP_K", 120))
+SKIP = int(os.environ.get("TP_SKIP", 20))  # launches before the ones that are analysed (TP_SKIP=500 TP_K=600: steps 500 - 600 after the reset)
 cfg = _capi.make_cfg(N, 10, bench.default_features(_capi), step_us=100_000, episode_us=1_800_000_000)
 sim = _capi.Sim(b, cfg)
-ps = bench.build_stream(60)
+ps = bench.build_stream(max(60, K // 10 + 10))
 sim.add_stream(ps); sim.set_portfolio(0, 10**12)
 starts = (36_000 + np.random.default_rng(1).integers(0, 60, size=N)) * 1_000_000
 sim.reset(starts, 0)
 dev = torch.device("cuda", 0)
-acts = torch.from_numpy(np.random.default_rng(2).uniform(0, 10, size=(K, N, 4))).to(dev)
+acts = torch.from_numpy(np.random.default_rng(2).uniform(0, 10, size=(min(K, 200), N, 4))).to(dev)
 obs = torch.zeros((N, sim.obs_dim), dtype=torch.float64, device=dev)
 reward = torch.zeros(N, dtype=torch.float64, device=dev); done = torch.zeros(N, dtype=torch.uint8, device=dev)
 out = np.zeros((N, 8), dtype=np.uint64)
@@ -33,11 +34,11 @@ tus = ps.msgs[:, 0]
 names = ["load_env", "build_ops", "agent_ops", "messages+resync", "features+reward", "outputs+store"]
 rows = []
 for t in range(K):
-    sim.step_device(acts[t].data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr(), 0)
+    sim.step_device(acts[t % acts.shape[0]].data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr(), 0)
     b.lib.lobsim_prof_read(sim.h, out.ctypes.data, 1)
     evb = np.zeros((N, 16), dtype=np.uint64)
     if "msg" not in sys.argv: b.lib.lobsim_prof_read_messages(sim.h, evb.ctypes.data, 1)
-    if t < 20: continue
+    if t < SKIP: continue
     ph = out[:, :6].astype(np.float64)
     tot = ph.sum(axis=1)
     lo, hi = starts + t * 100_000, starts + (t + 1) * 100_000
