@@ -36,7 +36,7 @@ HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md
 ENVS_PER_GPU = 4096
 STEP_US = 100_000
 EPISODE_US = 1_800_000_000  # 30 min, the reference default
-PROFILE_ROUND = "r4"
+PROFILE_ROUND = "r5"
 REPEATS = 5  # timed regions of --steps steps per invocation; `value` is the median region
 
 WORKLOADS = {
@@ -44,6 +44,7 @@ WORKLOADS = {
     "teradactyl": "4096 envs per GPU, synthetic 10-level SPY-shaped stream, on-device Teradactyl rule-based agent, PnL reward (BASELINE.json configs[2] shape; real SPY 2018-02-21 data absent)",
     "ad": "4096 envs per GPU, synthetic 10-level stream, random actions, AD (asymmetrically dampened) per-step reward (BASELINE.json configs[3] shard)",
     "deep50": "8192 envs per GPU, 50-level books, 4 tickers at 50/150/300/600 msg/s, 100 ms snapshots (BASELINE.json configs[4] shard)",
+    "rs": "4096 envs per GPU, synthetic 10-level stream, random actions, RollingSharpe per-step and terminal reward (env_config -psr RS: the kernel variants that carry RollingSharpe / normalisation)",
 }
 DEEP50_RATES = (50.0, 150.0, 300.0, 600.0)
 TERADACTYL_PARAMS = [1000, 10.0, 0.5, 10.0, 1.0, 5, 0, 1000]  # max_inventory, kappa, omega, max_kappa, exponent, inventory feature index, no MOC, denom
@@ -164,6 +165,8 @@ def workload_cfg(capi, workload, n_envs, device_id=0, ladder_levels=0, agent_ord
     kw = dict(step_us=STEP_US, episode_us=EPISODE_US, device_id=device_id, ladder_levels=ladder_levels, agent_orders=agent_orders)
     if workload == "ad":  # get_reward_function("AD"), rl4mm/gym/utils.py:29-39
         kw.update(per_step_reward=(capi.R_INVENTORY_ADJUSTED, 1, 0.1), terminal_reward=(capi.R_INVENTORY_ADJUSTED, 1, 0.1))
+    if workload == "rs":  # get_reward_function("RS"): RollingSharpe(max_window_size=120, min_window_size=60)
+        kw.update(per_step_reward=(capi.R_ROLLING_SHARPE, 0, 0.0, 120, 60), terminal_reward=(capi.R_ROLLING_SHARPE, 0, 0.0, 120, 60))
     return capi.make_cfg(n_envs, 50 if workload == "deep50" else 10, default_features(capi), **kw)
 
 
@@ -181,6 +184,8 @@ def pmc_traffic(workload, n_envs):
     run).  FETCH_SIZE / WRITE_SIZE are in KB per dispatch; on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes
     for wide reads, so it is doubled (MI355X_MICROARCH.md, HBM section): an upper bound for this kernel's mix of
     8- and 16-byte-per-lane loads.  None when the file is absent or was taken at another batch size / workload."""
+    if os.environ.get("LOBSIM_GENERIC_KERNELS"):
+        workload = "generic" if workload == "random" else workload + "_generic"
     f = ROOT / "profiles" / PROFILE_ROUND / ("pmc_step_kernel.csv" if workload == "random" else f"pmc_step_kernel_{workload}.csv")
     try:
         rows = {r.split(",")[1]: float(r.split(",")[2]) for r in f.read_text().splitlines()[1:] if r.count(",") >= 3}
@@ -345,6 +350,10 @@ def facade_leg(sim, stream, n_envs, device_id, steps=60):
     venv.vector_reset_tensors()
     with torch.cuda.stream(torch.cuda.Stream(device=torch.device("cuda", device_id))):
         out["vector_step_tensors_f32_obs"] = rate(lambda t: venv.vector_step_tensors(d_acts[t]), sync=torch.cuda.synchronize)
+    try:
+        out["closed_loop"] = closed_loop_leg(venv, n_envs, device_id)
+    except Exception as e:  # noqa: BLE001  (a stretch entry: never the reason a bench line is lost)
+        out["closed_loop"] = {"error": repr(e)[:300]}
     venv.close()
     # RLlib's episode boundary: every env finishes on the same step, then reset_at(i) for each
     short = E.HistoricalOrderbookVectorEnv(
@@ -360,6 +369,93 @@ def facade_leg(sim, stream, n_envs, device_id, steps=60):
         short.reset_at(i)
     out["reset_at_all_ms"] = (time.perf_counter() - t0) * 1e3
     short.close()
+    return out
+
+
+def closed_loop_leg(venv, n_envs, device_id, steps=200):
+    """The rate a learner on the GPU sees (reported beside `value`, never as it; outside SURVEY 8's rows): a 2 x 256 tanh MLP policy
+    (the reference's PPO default, rl4mm/helpers/main_helper.py:253-300: fcnet_hiddens [256, 256]) between vector_step_tensors calls -
+    observation f32 [N, D] -> Beta parameters f64 [N, 4] in (0, 10) -> env step - once as eager torch calls on a side stream, once
+    with policy + step captured in ONE hipGraph and replayed."""
+    import torch
+
+    dev = torch.device("cuda", device_id)
+    D = venv.sim.obs_dim
+    torch.manual_seed(0)
+    policy = torch.nn.Sequential(torch.nn.Linear(D, 256), torch.nn.Tanh(), torch.nn.Linear(256, 256), torch.nn.Tanh(), torch.nn.Linear(256, 4)).to(dev)
+    lo = torch.as_tensor(venv.observation_space.low, device=dev)
+    span = torch.clamp(torch.as_tensor(venv.observation_space.high, device=dev) - lo, min=1e-6)
+    act = torch.full((n_envs, 4), 1.0, dtype=torch.float64, device=dev)
+
+    def think(obs):  # -> writes the next action batch in place
+        with torch.no_grad():
+            x = (obs.float() - lo) / span
+            act.copy_(torch.sigmoid(policy(x)).double() * 10.0)
+
+    out = {}
+    s = torch.cuda.Stream(device=dev)
+    venv.vector_reset_tensors()
+    with torch.cuda.stream(s):
+        obs, _, _ = venv.vector_step_tensors(act)  # binds the handle to the stream
+        for _ in range(5):
+            think(obs)
+            obs, _, _ = venv.vector_step_tensors(act)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            think(obs)
+            obs, _, _ = venv.vector_step_tensors(act)
+        torch.cuda.synchronize()
+        out["eager"] = n_envs * steps / (time.perf_counter() - t0)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        think(obs)
+        venv.vector_step_tensors(act)
+    for _ in range(5):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    torch.cuda.synchronize()
+    out["hip_graph"] = n_envs * steps / (time.perf_counter() - t0)
+    out["note"] = "2 x 256 tanh MLP (f32) -> sigmoid x 10 -> f64 actions -> vector_step_tensors (f32 observations), per env-step of the closed loop; done envs are skipped on the device, none finishes inside the leg"
+    return out
+
+
+def facade_tensor_leg(streams, n_envs, device_id, n_levels, steps=60):
+    """The batched env over SEVERAL tickers through the Python boundary (configs[4]: mixed tickers in one batch):
+    HistoricalOrderbookVectorEnv(ticker=[...]).vector_step_tensors, env i on ticker i mod T, the rate-ordered launch picked by the library."""
+    from datetime import datetime, timedelta
+
+    import torch
+
+    from rl4mm_amd import env as E
+
+    cat = E.StreamCatalog()
+    for s in streams:
+        cat.add(s)
+    day = datetime.strptime(streams[0].trading_date, "%Y-%m-%d")
+    venv = E.HistoricalOrderbookVectorEnv(
+        n_envs, cat, ticker=[s.ticker for s in streams] if len(streams) > 1 else streams[0].ticker, n_levels=n_levels, min_date=day, max_date=day,
+        min_start_timedelta=timedelta(hours=10), max_end_timedelta=timedelta(hours=10, minutes=31), episode_length=timedelta(minutes=30),
+        initial_portfolio=E.Portfolio(inventory=0, cash=10**12), per_step_reward_function=E.PnL(), terminal_reward_function=E.PnL(), device_id=device_id, obs_dtype=np.float32)  # fmt: skip
+    np.random.seed(11)
+    dev = torch.device("cuda", device_id)
+    d_acts = torch.from_numpy(np.random.Generator(np.random.PCG64(7)).uniform(0, 10, size=(steps + 5, n_envs, 4))).to(dev)
+    t0 = time.perf_counter()
+    venv.vector_reset_tensors()
+    out = {"unit": "env-steps/s", "envs": n_envs, "tickers": len(streams), "vector_reset_ms": (time.perf_counter() - t0) * 1e3, "limits": venv.limits}
+    with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+        for t in range(5):
+            venv.vector_step_tensors(d_acts[t])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(5, 5 + steps):
+            venv.vector_step_tensors(d_acts[t])
+        torch.cuda.synchronize()
+        out["vector_step_tensors_f32_obs"] = n_envs * steps / (time.perf_counter() - t0)
+    venv.close()
     return out
 
 
@@ -427,6 +523,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=REPEATS, help="timed regions of --steps steps; `value` is the median region")
     ap.add_argument("--ladder-levels", type=int, default=0, help="price levels per side kept on chip (0 = the library's choice: 64 for books of <= 56 visible levels, else 128)")
     ap.add_argument("--agent-orders", type=int, default=0, help="the env's table of live agent orders: 0 = the library's default (256: cannot overflow), 128 = the smaller, faster table (cfg.agent_orders)")
+    ap.add_argument("--generic-kernels", action="store_true", help="run the default configuration through the GENERIC kernels (what any non-default env_config runs) instead of the ones specialised for it")
     ap.add_argument("--no-facade", action="store_true", help="skip the Python-boundary leg (VectorEnv.vector_step_arrays, host-pointer lobsim_step)")
     # multi-rank readiness on a ONE-GPU box (tests/test_gpu_multirank.py): every rank uses device 0; RCCL refuses two ranks on one
     # device, so the collectives of that mode run over gloo on host copies - the rank body, sharding, seeding, timing harness and
@@ -437,6 +534,8 @@ def main():
     args = ap.parse_args()
     if args.envs is None:
         args.envs = 8192 if args.workload == "deep50" else ENVS_PER_GPU
+    if args.generic_kernels:
+        os.environ["LOBSIM_GENERIC_KERNELS"] = "1"  # (read by lobsim_create)
 
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline_child(args.workload, args.cpu_budget)))
@@ -574,14 +673,17 @@ def main():
         sample = range(0, N, max(1, N // 64))
         st_bad = sum(sim.env_state(int(e))["status"] != 0 for e in sample)
         traffic, traffic_src = pmc_traffic(wl, N)
-        kernel = "lob_step_kernel"  # (Teradactyl: lobsim_rollout_device with T = 1 runs the step kernel, the policy in its prologue)
+        lim = sim.limits()
+        kernel = "lob_step_kernel<%s, %d, %d, %s>" % ("true" if wl == "rs" else "false", lim["ladder_levels"], lim["agent_orders"],
+                                                     "false" if (wl == "rs" or os.environ.get("LOBSIM_GENERIC_KERNELS")) else "true")  # <EXTRAS, ladder, agent table, SPEC>
+        # (Teradactyl: lobsim_rollout_device with T = 1 runs the step kernel, the policy in its prologue)
         out = {
             "metric": "env-steps/sec (batched LOB sims)", "value": world * N * K / elapsed, "unit": "env-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, **region_stats, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int64+f64", "data": "synthetic",
             "config": {
                 "workload": WORKLOADS[wl], "envs_per_gpu": N, "global_envs": world * N, "features": "full_state (10 default features, 5 min warm-up)",
-                "agent_orders": sim.limits()["agent_orders"], "step_size_s": 0.1, "reward": "AD" if wl == "ad" else "PnL", "messages_per_env_step": round(m_bar, 2), "messages_per_s": round(world * N * K / elapsed * m_bar), "parallelism": f"env-sharded x{world}",
+                "agent_orders": lim["agent_orders"], "device_bytes_per_env": lim["bytes_per_env"], "step_size_s": 0.1, "reward": "AD" if wl == "ad" else "RS" if wl == "rs" else "PnL", "messages_per_env_step": round(m_bar, 2), "messages_per_s": round(world * N * K / elapsed * m_bar), "parallelism": f"env-sharded x{world}",
                 "reset_seconds": round(reset_s, 3), "envs_in_error_state_sampled": int(st_bad), "nan_returns": n_bad,
                 "ranks": world, "ms_per_step_per_rank": [round(x, 5) for x in per_rank_ms], "gathered_returns": int(all_returns.numel()),
             },
@@ -605,6 +707,9 @@ def main():
             out["config"]["collective_backend"] = out["config"].get("collective_backend", f"{dist.get_backend()} (RCCL)" if dist.get_backend() == "nccl" else dist.get_backend())
         if world == 1 and wl == "random" and not args.no_facade:
             out["facade"] = facade_leg(sim, streams[0], N, local_rank)
+        if world == 1 and wl == "deep50" and not args.no_facade:
+            sim.close()  # (two 8192-env handles of 50-level books at once would be 2 x 22 GB: fine, but the first one is done)
+            out["facade"] = facade_tensor_leg(streams, N, local_rank, 50)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_budget)
         print(json.dumps(out))

@@ -245,9 +245,18 @@ SDI int m_head(uint64_t m) { return (int)((m >> 16) & 0xffff); }
 SDI int m_tail(uint64_t m) { return (int)((m >> 32) & 0xffff); }
 SDI int m_live(uint64_t m) { return (int)(m >> 48); }
 // the slab a meta word (or a position-cache entry) names: class << 14 | first page (lobsim_layout.h)
+#ifndef LOBSIM_FLAT_SLABS
+#define LOBSIM_FLAT_SLABS 0  // 1 (diagnostic builds only): round 4's layout - every level owns a fixed 16 KiB slab - under round 5's code, to tell what the layout costs from what the code costs
+#endif
+#if LOBSIM_FLAT_SLABS
+SDI int slab_cap(int slab) { return SLOTS; }
+SDI int m_cap(uint64_t m) { return SLOTS; }
+template <typename T> SDI T* slab_ptr(T* slots, int slab) { return slots + (size_t)slab * SLOTS; }
+#else
 SDI int slab_cap(int slab) { return PAGE_SLOTS << (2 * (slab >> SLAB_CLASS_SHIFT)); }  // 64 / 256 / 1024 slots
 SDI int m_cap(uint64_t m) { return slab_cap(m_slab(m)); }
 template <typename T> SDI T* slab_ptr(T* slots, int slab) { return slots + (size_t)(slab & SLAB_PAGE_MASK) * PAGE_SLOTS; }
+#endif
 
 // wave-uniform scalars of the env being advanced (kept in registers)
 template <typename T>
@@ -467,6 +476,10 @@ SDI int slab_alloc_cls(Slot* slots, int cls) {
     uint64_t* w = hi_free_words(slots);
     cls = uni(cls);
     int b = -1;
+#if LOBSIM_FLAT_SLABS
+    b = buddy_take(w, HI_W0, 64);
+    return b < 0 ? -1 : NSLAB + b;
+#endif
     if (cls == 0) {
         b = buddy_take(w, HI_W0, 64);
         if (b < 0) {
@@ -503,6 +516,11 @@ SDI int slab_alloc_larger(Slot* slots, int cls) {
 SDI void slab_release(Lds& L, Slot* slots, int slab) {  // (inside the cold routines)
     if (slab < NSLAB) { mask_set(L.slab_free, slab); return; }
     uint64_t* w = hi_free_words(slots);
+#if LOBSIM_FLAT_SLABS
+    if (lane() == 0) w[HI_W0 + ((slab - NSLAB) >> 6)] |= 1ull << ((slab - NSLAB) & 63);
+    wsync();
+    return;
+#endif
     int cls = uni(slab >> SLAB_CLASS_SHIFT);
     int b = ((slab & SLAB_PAGE_MASK) - NSLAB) >> (2 * cls);
     for (;;) {  // free block b of size class cls; four free siblings merge into their parent
@@ -707,7 +725,11 @@ SDI bool ladder_insert(Lds& L, Scal& S, int side, int pos, int64_t price) {
     EVENT(ev_ladder);
     if (!(LOBSIM_FAR && LOBSIM_FAR_EVICT) && n >= LV) { S.status |= LOBSIM_ST_LEVEL_OVERFLOW; return false; }
     int slab = mask_take_first(L.slab_free);
-    if (UNLIKELY(n >= LV || slab < 0 || S.n_lv[side ^ 1] >= LV)) {  // (either side full: far levels may exist, the level budget is checked)
+#ifdef LOBSIM_X_SIDECHK
+    if (UNLIKELY(n >= LV || slab < 0)) {
+#else
+    if (UNLIKELY(n >= LV || slab < 0 || S.n_lv[side ^ 1] >= LV)) {
+#endif  // (either side full: far levels may exist, the level budget is checked)
         int r = LOBSIM_ST_LEVEL_OVERFLOW << 16;
         if (LOBSIM_FAR && LOBSIM_FAR_EVICT) r = ladder_insert_cold(L, S.slots, side, n >= LV ? 1 : 0, slab, S.n_lv[0] + S.n_lv[1]);
         if (r >> 16) { S.status |= r >> 16; return false; }
@@ -862,20 +884,31 @@ SDI uint64_t compact_level(Lds& L, Scal& S, int side, int idx, uint64_t m, int d
 // level; the stale levels a drifting price leaves behind never do), a four-page level (256 slots) of which three quarters are LIVE
 // orders.  A thick book's levels of ~180 orders stay in four pages (squeezed every ~75 removals instead of every 128) - sixteen pages
 // each would exhaust the pool on a day that leaves hundreds of them behind.  Returns the new meta word (the caller stores it).
+// "Nearly full" counts as full (LOBSIM_ROOM slots before the end): the lane-parallel pass books a window's appends only into levels
+// that have room for all of them, and every append it has to leave to the serial routines cuts the pass short (~6k cycles) - so the
+// first serial append that finds a level nearly full makes room at once, instead of the next eight doing the same.
+#ifndef LOBSIM_ROOM
+#define LOBSIM_ROOM 24
+#endif
+SDI bool nearly_full(uint64_t m) { return m_tail(m) + LOBSIM_ROOM > m_cap(m); }
 SDI uint64_t make_room(Lds& L, Scal& S, int side, int idx, uint64_t m) {
     const int slab = m_slab(m), cap = slab_cap(slab), cls = slab >> SLAB_CLASS_SHIFT;
     int dst = -1;
-    const bool grow = cls == 0 ? m_tail(m) >= cap - 1 : m_live(m) * 4 > cap * 3;
-    if (UNLIKELY(cls < 2 && grow)) dst = slab_alloc_larger(S.slots, cls);
+    const bool grow = cls == 0 ? m_tail(m) + LOBSIM_ROOM > cap : m_live(m) * 4 > cap * 3;
+    if (UNLIKELY(!LOBSIM_FLAT_SLABS && cls < 2 && grow)) dst = slab_alloc_larger(S.slots, cls);
     const uint64_t nm = compact_level(L, S, side, idx, m, dst);
     if (UNLIKELY(dst >= 0)) slab_release(L, S.slots, slab);
     return nm;
 }
 
 SDI void level_append(Lds& L, Scal& S, int side, int idx, int64_t id, int32_t vol, int32_t kind, uint64_t m) {
-    if (m_tail(m) == m_cap(m) || m_tail(m) - m_head(m) - m_live(m) >= LOBSIM_TOMB) {  // full, or two chunks' worth of tombstones
-        m = make_room(L, S, side, idx, m);
-        if (m_tail(m) == m_cap(m)) { S.status |= LOBSIM_ST_QUEUE_OVERFLOW; return; }
+    {
+        const int tombs = m_tail(m) - m_head(m) - m_live(m);
+        // two chunks' worth of tombstones, or (nearly) full with something to gain: tombstones to squeeze out, or a larger slab to move to
+        if (tombs >= LOBSIM_TOMB || (nearly_full(m) && (tombs > 0 || m_cap(m) < SLOTS))) {
+            m = make_room(L, S, side, idx, m);
+            if (m_tail(m) == m_cap(m)) { S.status |= LOBSIM_ST_QUEUE_OVERFLOW; return; }
+        } else if (m_tail(m) == m_cap(m)) { S.status |= LOBSIM_ST_QUEUE_OVERFLOW; return; }
     }
     int tail = m_tail(m), live = m_live(m);
     if (lane() == 0) {
@@ -913,7 +946,7 @@ SDI void squeeze_ahead(Lds& L, Scal& S) {
             if (i < S.n_lv[sd]) {
                 const uint64_t m = L.meta[sd][i];
                 const int t = m_tail(m) - m_head(m) - m_live(m);
-                due = t >= LOBSIM_TOMB_AHEAD || (t >= 16 && m_tail(m) > m_cap(m) - 32);  // (or its slab is nearly full and a squeeze would make room)
+                due = t >= LOBSIM_TOMB_AHEAD || (nearly_full(m) && (t >= 16 || m_cap(m) == PAGE_SLOTS));  // (or its slab is nearly full and a squeeze / a move would make room)
             }
             const uint64_t b = ballot(due);
             if (b && side < 0) { side = sd; idx = 64 * r + ffs64(b); }
@@ -1681,9 +1714,9 @@ SDI void ladder_clear(Lds& L, Scal& S, const DevPtrs& P) {
     S.ladder_ver = 0;
     if (lane() < 2) { L.far_n[lane()] = 0; L.far_front[lane()] = 0; }
     uint64_t* hw = hi_free_words(S.slots);
-    hw[HI_W0 + lane()] = 0;  // the buddy pool (slab_alloc_cls): all of it free as 16-page blocks, none split yet
+    hw[HI_W0 + lane()] = LOBSIM_FLAT_SLABS ? mask_word(P.n_slab - NSLAB, lane()) : 0;  // the buddy pool (slab_alloc_cls): all of it free as 16-page blocks, none split yet
     if (lane() < NMID_MAX / 64) hw[HI_W1 + lane()] = 0;
-    if (lane() < NBIG_MAX / 64) hw[HI_W2 + lane()] = mask_word(P.n_big, lane());
+    if (lane() < NBIG_MAX / 64) hw[HI_W2 + lane()] = LOBSIM_FLAT_SLABS ? 0 : mask_word(P.n_big, lane());
     if (lane() == 0) hw[HI_COUNTS] = (uint64_t)P.n_slab | ((uint64_t)P.n_big << 32);  // (n_slab: the env's budget of price levels, ladder_insert_cold)
     if (lane() < NSLAB / 64) L.slab_free[lane()] = ~0ull;
     if (lane() < NA / 64) { L.agent_free[lane()] = ~0ull; L.agent_pending[lane()] = 0; }
@@ -1873,9 +1906,14 @@ SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt,
     bool cross = false;
     if (is_lim && S.n_lv[side ^ 1] > 0) { const int64_t bp = L.price[side ^ 1][0]; cross = side == LOBSIM_BUY ? b.price >= bp : b.price <= bp; }
     // (room: every limit order of the pass could land on this lane's level)
+#ifdef LOBSIM_X_NLIM
+    const bool plain = is_lim && vol64 > 0 && vol64 < (1ll << 31) && li >= 0 && !cross && m_live(m) > 0 &&
+                       m_tail(m) <= SLOTS - WAVE && m_tail(m) - m_head(m) - m_live(m) < LOBSIM_TOMB;
+#else
     const int n_lim = popc64(ballot(is_lim));
     const bool plain = is_lim && vol64 > 0 && vol64 < (1ll << 31) && li >= 0 && !cross && m_live(m) > 0 &&
                        m_tail(m) + n_lim <= m_cap(m) && m_tail(m) - m_head(m) - m_live(m) < LOBSIM_TOMB;
+#endif
     const uint64_t stop = ballot(in && !(plain || is_rem));
     seg_end = stop ? ffs64(stop) : cnt;
     const bool app = plain && ln < seg_end;

@@ -57,3 +57,23 @@ def test_one_rank_under_torchrun_goes_through_rccl(tmp_path):
     assert line["n_gpus"] == 1 and line["config"]["collective_backend"].startswith("nccl") and line["config"]["gathered_returns"] == 512
     plain, ret_plain = _bench([], tmp_path, "plain")
     assert np.array_equal(np.load(out), ret_plain)
+
+
+def test_every_visible_gpu_runs_a_rank_when_there_is_more_than_one(tmp_path):
+    """On a node with N > 1 GPUs (the driver's 8-GPU node; skipped on the one-GPU test box, and not a request for a node): `bench.py
+    --gpus N` as the driver launches it - one rank per GPU, RCCL over xGMI for the barriers, the MAX all-reduce and the episode-return
+    gather - must report N per-rank times, N x envs gathered returns, and every rank's returns must equal a single-rank run with that
+    rank's seeds (envs are independent: SURVEY 8e).  No scaling figure is asserted - the curve is the driver's to measure."""
+    import torch
+
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("one GPU visible: the N > 1 RCCL path needs a multi-GPU node (covered by gloo at world size 2 / 8 on CPU and by two ranks sharing this GPU)")
+    line, returns = _bench(["--gpus", str(n)], tmp_path, "all")
+    assert line["n_gpus"] == n and line["config"]["ranks"] == n and len(line["config"]["ms_per_step_per_rank"]) == n
+    assert line["config"]["gathered_returns"] == n * 512 and line["config"]["collective_backend"].startswith("nccl")
+    assert line["config"]["envs_in_error_state_sampled"] == 0 and line["config"]["nan_returns"] == 0 and line["scaling"] == "weak"
+    assert line["value"] == pytest.approx(n * 512 / (line["ms_per_step"] * 1e-3), rel=1e-6)
+    for r in sorted({0, 1, n - 1}):
+        one, ret_r = _bench(["--seed-rank", str(r)], tmp_path, f"solo{r}")
+        assert np.array_equal(returns[512 * r : 512 * (r + 1)], ret_r), f"rank {r}: returns differ from a single-rank run with its seeds"

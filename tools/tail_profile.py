@@ -14,15 +14,18 @@ so.parent.mkdir(exist_ok=True)
 if os.environ.get("PROF_LIB"): so = ROOT / os.environ["PROF_LIB"]  # prebuilt in the build container: tools/build_variant.sh prof -DLOBSIM_PROFILE
 else: _lib.compile_library(so, ["-DLOBSIM_PROFILE", *(["-DLOBSIM_PROFILE_MSG"] if "msg" in sys.argv else [])])
 b = _capi.Binding(so)
-N = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 4096
+WL = os.environ.get("TP_WORKLOAD", "random")  # a bench.py workload: random / ad / rs / deep50 (TP_GENERIC=1: the generic kernels)
+if os.environ.get("TP_GENERIC"): os.environ["LOBSIM_GENERIC_KERNELS"] = "1"
+N = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else (8192 if WL == "deep50" else 4096)
 K = int(os.environ.get("TP_K", 120))
 SKIP = int(os.environ.get("TP_SKIP", 20))  # launches before the ones that are analysed (TP_SKIP=500 TP_K=600: steps 500 - 600 after the reset)
-cfg = _capi.make_cfg(N, 10, bench.default_features(_capi), step_us=100_000, episode_us=1_800_000_000)
+cfg = bench.workload_cfg(_capi, WL, N, agent_orders=int(os.environ.get("TP_AGENT_ORDERS", 0)))
 sim = _capi.Sim(b, cfg)
-ps = bench.build_stream(max(60, K // 10 + 10))
-sim.add_stream(ps); sim.set_portfolio(0, 10**12)
-starts = (36_000 + np.random.default_rng(1).integers(0, 60, size=N)) * 1_000_000
-sim.reset(starts, 0)
+streams = bench.build_streams(WL, max(60, K // 10 + 10))
+for st in streams: sim.add_stream(st)
+sim.set_portfolio(0, 10**12)
+starts, sids = bench.workload_starts(WL, N, len(streams), 1)
+sim.reset(starts, sids)
 dev = torch.device("cuda", 0)
 acts = torch.from_numpy(np.random.default_rng(2).uniform(0, 10, size=(min(K, 200), N, 4))).to(dev)
 obs = torch.zeros((N, sim.obs_dim), dtype=torch.float64, device=dev)
@@ -30,7 +33,7 @@ reward = torch.zeros(N, dtype=torch.float64, device=dev); done = torch.zeros(N, 
 out = np.zeros((N, 8), dtype=np.uint64)
 b.lib.lobsim_prof_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 b.lib.lobsim_prof_read_messages.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-tus = ps.msgs[:, 0]
+tus_of = [st.msgs[:, 0] for st in streams]
 names = ["load_env", "build_ops", "agent_ops", "messages+resync", "features+reward", "outputs+store"]
 rows = []
 for t in range(K):
@@ -42,7 +45,10 @@ for t in range(K):
     ph = out[:, :6].astype(np.float64)
     tot = ph.sum(axis=1)
     lo, hi = starts + t * 100_000, starts + (t + 1) * 100_000
-    nmsg = np.searchsorted(tus, hi, side="right") - np.searchsorted(tus, lo, side="right")
+    nmsg = np.zeros(N, dtype=np.int64)
+    for k, tus in enumerate(tus_of):
+        mk = sids == k
+        nmsg[mk] = np.searchsorted(tus, hi[mk], side="right") - np.searchsorted(tus, lo[mk], side="right")
     sec_cross = (hi // 1_000_000) != (lo // 1_000_000)
     order = np.argsort(tot)
     i = order[-1]
@@ -53,7 +59,8 @@ if "rows" in sys.argv:  # the slowest env of each launch, one line per launch
     for r in rows[:40]:
         print("%6d | %s | %2d | %s | %s" % (r["max"], " ".join("%5d" % x for x in r["ph_max"]), r["n_max"], " ".join("%2d" % x for x in r["ev_max"]), " ".join("%2d" % x if k not in (2, 3, 7, 8, 9) else "%5d" % x for k, x in enumerate(r["sub_max"][:10]))))
 A = lambda k: np.array([r[k] for r in rows])
-print(f"{N} envs, {len(rows)} launches: wave cycles  mean {A('mean').mean():.0f}  p50 {A('p50').mean():.0f}  p99 {A('p99').mean():.0f}  p99.9 {A('p999').mean():.0f}  MAX {A('max').mean():.0f}")
+print(f"workload {WL}{' (generic kernels)' if os.environ.get('TP_GENERIC') else ''}, limits {sim.limits()}")
+print(f"{N} envs, {len(rows)} launches (steps {SKIP} .. {K} after the reset): wave cycles  mean {A('mean').mean():.0f}  p50 {A('p50').mean():.0f}  p99 {A('p99').mean():.0f}  p99.9 {A('p999').mean():.0f}  MAX {A('max').mean():.0f}")
 print(f"messages in the slowest env {A('n_max').mean():.1f} (mean env {A('n_mean').mean():.1f}, busiest env {A('n_top').mean():.1f})")
 pm, pa = np.array([r['ph_max'] for r in rows]).mean(axis=0), np.array([r['ph_mean'] for r in rows]).mean(axis=0)
 for k, n in enumerate(names): print(f"  {n:18s} slowest env {pm[k]:8.0f}   mean env {pa[k]:8.0f}")
