@@ -184,6 +184,13 @@ static constexpr int HALVES = LVT / 64;  // ladder entries per lane
 static constexpr int NA = NAT;
 static constexpr int OPS_MAX = na_ops_max(NAT);
 static constexpr int AE = NA / 64;       // agent entries per lane = words of the free masks
+// Of the agent table only the first NAL entries are staged in LDS.  Entries are handed out lowest-first, so the upper half of the
+// 256-entry table holds live orders only when a policy keeps more than 128 orders alive (it takes moving the quotes a share at a time:
+// tests/test_gpu_agent_capacity.py); they stay in the env's aux block in HBM and every routine that can meet one goes through the
+// accessors below - a uniform, never-taken branch for everyone else.  That keeps the larger table at the smaller one's LDS footprint
+// (20 envs per CU) and register budget: the table that cannot overflow costs nothing to those who do not fill it.
+static constexpr int NAL = 128;
+static constexpr int AEL = NAL / 64;
 #define CFG_Q(C) (SPEC ? 10 : (C).Q)
 #define CFG_TICK(C) (SPEC ? 100 : (C).c.tick_size)
 #define CFG_MINQ(C) (SPEC ? 0 : (C).c.min_quote_level)
@@ -202,13 +209,13 @@ struct Lds {
     int64_t price[2][LV + 1];
     uint64_t meta[2][LV + 1];  // slab | head << 16 | tail << 32 | live << 48 : one ds_read_b64 per level access
     int32_t vol[2][LV + 1];    // total resting volume of the level
-    AgentOrd agent[NA];
+    AgentOrd agent[NAL];
     Op8 ops[OPS_MAX];
     int32_t cur[2][QMAX];
     // (the Beta pdf values of a step - 2 x QMAX doubles, dead once the integer volumes are out - and, after them, the per-level
     // candidate counters of build_agent_ops live in the LAST 64 entries of `ops`, which the op list only reaches when everything
     // that used them is done: pdf_area())
-    uint16_t apos[NA];             // slot index of each live agent order inside its level's slab
+    uint16_t apos[NAL];            // slot index of each live agent order inside its level's slab
     union {
         // step kernel: the two ring words each feature lane will read, asked for right after the env state and parked here until
         // the feature phase (one HBM round trip less at the end of the step)
@@ -233,7 +240,7 @@ struct Lds {
     uint32_t agent_seq;
     uint16_t far_n[2], far_front[2];  // far levels per side, ring position of the best one (EnvHdr; invariant: far_n > 0 only while the near side is full)
 };
-static_assert(sizeof(Lds) <= (NA == 128 ? (LVT == 64 ? 8192 : 10240) : (LVT == 64 ? 10240 : 13056)), "LDS per env: 16 envs per CU with the 64-level ladder (12 with the 128-level one); 20 / 16 with 128 agent entries");
+static_assert(sizeof(Lds) <= (LVT == 64 ? 8192 : NA == 128 ? 10240 : 11264), "LDS per env: 20 envs per CU with the 64-level ladder (either agent table), 16 with the 128-level one (14 with the larger table's longer op list)");
 
 static_assert(OPS_MAX >= 128 && 64 * sizeof(Op8) == 2 * QMAX * sizeof(double), "pdf_area: the last 64 op entries hold 2 x QMAX doubles");
 SDI double* pdf_area(Lds& L) { return reinterpret_cast<double*>(&L.ops[OPS_MAX - 64]); }
@@ -368,6 +375,60 @@ SDI void trade(Lds& L, int64_t dinv, int64_t dcash) {
     if (lane() == 0) { L.inv += dinv; L.cash += dcash; }
 }
 
+#define UNLIKELY(x) __builtin_expect(!!(x), 0)  // rare branches: laid out away from the hot path, spills kept inside them
+// ---- the agent's order table: entries [0, NAL) in LDS, [NAL, NA) in the env's aux block in HBM (lobsim_layout.h: AGHI_BYTES).  A wave's
+// vector-memory instructions execute in program order, so the lanes of the one wave that owns the env see each other's writes there.
+SDI AgentOrd* agent_hi(Slot* slots) { return reinterpret_cast<AgentOrd*>(reinterpret_cast<char*>(slots) - HI_BYTES - AGHI_BYTES); }
+SDI uint16_t* apos_hi(Slot* slots) { return reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(slots) - HI_BYTES - AGHI_BYTES + (NA_MAX - NAL) * sizeof(AgentOrd)); }
+SDI bool ag_is_hi(int idx) { return NA > NAL && UNLIKELY(idx >= NAL); }
+SDI AgentOrd ag_get(const Lds& L, const Scal& S, int idx) {
+    if (ag_is_hi(idx)) return agent_hi(S.slots)[idx - NAL];
+    return L.agent[idx];
+}
+SDI int32_t ag_vol(const Lds& L, const Scal& S, int idx) {
+    if (ag_is_hi(idx)) return agent_hi(S.slots)[idx - NAL].vol;
+    return L.agent[idx].vol;
+}
+SDI int64_t ag_price(const Lds& L, const Scal& S, int idx) {
+    if (ag_is_hi(idx)) return agent_hi(S.slots)[idx - NAL].price;
+    return L.agent[idx].price;
+}
+SDI void ag_put(Lds& L, const Scal& S, int idx, const AgentOrd& o) {
+    if (ag_is_hi(idx)) agent_hi(S.slots)[idx - NAL] = o;
+    else L.agent[idx] = o;
+}
+SDI void ag_set_vol(Lds& L, const Scal& S, int idx, int32_t v) {
+    if (ag_is_hi(idx)) agent_hi(S.slots)[idx - NAL].vol = v;
+    else L.agent[idx].vol = v;
+}
+SDI int ap_get(const Lds& L, const Scal& S, int idx) {
+    if (ag_is_hi(idx)) return (int)apos_hi(S.slots)[idx - NAL];
+    return (int)L.apos[idx];
+}
+SDI void ap_put(Lds& L, const Scal& S, int idx, int pos) {
+    if (ag_is_hi(idx)) apos_hi(S.slots)[idx - NAL] = (uint16_t)pos;
+    else L.apos[idx] = (uint16_t)pos;
+}
+// does the half of the table that stays in HBM hold anything?  (bits of its free-mask words: set = free; an entry freed in this
+// step keeps its bit clear until the step ends: conservative)
+SDI bool ag_upper_free(const Lds& L) {
+    if constexpr (AE > AEL) {
+        static_assert(AE == 4 && AEL == 2, "the upper half of the agent table = words 2 and 3 of its free mask");
+        return (lds_u64(L.agent_free[2]) & lds_u64(L.agent_free[3])) == ~0ull;
+    }
+    return true;
+}
+// this lane's r-th entry (entry lane + 64 r: r is a compile-time constant in the unrolled loops that use it).  `upper_free`
+// (ag_upper_free): nothing lives beyond the on-chip half - no trip to memory to find that out entry by entry
+SDI AgentOrd ag_lane(const Lds& L, const Scal& S, int r, bool upper_free = false) {
+    if (r >= AEL) {
+        AgentOrd o; o.price = 0; o.vol = 0; o.seq_side = 0;
+        if (UNLIKELY(!upper_free)) o = agent_hi(S.slots)[lane() + 64 * (r - AEL)];
+        return o;
+    }
+    return L.agent[lane() + 64 * r];
+}
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // price ladder (LDS): sorted best first; SortedDict of rl4mm/orderbook/models.py:64-69
@@ -449,7 +510,6 @@ SDI void far_st(FarLevel* e, int64_t price, uint64_t meta, int64_t vol) {
     q[0] = a; q[1] = b;
 }
 
-#define UNLIKELY(x) __builtin_expect(!!(x), 0)  // the far branches: laid out away from the hot path, spills kept inside them
 // Slabs beyond the first NSLAB pages come from a BUDDY pool (pages NSLAB .. NSLAB + 16 n_big of the env): blocks of 1, 4 and 16
 // pages, a free mask per size in the env's aux block (HBM; all of this is rare and serial).  A block of 4 or 16 pages that is asked for
 // and not free is split off the next size up - three quarters go to the smaller size's mask -, four free siblings merge back when the
@@ -725,11 +785,7 @@ SDI bool ladder_insert(Lds& L, Scal& S, int side, int pos, int64_t price) {
     EVENT(ev_ladder);
     if (!(LOBSIM_FAR && LOBSIM_FAR_EVICT) && n >= LV) { S.status |= LOBSIM_ST_LEVEL_OVERFLOW; return false; }
     int slab = mask_take_first(L.slab_free);
-#ifdef LOBSIM_X_SIDECHK
-    if (UNLIKELY(n >= LV || slab < 0)) {
-#else
-    if (UNLIKELY(n >= LV || slab < 0 || S.n_lv[side ^ 1] >= LV)) {
-#endif  // (either side full: far levels may exist, the level budget is checked)
+    if (UNLIKELY(n >= LV || slab < 0 || S.n_lv[side ^ 1] >= LV)) {  // (either side full: far levels may exist, the level budget is checked)
         int r = LOBSIM_ST_LEVEL_OVERFLOW << 16;
         if (LOBSIM_FAR && LOBSIM_FAR_EVICT) r = ladder_insert_cold(L, S.slots, side, n >= LV ? 1 : 0, slab, S.n_lv[0] + S.n_lv[1]);
         if (r >> 16) { S.status |= r >> 16; return false; }
@@ -869,7 +925,7 @@ SDI uint64_t compact_level(Lds& L, Scal& S, int side, int idx, uint64_t m, int d
             if (s[k].kind != K_DEAD) {
                 int np = out + popc64(b & below);
                 dl[np] = s[k];
-                if (s[k].kind == K_AGENT) L.apos[s[k].id] = (uint16_t)np;
+                if (s[k].kind == K_AGENT) ap_put(L, S, (int)s[k].id, np);
                 if (s[k].kind == K_EXT) idc_put(S, s[k].id, dst, np);
             }
             out += popc64(b);
@@ -914,7 +970,7 @@ SDI void level_append(Lds& L, Scal& S, int side, int idx, int64_t id, int32_t vo
     if (lane() == 0) {
         Slot s; s.id = id; s.vol = vol; s.kind = kind;
         slab_ptr(S.slots, m_slab(m))[tail] = s;
-        if (kind == K_AGENT) L.apos[id] = (uint16_t)tail;
+        if (kind == K_AGENT) ap_put(L, S, (int)id, tail);
         if (kind == K_EXT) idc_put(S, id, m_slab(m), tail);
         L.meta[side][idx] = mk_meta(m_slab(m), live == 0 ? tail : m_head(m), tail + 1, live + 1);
         atomicAdd(&L.vol[side][idx], vol);  // ds_add, no read-modify-write round trip
@@ -975,7 +1031,7 @@ SDI void reduce_slot(Lds& L, Scal& S, int side, int idx, uint64_t m, int pos, in
     if (ln == 0) {
         Slot w; w.id = pid; w.vol = nv; w.kind = gone ? K_DEAD : pk;
         sl[pos] = w;
-        if (pk == K_AGENT) L.agent[pid].vol = nv;
+        if (pk == K_AGENT) ag_set_vol(L, S, (int)pid, nv);
     }
     if (gone && pk == K_AGENT) mask_set(L.agent_pending, (int)pid);
     int live = m_live(m) - (gone ? 1 : 0);
@@ -1016,8 +1072,8 @@ SDI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, in
     // apply_agent_ops_parallel) - no queue scan
     bool known_agent = false;
     if (kind == K_AGENT && id >= 0 && id < NA) {
-        const int32_t av = uni(L.agent[id].vol);
-        const int ap = (int)uni((int32_t)L.apos[id]);
+        const int32_t av = uni(ag_vol(L, S, (int)id));
+        const int ap = (int)uni((int32_t)ap_get(L, S, (int)id));
         if (av > 0 && ap >= head && ap < tail) { pos = ap; pv = av; known_agent = true; }
     }
 #else
@@ -1080,6 +1136,9 @@ SDI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, in
             uint64_t lv = ballot(s.kind != K_DEAD);
             if (lv) { int l = ffs64(lv); first_live = c * 64 + l; hk = rl32(s.kind, l); hv = rl32(s.vol, l); }
         }
+#endif
+#if defined(LOBSIM_PROFILE) && defined(LOBSIM_PROF_SNAPHEAD)
+        if (hk == K_SNAP) S.ev_rare++;  // (diagnostic: in place of "limits opening a new best" - unknown ids a snapshot head absorbs)
 #endif
         if (hk != K_SNAP) return;  // (a staged far level is left as it was: nothing to write back)
         if (vol < 0) { S.status |= LOBSIM_ST_ASSERT; return; }
@@ -1169,7 +1228,7 @@ SDI int32_t execute(Lds& L, Scal& S, int side, bool is_agent, bool is_market, in
             if (reached) {
                 Slot w = s; w.vol = nv; if (gone) w.kind = K_DEAD;
                 sl[i] = w;
-                if (is_ag) L.agent[s.id].vol = nv;
+                if (is_ag) ag_set_vol(L, S, (int)s.id, nv);
             }
             if constexpr (LOG) {  // the reference's fill records (:104-115): the resting order by its own side, at the level's price; an
                                   // aggressing agent order gets a MarketOrder copy per resting fill
@@ -1243,7 +1302,9 @@ SDI void submit_limit(Lds& L, Scal& S, int side, int64_t price, int32_t vol, boo
         } else {
             idx = insert_pos(L, S, side, price);
 #ifdef LOBSIM_PROFILE
+#ifndef LOBSIM_PROF_SNAPHEAD
             if (!is_agent && idx == 0) S.ev_rare++;  // (diagnostic) an external limit that opens a new best level
+#endif
 #endif
             if (!ladder_insert(L, S, side, idx, price)) return;
             m = (uint64_t)uni64((int64_t)L.meta[side][idx]);
@@ -1253,7 +1314,7 @@ SDI void submit_limit(Lds& L, Scal& S, int side, int64_t price, int32_t vol, boo
     if (is_agent) {
         int a = alloc_agent(L, S);
         if (a >= 0) {
-            if (lane() == 0) { AgentOrd o; o.price = price; o.vol = vol; o.seq_side = (L.agent_seq & 0x7fffffffu) | ((uint32_t)side << 31); L.agent[a] = o; L.agent_seq++; }
+            if (lane() == 0) { AgentOrd o; o.price = price; o.vol = vol; o.seq_side = (L.agent_seq & 0x7fffffffu) | ((uint32_t)side << 31); ag_put(L, S, a, o); L.agent_seq++; }
             id = a;
         }
     }
@@ -1289,7 +1350,7 @@ SDI void process_op(Lds& L, Scal& S, const DevCfg& C, Op8 op) {
     if (type == LOBSIM_LIMIT && !from_agent) {
         int64_t off = (int64_t)(CFG_MINQ(C) + idx) * CFG_TICK(C);
         price = side == LOBSIM_BUY ? S.q_buy - off : S.q_sell + off;
-    } else price = uni64(L.agent[idx].price);
+    } else price = uni64(ag_price(L, S, idx));
     if (type == LOBSIM_LIMIT) submit_limit(L, S, side, price, op.vol, true, 0);
     else remove_order(L, S, side, price, K_AGENT, idx, op.vol);
 }
@@ -1405,7 +1466,7 @@ SDI void build_agent_ops_r(Lds& L, Scal& S, const DevCfg& C, const Act5& action,
     int ek[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        AgentOrd o = L.agent[ln + 64 * r];
+        AgentOrd o = ag_lane(L, S, r);
         ek[r] = -2;  // free entry
         if (o.vol > 0) {
             int s = o.seq_side >> 31;
@@ -1437,7 +1498,7 @@ SDI void build_agent_ops_r(Lds& L, Scal& S, const DevCfg& C, const Act5& action,
     bool cand[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        ao[r] = L.agent[ln + 64 * r];
+        ao[r] = ag_lane(L, S, r);
         newer[r] = 0;
         const int sd = (int)(ao[r].seq_side >> 31);
         need[r] = ek[r] >= 0 ? -L.cur[sd][ek[r]] : 0;
@@ -1531,11 +1592,13 @@ SDI void build_agent_ops_r(Lds& L, Scal& S, const DevCfg& C, const Act5& action,
     SUBSTAMP(6);
 }
 
+// (The variant that looks at all four entries per lane - a table with live orders beyond its on-chip half - stays INLINE behind its
+// never-taken branch.  As a real function (one call site, plain values in and out, the configuration handed over as eight scalars) it
+// left the specialised step kernel with 44 spilled vector registers and 144 B of scratch where the inlined form has none: a call site
+// constrains the caller's whole allocation.)
 SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, int32_t desired, bool want_info = false) {
     if constexpr (AE > 2) {
-        static_assert(AE == 4, "the upper half of the agent table = words 2 and 3 of its free mask");
-        const bool upper_free = (lds_u64(L.agent_free[2]) & lds_u64(L.agent_free[3])) == ~0ull;  // (an entry freed in this step keeps its bit clear until the step ends: conservative)
-        if (UNLIKELY(!upper_free)) { build_agent_ops_r<AE>(L, S, C, action, desired, want_info); return; }
+        if (UNLIKELY(!ag_upper_free(L))) { build_agent_ops_r<AE>(L, S, C, action, desired, want_info); return; }
     }
     build_agent_ops_r<2>(L, S, C, action, desired, want_info);
 }
@@ -1609,44 +1672,33 @@ SDI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
         int64_t off = (int64_t)(CFG_MINQ(C) + idx) * CFG_TICK(C);
         price = side == LOBSIM_BUY ? S.q_buy - off : S.q_sell + off;
     }
-    if (is_cancel) price = L.agent[idx].price;
+    const bool in_lds = NA == NAL || idx < NAL;  // (a cancellation of an entry beyond the on-chip half: left to the sequential path)
+    if (is_cancel && in_lds) price = L.agent[idx].price;
     const int nlv = S.n_lv[side];
-    const int li = (is_limit || is_cancel) ? lane_find_level(L, side, nlv, price) : -1;
+    const int li = (is_limit || (is_cancel && in_lds)) ? lane_find_level(L, side, nlv, price) : -1;
     const uint64_t m = li >= 0 ? L.meta[side][li] : 0;
     Slot* sl = slab_ptr(S.slots, m_slab(m));
     // ---- new orders: append at the tail of an existing level that has room
     bool lim_ok = is_limit && li >= 0 && m_tail(m) < m_cap(m) && m_tail(m) - m_head(m) - m_live(m) < LOBSIM_TOMB;
     uint64_t lim_mask = ballot(lim_ok);
     int R = popc64(lim_mask);
-    uint64_t fw[AE];
+    // (new orders take their entries from the on-chip half of the table; when that does not have enough free ones left, the
+    // sequential path books them one by one - into the other half, or reports the overflow)
+    uint64_t fw[AEL];
     int n_free = 0;
 #pragma unroll
-    for (int k = 0; k < AE; k++) { fw[k] = lds_u64(L.agent_free[k]); n_free += popc64(fw[k]); }
+    for (int k = 0; k < AEL; k++) { fw[k] = lds_u64(L.agent_free[k]); n_free += popc64(fw[k]); }
     const uint32_t seq0 = (uint32_t)uni((int32_t)L.agent_seq);
-    if (R > n_free) { lim_ok = false; lim_mask = 0; R = 0; }  // sequential path reports the overflow
+    if (R > n_free) { lim_ok = false; lim_mask = 0; R = 0; }
     if (lim_ok) {
         int r = popc64(lim_mask & below);  // my rank among the appenders -> the r-th free agent entry
-        // (the r-th set bit of the free mask, by popcounts over its 32-bit words - a loop clearing r bits ran up to 20 turns per lane)
-        int word = 0, before = 0;
-        uint32_t qw = (uint32_t)fw[0];
-        const int c01 = popc64(fw[0]) + popc64(fw[1]);
-        if (AE == 2 || R <= c01) {  // (the usual case of the larger table too: every new order finds its entry in the first two words - four 32-bit halves, straight-line)
-            const uint32_t q0 = (uint32_t)fw[0], q1 = (uint32_t)(fw[0] >> 32), q2 = (uint32_t)fw[1], q3 = (uint32_t)(fw[1] >> 32);
-            const int c0 = __popc(q0), c1 = c0 + __popc(q1), c2 = c1 + __popc(q2);
-            word = (r >= c0) + (r >= c1) + (r >= c2);
-            qw = word == 0 ? q0 : word == 1 ? q1 : word == 2 ? q2 : q3;
-            before = word == 0 ? 0 : word == 1 ? c0 : word == 2 ? c1 : c2;
-        } else {
-#pragma unroll
-            for (int k = 0; k < 2 * AE - 1; k++) {  // (uniform words, per-lane rank: selects on values)
-                const uint32_t wk = (uint32_t)(fw[k >> 1] >> (32 * (k & 1))), wn = (uint32_t)(fw[(k + 1) >> 1] >> (32 * ((k + 1) & 1)));
-                const int ck = __popc(wk);
-                const bool past = word == k && r >= before + ck;
-                before += past ? ck : 0;
-                qw = past ? wn : qw;
-                word += past ? 1 : 0;
-            }
-        }
+        // (the r-th set bit of the free mask, by popcounts over its four 32-bit words - a loop clearing r bits ran up to 20 turns per lane)
+        static_assert(AEL == 2, "");
+        const uint32_t q0 = (uint32_t)fw[0], q1 = (uint32_t)(fw[0] >> 32), q2 = (uint32_t)fw[1], q3 = (uint32_t)(fw[1] >> 32);
+        const int c0 = __popc(q0), c1 = c0 + __popc(q1), c2 = c1 + __popc(q2);
+        const int word = (r >= c0) + (r >= c1) + (r >= c2);
+        const uint32_t qw = word == 0 ? q0 : word == 1 ? q1 : word == 2 ? q2 : q3;
+        const int before = word == 0 ? 0 : word == 1 ? c0 : word == 2 ? c1 : c2;
         const int aidx = 32 * word + nth_set_bit32(qw, r - before);
         const int tail = m_tail(m), live = m_live(m);
         Slot w; w.id = aidx; w.vol = op.vol; w.kind = K_AGENT;
@@ -1661,7 +1713,7 @@ SDI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
     }
     if (ln == 0 && R) L.agent_seq = seq0 + (uint32_t)R;
     // ---- cancellations: straight to the recorded slot
-    bool can_ok = is_cancel && li >= 0;
+    bool can_ok = is_cancel && in_lds && li >= 0;
     const int pos = can_ok ? L.apos[idx] : 0;
     can_ok = can_ok && pos >= m_head(m) && pos < m_tail(m);
     // The slot's contents are known without reading it: an agent order's slot is {index, volume, K_AGENT}, its volume is
@@ -1721,7 +1773,9 @@ SDI void ladder_clear(Lds& L, Scal& S, const DevPtrs& P) {
     if (lane() < NSLAB / 64) L.slab_free[lane()] = ~0ull;
     if (lane() < NA / 64) { L.agent_free[lane()] = ~0ull; L.agent_pending[lane()] = 0; }
 #pragma unroll
-    for (int r = 0; r < AE; r++) { L.agent[lane() + 64 * r].vol = 0; L.apos[lane() + 64 * r] = 0; }
+    for (int r = 0; r < AEL; r++) { L.agent[lane() + 64 * r].vol = 0; L.apos[lane() + 64 * r] = 0; }
+#pragma unroll
+    for (int r = AEL; r < AE; r++) { agent_hi(S.slots)[lane() + 64 * (r - AEL)].vol = 0; apos_hi(S.slots)[lane() + 64 * (r - AEL)] = 0; }  // (the half that stays in HBM)
     if (lane() == 0) L.agent_seq = 0;
     wsync();
 }
@@ -1811,9 +1865,10 @@ SDI void resync_outer_levels(Lds& L, Scal& S, const DevCfg& C, const StreamDev& 
                     {
                         bool hit[AE]; uint32_t q[AE]; int32_t ov[AE]; int rank[AE]; uint64_t hm[AE];
                         int total = 0;
+                        const bool upper_free = ag_upper_free(L);
 #pragma unroll
                         for (int r = 0; r < AE; r++) {
-                            const AgentOrd o = L.agent[ln + 64 * r];
+                            const AgentOrd o = ag_lane(L, S, r, upper_free);
                             hit[r] = o.vol > 0 && (int)(o.seq_side >> 31) == side && o.price == price;
                             q[r] = o.seq_side & 0x7fffffffu; ov[r] = o.vol; rank[r] = 0;
                             hm[r] = ballot(hit[r]);
@@ -1906,14 +1961,9 @@ SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt,
     bool cross = false;
     if (is_lim && S.n_lv[side ^ 1] > 0) { const int64_t bp = L.price[side ^ 1][0]; cross = side == LOBSIM_BUY ? b.price >= bp : b.price <= bp; }
     // (room: every limit order of the pass could land on this lane's level)
-#ifdef LOBSIM_X_NLIM
-    const bool plain = is_lim && vol64 > 0 && vol64 < (1ll << 31) && li >= 0 && !cross && m_live(m) > 0 &&
-                       m_tail(m) <= SLOTS - WAVE && m_tail(m) - m_head(m) - m_live(m) < LOBSIM_TOMB;
-#else
     const int n_lim = popc64(ballot(is_lim));
     const bool plain = is_lim && vol64 > 0 && vol64 < (1ll << 31) && li >= 0 && !cross && m_live(m) > 0 &&
                        m_tail(m) + n_lim <= m_cap(m) && m_tail(m) - m_head(m) - m_live(m) < LOBSIM_TOMB;
-#endif
     const uint64_t stop = ballot(in && !(plain || is_rem));
     seg_end = stop ? ffs64(stop) : cnt;
     const bool app = plain && ln < seg_end;
@@ -2562,8 +2612,8 @@ SDI EnvRegs load_env_issue(Scal& S, const DevPtrs& P, int env, const HdrRegs& H)
     int64_t pb = 0, psl = 0; uint64_t mb = 0, ms = 0; int32_t vb = 0, vs = 0;
     if (hb) { pb = G.price[0][ln]; mb = G.meta[0][ln]; vb = G.vol[0][ln]; }
     if (hs) { psl = G.price[1][ln]; ms = G.meta[1][ln]; vs = G.vol[1][ln]; }
-    const AgentOrd* A = P.agent + (size_t)env * NA;
-    const uint16_t* AP = P.apos + (size_t)env * NA;
+    const AgentOrd* A = P.agent + (size_t)env * NAL;
+    const uint16_t* AP = P.apos + (size_t)env * NAL;
     EnvRegs r;
     r.pb = pb; r.psl = psl; r.mb = mb; r.ms = ms; r.vb = vb; r.vs = vs;
 #pragma unroll
@@ -2583,14 +2633,6 @@ SDI void load_env_commit(Lds& L, Scal& S, const DevPtrs& P, int env, const HdrRe
     if (hs) { L.price[1][ln] = r.psl; L.meta[1][ln] = r.ms; L.vol[1][ln] = r.vs; }
 #pragma unroll
     for (int k = 0; k < 2; k++) { L.agent[ln + 64 * k] = r.a[k]; L.apos[ln + 64 * k] = r.q[k]; }
-#pragma unroll
-    for (int k = 2; k < AE; k++) {  // the upper half of the larger table: zeros, unless it holds live orders (a round trip of its own, then)
-        AgentOrd o; o.price = 0; o.vol = 0; o.seq_side = 0;
-        uint16_t q = 0;
-        const uint64_t af = H.af[k];
-        if (UNLIKELY(af != ~0ull) && !((af >> ln) & 1)) { o = (P.agent + (size_t)env * NA)[ln + 64 * k]; q = (P.apos + (size_t)env * NA)[ln + 64 * k]; }
-        L.agent[ln + 64 * k] = o; L.apos[ln + 64 * k] = q;
-    }
 #pragma unroll
     for (int s = 0; s < 2; s++)
         for (int i = ln + 64; i < S.n_lv[s]; i += 64) {
@@ -2631,10 +2673,10 @@ SDI void store_env(const Lds& L, const Scal& S, const DevPtrs& P, int env, EnvHd
             if (prices) G.price[s][i] = L.price[s][i];
             G.meta[s][i] = L.meta[s][i]; G.vol[s][i] = L.vol[s][i];
         }
-    AgentOrd* A = P.agent + (size_t)env * NA;
-    uint16_t* AP = P.apos + (size_t)env * NA;
+    AgentOrd* A = P.agent + (size_t)env * NAL;
+    uint16_t* AP = P.apos + (size_t)env * NAL;
 #pragma unroll
-    for (int k = 0; k < AE; k++) {  // live entries only (see load_env)
+    for (int k = 0; k < AEL; k++) {  // live entries only (see load_env); the entries beyond the on-chip half are in HBM as they are
         const uint64_t af = lds_u64(L.agent_free[k]) | lds_u64(L.agent_pending[k]);
         if ((k == 0 || af != ~0ull) && !((af >> ln) & 1)) { A[ln + 64 * k] = L.agent[ln + 64 * k]; AP[ln + 64 * k] = L.apos[ln + 64 * k]; }
     }
@@ -3215,7 +3257,7 @@ SDI void process_raw_order(Lds& L, Scal& S, const int64_t* r) {
         int older[AE];
 #pragma unroll
         for (int k = 0; k < AE; k++) {
-            const AgentOrd o = L.agent[ln + 64 * k];
+            const AgentOrd o = ag_lane(L, S, k, ag_upper_free(L));
             mt[k] = o.vol > 0 && (int)(o.seq_side >> 31) == side && o.price == price;
             q[k] = o.seq_side & 0x7fffffffu;
             older[k] = 0;
@@ -3400,9 +3442,9 @@ SDI void features_reset_body(const DevCfg& C, const DevPtrs& P, const int32_t* e
 #ifndef LOBSIM_ROLLOUT_WAVES
 #define LOBSIM_ROLLOUT_WAVES 4
 #endif
-// (the budget must be one the LDS allows - 16 envs per CU = 4 waves per SIMD with the 64-level ladder and 256 agent entries, 12 = 3 with
-// the 128-level one: asked for more, the compiler drops the constraint altogether and takes 148 registers)
-constexpr int step_waves(int lvt, int na, bool extras) { return lvt == 64 ? (extras || na != 128 ? 4 : LOBSIM_STEP_WAVES) : (na == 128 ? LOBSIM_STEP_WAVES_DEEP : 3); }
+// (the budget must be one the LDS allows - 20 envs per CU with the 64-level ladder, 16 with the 128-level one, 14 = 3 waves per SIMD with
+// the 128-level ladder and the larger table's op list: asked for more, the compiler drops the constraint altogether and takes 148 registers)
+constexpr int step_waves(int lvt, int na, bool extras) { return lvt == 64 ? (extras ? 4 : LOBSIM_STEP_WAVES) : (na == 128 ? LOBSIM_STEP_WAVES_DEEP : 3); }
 constexpr int other_waves(int lvt, int na) { return lvt == 64 ? 4 : (na == 128 ? LOBSIM_STEP_WAVES_DEEP : 3); }
 template <bool EXTRAS, int LVT, int NAT, bool SPEC = false>
 __global__ __launch_bounds__(64, step_waves(LVT, NAT, EXTRAS)) void lob_step_kernel(DevCfg C, DevPtrs P, StepArgs A) { Eng<LVT, SPEC, false, NAT>::template step_body<EXTRAS>(C, P, A); }

@@ -14,7 +14,7 @@
 //                               to a larger one when it outgrows its slab (rare: make_room).  Slot index = time priority; removed
 //                               orders leave tombstones, squeezed out once LOBSIM_TOMB of them have piled up (or the slab is
 //                               full), so a scan touches ceil((live+tombstones)/64) chunks
-//   AgentOrd agent[na]          the agent's own live orders (the reference's "internal orderbook")
+//   AgentOrd agent[na]          the agent's own live orders (the reference's "internal orderbook"); the first 128 are staged on chip
 //   feature scalars + rings     rolling windows of the observation features
 // During a launch the ladder, the agent orders and the op list live in LDS; slabs stay in HBM/L2 and are read
 // 1 KiB per wave-instruction (16 B per lane), so "find order by id", "volume ahead" and "sweep the level" are
@@ -54,7 +54,8 @@ struct alignas(16) FarLevel { int64_t price; uint64_t meta; int64_t vol; int64_t
 static_assert(sizeof(FarLevel) == 32, "");
 constexpr size_t FAR_BYTES = 2 * (size_t)FAR_CAP * sizeof(FarLevel);
 constexpr size_t HI_BYTES = 1024;                  // hi_free[128] u64 (85 used; pages stay 1 KiB-aligned)
-constexpr size_t AUX_BYTES = FAR_BYTES + HI_BYTES;  // per env, in front of its slabs: far rings, then hi_free
+constexpr size_t AGHI_BYTES = 3072;                // the agent-order entries beyond the 128 that are staged on chip: AgentOrd[128] (2048 B), then their slot indices u16[128]
+constexpr size_t AUX_BYTES = FAR_BYTES + AGHI_BYTES + HI_BYTES;  // per env, in front of its pages: far rings, upper agent entries, hi_free
 // Agent orders per env (live ones + those freed in the current step): a property of the HANDLE since round 5 (cfg.agent_orders), the
 // engine is a template on it (Eng<.., NAT>: NAT / 64 entries per lane).  What bounds the reference's internal book is VOLUME - a side
 // quotes sum(round(100 pdf)) <= 100 + Q/2 shares, so at most ~105 one-share orders per side - and 2 x 105 live entries + the <= 2Q a
@@ -165,13 +166,13 @@ struct DevCfg {
 struct DevPtrs {
     EnvHdr* hdr;
     Ladder* ladder;
-    uint8_t* pool;     // [env]{FarLevel far[2][FAR_CAP]; u64 hi_free[128]; Slot pages[NSLAB + 16 n_big][64]}
+    uint8_t* pool;     // [env]{FarLevel far[2][FAR_CAP]; AgentOrd agent_hi[128]; u16 apos_hi[128] (+pad); u64 hi_free[128]; Slot pages[NSLAB + 16 n_big][64]}
     int64_t pool_stride;  // bytes per env
     int32_t n_slab;    // the env's budget of price levels (NSLAB .. NSLAB_MAX, a multiple of 64)
     int32_t na;        // agent entries per env (128 or 256: the NAT of the kernels this handle launches)
     int32_t n_mid, n_big;  // n_big: 16-page blocks of the env's buddy pool (pages NSLAB .. NSLAB + 16 n_big; slabs of 1 / 4 / 16 pages are cut from it); n_mid = 4 n_big
-    AgentOrd* agent;   // [env][na]
-    uint16_t* apos;    // [env][na] slot index of each live agent order inside its level's slab
+    AgentOrd* agent;   // [env][128] the agent-order entries that are staged in LDS (entries 128 .. na - 1: in the env's pool block, see `pool`)
+    uint16_t* apos;    // [env][128] slot index of each live agent order inside its level's slab
     uint64_t* idc;     // [env][IDC_N] position cache of external orders: tag(id) << 32 | slab << 16 | slot, direct-mapped by id
     FeatState* feat;   // [env][LOBSIM_MAX_FEATURES]
     int64_t* rings;    // [env][ring_words]

@@ -303,12 +303,16 @@ class OrderbookSimulator:
         cancellation names into the FIFO rank of its target among the agent's orders at that price."""
         rows = []
         may_have_swept_own = False
+        marketable = set()  # (side, price) of this call's own limit orders that cross the touch: the device may fill them (in part) on arrival
+        st = self._state() if any(isinstance(o, Deletion) for o in orders) else None
         for o in orders:
             assert not o.is_external, "internal_orders are the agent's own orders (historical messages come from the packed stream)"
             side = SIDE[o.direction]
             if isinstance(o, LimitOrder):
                 opp_live = any(s == 1 - side and (p <= o.price if side == 0 else p >= o.price) for (s, p), q in self._agent.items() if q)
                 may_have_swept_own = may_have_swept_own or opp_live
+                if st is not None and ((side == 0 and o.price >= st["best_sell"]) or (side == 1 and o.price <= st["best_buy"])):
+                    marketable.add((side, int(o.price)))
                 self._next_internal_id += 1
                 o.internal_id = self._next_internal_id
                 self._agent.setdefault((side, int(o.price)), []).append([o.internal_id, int(o.volume)])
@@ -319,6 +323,9 @@ class OrderbookSimulator:
             elif isinstance(o, Deletion):  # Cancellation is a Deletion
                 if may_have_swept_own:
                     raise NotImplementedError("a cancellation after a self-crossing own order in one forward_step call: submit them in separate calls")
+                if (side, int(o.price)) in marketable:
+                    # (the marketable order may never rest, or rest with less volume: the FIFO rank the host would name is not the device's)
+                    raise NotImplementedError("a cancellation at the price of a marketable own limit order of the same forward_step call: submit them in separate calls")
                 q = self._agent.get((side, int(o.price)), [])
                 rank = next((i for i, e in enumerate(q) if e[0] == o.internal_id), None)
                 typ = _capi_type("cancellation" if isinstance(o, Cancellation) else "deletion")

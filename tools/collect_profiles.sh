@@ -18,14 +18,14 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 cd $R
 # ---- PMC counters of the step kernel, per workload (one rocprofv3 run per counter group)
-PMC_ARGS="" bash tools/pmc_passes.sh $1/pmc_random > /dev/null 2>&1; python3 tools/pmc_csv.py $OUT/pmc_random $OUT/pmc_step_kernel.csv > /dev/null
+PMC_ARGS="" bash tools/pmc_passes.sh $1/pmcdir_random > /dev/null 2>&1; python3 tools/pmc_csv.py $OUT/pmcdir_random $OUT/pmc_step_kernel.csv > /dev/null
 for w in teradactyl ad deep50 rs; do
-  PMC_ONLY="sq1 sq2 fetch write" PMC_ARGS="--workload $w" bash tools/pmc_passes.sh $1/pmc_$w > /dev/null 2>&1
-  python3 tools/pmc_csv.py $OUT/pmc_$w $OUT/pmc_step_kernel_$w.csv > /dev/null
+  PMC_ONLY="sq1 sq2 fetch write" PMC_ARGS="--workload $w" bash tools/pmc_passes.sh $1/pmcdir_$w > /dev/null 2>&1
+  python3 tools/pmc_csv.py $OUT/pmcdir_$w $OUT/pmc_step_kernel_$w.csv > /dev/null
 done
-PMC_ONLY="sq1 sq2 fetch write" PMC_ARGS="--generic-kernels" bash tools/pmc_passes.sh $1/pmc_generic > /dev/null 2>&1
-python3 tools/pmc_csv.py $OUT/pmc_generic $OUT/pmc_step_kernel_generic.csv > /dev/null
-rm -rf $OUT/pmc_* $OUT/stats $OUT/*.log
+PMC_ONLY="sq1 sq2 fetch write" PMC_ARGS="--generic-kernels" bash tools/pmc_passes.sh $1/pmcdir_generic > /dev/null 2>&1
+python3 tools/pmc_csv.py $OUT/pmcdir_generic $OUT/pmc_step_kernel_generic.csv > /dev/null
+rm -rf $OUT/pmcdir_* $OUT/stats $OUT/*.log
 # ---- what the slowest wave of a launch does (stamp build), per workload
 if [ -f build/variants/prof.so ]; then
   PROF_LIB=build/variants/prof.so python3 tools/tail_profile.py 4096 rows > $OUT/tail_profile.txt 2>/dev/null
