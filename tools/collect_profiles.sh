@@ -1,6 +1,7 @@
 #!/bin/bash
 # Everything profiles/<round>/ holds, in one GPU call: bash tools/collect_profiles.sh <tag>  -> gpurun_out/<tag>/
-# (needs build/variants/prof.so for the tail profiles: tools/build_variant.sh prof -DLOBSIM_PROFILE in the build container)
+# (needs build/variants/prof.so for the tail profiles: tools/build_variant.sh prof -DLOBSIM_PROFILE -DLOBSIM_STEP_WAVES=4 in the build container;
+#  roofline.traffic of the bench lines comes from profiles/<round>/pmc_step_kernel*.csv: copy the csvs there, then bash tools/rebench_lines.sh)
 set -u
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$1; mkdir -p $OUT
 cd $R
@@ -27,13 +28,7 @@ PMC_ONLY="sq1 sq2 fetch write" PMC_ARGS="--generic-kernels" bash tools/pmc_passe
 python3 tools/pmc_csv.py $OUT/pmcdir_generic $OUT/pmc_step_kernel_generic.csv > /dev/null
 rm -rf $OUT/pmcdir_* $OUT/stats $OUT/*.log
 # ---- what the slowest wave of a launch does (stamp build), per workload
-if [ -f build/variants/prof.so ]; then
-  PROF_LIB=build/variants/prof.so python3 tools/tail_profile.py 4096 rows > $OUT/tail_profile.txt 2>/dev/null
-  for w in deep50 rs; do PROF_LIB=build/variants/prof.so TP_WORKLOAD=$w python3 tools/tail_profile.py > $OUT/tail_profile_$w.txt 2>/dev/null; done
-  PROF_LIB=build/variants/prof.so TP_GENERIC=1 python3 tools/tail_profile.py > $OUT/tail_profile_generic.txt 2>/dev/null
-  PROF_LIB=build/variants/prof.so TP_SKIP=5 TP_K=105 python3 tools/tail_profile.py > $OUT/tail_profile_steps5_105.txt 2>/dev/null
-  PROF_LIB=build/variants/prof.so TP_SKIP=500 TP_K=600 python3 tools/tail_profile.py > $OUT/tail_profile_steps500_600.txt 2>/dev/null
-fi
+if [ -f build/variants/prof.so ]; then bash tools/tail_profiles.sh $1 > /dev/null 2>&1; fi
 # ---- the bench lines again, now that the PMC files of this collection exist (roofline.traffic reads them from profiles/<round>/): done by
 # copying gpurun_out/<tag>/pmc_step_kernel*.csv into profiles/<round>/ and re-running the lines that are committed
 for f in $OUT/bench_*.json; do echo $f; cut -c1-260 $f; done; cat $OUT/kernel_stats.csv | head -4; grep -E "FETCH|WRITE|WAVES,|WAVE_CYCLES|WAIT_ANY|INSTS_VALU|INSTS_SALU" $OUT/pmc_step_kernel.csv
