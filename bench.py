@@ -121,28 +121,32 @@ def timed_regions(step, K, repeats, first_step, dist, sync, make_events=None):
     import torch
 
     local, ev_ms = [], []
+    # everything the loop needs is made BEFORE it (event objects, the clock function): between two regions the host does the
+    # bracket's barrier + synchronise and nothing else, so a region does not start on a GPU that idled through Python bookkeeping
+    all_evs = [make_events() for _ in range(repeats)] if make_events else None
+    clock = time.perf_counter
     gc.collect()
     gc.disable()  # (a cyclic collection inside a 0.7 ms region would be a third of it)
     for r in range(repeats):
-        evs = make_events() if make_events else None
+        evs = all_evs[r] if all_evs else None
         if dist:
             dist.barrier()
         sync()
         if evs:
             evs[0].record()  # on the idle stream, just ahead of the clock: instrumentation, not steps
-        t0 = time.perf_counter()
-        for t in range(K):
-            step(first_step + r * K + t)
+        t0 = clock()
+        for t in range(first_step + r * K, first_step + (r + 1) * K):
+            step(t)
         if evs:
             evs[1].record()
         sync()
-        local.append(time.perf_counter() - t0)
+        local.append(clock() - t0)
         if dist:
             dist.barrier()  # the closing side of the bracket: every rank is done before anything else happens
         sync()
-        if evs:
-            ev_ms.append(evs[0].elapsed_time(evs[1]))
     gc.enable()
+    if all_evs:
+        ev_ms = [e[0].elapsed_time(e[1]) for e in all_evs]
     mine = torch.tensor(local, dtype=torch.float64)
     job = mine.clone()
     if dist:

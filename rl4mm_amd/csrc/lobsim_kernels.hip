@@ -1428,10 +1428,12 @@ SDI int32_t beta_volumes(Lds& L, const DevCfg& C, const Act5& action, const Beta
     return desired;
 }
 
-// R = agent entries per lane this pass looks at: all of them (AE), or - the table of 256 whose upper half holds no live order, which
-// is its usual state: entries are handed out lowest-first - only the first two (the registers and instructions of the 128-entry build).
-template <int R>
-SDI void build_agent_ops_r(Lds& L, Scal& S, const DevCfg& C, const Act5& action, int32_t desired, bool want_info) {
+// The op list is worked out from the entries that are staged on chip (two per lane).  A table whose upper half holds live orders too
+// (ag_upper_free() false: more than 128 orders alive) adds them at four small hooks - `upper` blocks below, each re-reading its two
+// entries per lane from HBM and keeping nothing but the two cancel volumes across the rest - instead of a second instantiation of the
+// whole routine over four entries per lane: that one, inlined behind a never-taken branch, cost the multi-step kernel 8 % in registers.
+SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, int32_t desired, bool want_info = false) {
+    constexpr int R = AEL, RH = AE - AEL;  // entries per lane: on chip / in HBM
     const lobsim_cfg& c = C.c;
     const int Q = CFG_Q(C), ln = lane();
     const int64_t tick = CFG_TICK(C);
@@ -1461,27 +1463,36 @@ SDI void build_agent_ops_r(Lds& L, Scal& S, const DevCfg& C, const Act5& action,
     }
     S.q_buy = best_buy; S.q_sell = best_sell;
     SUBSTAMP(3);
+    const bool upper = RH > 0 && UNLIKELY(!ag_upper_free(L));  // (uniform)
+    // the quote level an entry sits at: -2 free entry, -1 "wide" (negative, not a tick multiple or beyond the quoted range), else the level
+    auto level_of = [&](const AgentOrd& o) -> int {
+        if (!(o.vol > 0)) return -2;
+        const int s = o.seq_side >> 31;
+        const int64_t d = s == LOBSIM_BUY ? best_buy - o.price : o.price - best_sell;
+        int e = -1;
+        if (d >= 0 && d < (int64_t)(CFG_MINQ(C) + Q) * tick) {  // small: 32-bit divide
+            const uint32_t du = (uint32_t)d, tu = (uint32_t)tick;
+            // d / tick: multiply-high by ceil(2^32 / tick) is exact while d * tick < 2^32 (the host checks the quoted
+            // range against that, tick_magic = 0 otherwise); a run-time 32-bit division is ~30 instructions per entry
+            const uint32_t qd = CFG_MAGIC(C) ? __umulhi(du, CFG_MAGIC(C)) : du / tu;
+            const int kk = (int)qd - CFG_MINQ(C);
+            if (qd * tu == du && kk >= 0) e = kk;
+        }
+        return e;
+    };
+    auto hi_entry = [&](int r) -> AgentOrd { return agent_hi(S.slots)[ln + 64 * r]; };
     // ---- current agent volume per quoted level (_get_current_internal_order_volumes, :291-296); each agent entry
     // finds its quote level (or "wide")
     int ek[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        AgentOrd o = ag_lane(L, S, r);
-        ek[r] = -2;  // free entry
-        if (o.vol > 0) {
-            int s = o.seq_side >> 31;
-            int64_t d = s == LOBSIM_BUY ? best_buy - o.price : o.price - best_sell;
-            ek[r] = -1;  // negative, not a tick multiple or beyond the quoted range: "wide"
-            if (d >= 0 && d < (int64_t)(CFG_MINQ(C) + Q) * tick) {  // small: 32-bit divide
-                uint32_t du = (uint32_t)d, tu = (uint32_t)tick;
-                // d / tick: multiply-high by ceil(2^32 / tick) is exact while d * tick < 2^32 (the host checks the quoted
-                // range against that, tick_magic = 0 otherwise); a run-time 32-bit division is ~30 instructions per entry
-                uint32_t qd = CFG_MAGIC(C) ? __umulhi(du, CFG_MAGIC(C)) : du / tu;
-                int kk = (int)qd - CFG_MINQ(C);
-                if (qd * tu == du && kk >= 0) ek[r] = kk;
-            }
-            if (ek[r] >= 0) atomicAdd(&L.cur[s][ek[r]], o.vol);
-        }
+        const AgentOrd o = L.agent[ln + 64 * r];
+        ek[r] = level_of(o);
+        if (ek[r] >= 0) atomicAdd(&L.cur[o.seq_side >> 31][ek[r]], o.vol);
+    }
+    if (upper) {
+#pragma unroll
+        for (int r = 0; r < RH; r++) { const AgentOrd o = hi_entry(r); const int e = level_of(o); if (e >= 0) atomicAdd(&L.cur[o.seq_side >> 31][e], o.vol); }
     }
     wsync();
     SUBSTAMP(4);
@@ -1498,13 +1509,17 @@ SDI void build_agent_ops_r(Lds& L, Scal& S, const DevCfg& C, const Act5& action,
     bool cand[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        ao[r] = ag_lane(L, S, r);
+        ao[r] = L.agent[ln + 64 * r];
         newer[r] = 0;
         const int sd = (int)(ao[r].seq_side >> 31);
         need[r] = ek[r] >= 0 ? -L.cur[sd][ek[r]] : 0;
         cand[r] = ek[r] >= 0 && need[r] > 0;
         code[r] = cand[r] ? (sd << 8) | ek[r] : -1 - r;  // (side, level) key; distinct dummies when not a candidate
     }
+    int32_t cvol_hi[RH > 0 ? RH : 1];  // what the entries that live in HBM cancel, and their sides (bit r): all that is kept of them
+    uint32_t side_hi = 0;
+#pragma unroll
+    for (int r = 0; r < (RH > 0 ? RH : 1); r++) cvol_hi[r] = 0;
     {
         // newer[r] = volume of the candidates at my level that are newer than me.  Every candidate posts (seq, vol) to
         // its level's list in LDS (the op list's storage, not yet written; counters in the pdf storage, already
@@ -1518,16 +1533,27 @@ SDI void build_agent_ops_r(Lds& L, Scal& S, const DevCfg& C, const Act5& action,
         const int cap = (OPS_MAX - 64) / (2 * Q);  // (the lists stop in front of the counters)
         if (ln < 2 * Q) cntr[ln] = 0;
         wsync();
-        int lvl[R], at[R];
+        int lvl[R];
         bool over = false;
 #pragma unroll
         for (int r = 0; r < R; r++) {
             lvl[r] = (code[r] >> 8) * Q + (code[r] & 0xff);
-            at[r] = 0;
             if (cand[r]) {
-                at[r] = atomicAdd(&cntr[lvl[r]], 1);
-                if (at[r] < cap) lists[lvl[r] * cap + at[r]] = ((unsigned long long)q[r] << 32) | (uint32_t)ao[r].vol;
-                over = over || at[r] >= cap;
+                const int at = atomicAdd(&cntr[lvl[r]], 1);
+                if (at < cap) lists[lvl[r] * cap + at] = ((unsigned long long)q[r] << 32) | (uint32_t)ao[r].vol;
+                over = over || at >= cap;
+            }
+        }
+        if (upper) {
+#pragma unroll
+            for (int r = 0; r < RH; r++) {
+                const AgentOrd o = hi_entry(r);
+                const int e = level_of(o), sd = (int)(o.seq_side >> 31);
+                if (e >= 0 && -L.cur[sd][e] > 0) {
+                    const int at = atomicAdd(&cntr[sd * Q + e], 1);
+                    if (at < cap) lists[(sd * Q + e) * cap + at] = ((unsigned long long)(o.seq_side & 0x7fffffffu) << 32) | (uint32_t)o.vol;
+                    over = over || at >= cap;
+                }
             }
         }
         wsync();
@@ -1544,18 +1570,58 @@ SDI void build_agent_ops_r(Lds& L, Scal& S, const DevCfg& C, const Act5& action,
                 }
             }
         }
-        wsync();
+        if (upper) {  // the same for the entries in HBM: their cancel volume is all that is kept
 #pragma unroll
-        for (int r = 0; r < R && overflow; r++) {  // broadcast every candidate once: volume of same-level orders newer than mine
-            uint64_t bb = ballot(cand[r]);
-            while (bb) {
-                const int t = ffs64(bb);
-                bb &= bb - 1;
-                const int tc = rl32(code[r], t);
-                const uint32_t tq = (uint32_t)rl32((int32_t)q[r], t);
-                const int32_t tv = rl32(ao[r].vol, t);
+            for (int r = 0; r < RH; r++) {
+                const AgentOrd o = hi_entry(r);
+                const int e = level_of(o), sd = (int)(o.seq_side >> 31);
+                side_hi |= (uint32_t)sd << r;
+                if (e == -1) cvol_hi[r] = o.vol;  // wide
+                const int32_t nd = e >= 0 ? -L.cur[sd][e] : 0;
+                if (e >= 0 && nd > 0 && !overflow) {
+                    const int lv = sd * Q + e, n = cntr[lv];
+                    const uint32_t mine = o.seq_side & 0x7fffffffu;
+                    int32_t nw = 0;
+                    for (int i = 0; i < n; i++) {
+                        const unsigned long long x = lists[lv * cap + i];
+                        nw += (uint32_t)(x >> 32) > mine ? (int32_t)(uint32_t)x : 0;
+                    }
+                    if (nd > nw) cvol_hi[r] = min(o.vol, nd - nw);
+                }
+            }
+        }
+        wsync();
+        if (UNLIKELY(overflow)) {  // broadcast every candidate once: volume of same-level orders newer than mine
+            // (with live entries in HBM: theirs too, held in registers for this block only)
+            int32_t code_h[RH > 0 ? RH : 1], vol_h[RH > 0 ? RH : 1], need_h[RH > 0 ? RH : 1], newer_h[RH > 0 ? RH : 1];
+            uint32_t q_h[RH > 0 ? RH : 1];
+#pragma unroll
+            for (int r = 0; r < (RH > 0 ? RH : 1); r++) { code_h[r] = -100 - r; vol_h[r] = 0; need_h[r] = 0; newer_h[r] = 0; q_h[r] = 0; }
+            if (upper) {
+#pragma unroll
+                for (int r = 0; r < RH; r++) {
+                    const AgentOrd o = hi_entry(r);
+                    const int e = level_of(o), sd = (int)(o.seq_side >> 31);
+                    need_h[r] = e >= 0 ? -L.cur[sd][e] : 0;
+                    if (e >= 0 && need_h[r] > 0) code_h[r] = (sd << 8) | e;
+                    vol_h[r] = o.vol; q_h[r] = o.seq_side & 0x7fffffffu;
+                }
+            }
+            auto bcast = [&](int tc, uint32_t tq, int32_t tv) {
 #pragma unroll
                 for (int k = 0; k < R; k++) newer[k] += (tc == code[k] && tq > q[k]) ? tv : 0;
+#pragma unroll
+                for (int k = 0; k < RH; k++) newer_h[k] += (tc == code_h[k] && tq > q_h[k]) ? tv : 0;
+            };
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                for (uint64_t bb = ballot(cand[r]); bb; bb &= bb - 1) { const int t = ffs64(bb); bcast(rl32(code[r], t), (uint32_t)rl32((int32_t)q[r], t), rl32(ao[r].vol, t)); }
+            if (upper) {
+#pragma unroll
+                for (int r = 0; r < RH; r++)
+                    for (uint64_t bb = ballot(code_h[r] >= 0); bb; bb &= bb - 1) { const int t = ffs64(bb); bcast(rl32(code_h[r], t), (uint32_t)rl32((int32_t)q_h[r], t), rl32(vol_h[r], t)); }
+#pragma unroll
+                for (int r = 0; r < RH; r++) if (code_h[r] >= 0 && need_h[r] > newer_h[r]) cvol_hi[r] = min(vol_h[r], need_h[r] - newer_h[r]);
             }
         }
     }
@@ -1581,6 +1647,15 @@ SDI void build_agent_ops_r(Lds& L, Scal& S, const DevCfg& C, const Act5& action,
             if (cn) { const int at = base + popc64(cm & below); if (at < OPS_MAX) { Op8 op; op.vol = cvol[r]; op.code = LOBSIM_CANCELLATION | (side << 4) | ((ln + 64 * r) << 8); L.ops[at] = op; } }
             base += popc64(cm);
         }
+        if (upper) {
+#pragma unroll
+            for (int r = 0; r < RH; r++) {
+                const bool cn = cvol_hi[r] > 0 && (int)((side_hi >> r) & 1) == side;
+                const uint64_t cm = ballot(cn);
+                if (cn) { const int at = base + popc64(cm & below); if (at < OPS_MAX) { Op8 op; op.vol = cvol_hi[r]; op.code = LOBSIM_CANCELLATION | (side << 4) | ((ln + 64 * (AEL + r)) << 8); L.ops[at] = op; } }
+                base += popc64(cm);
+            }
+        }
     }
     S.n_ops = base;
     if (clearing) {  // _get_inventory_clearing_market_order (:260-266)
@@ -1590,17 +1665,6 @@ SDI void build_agent_ops_r(Lds& L, Scal& S, const DevCfg& C, const Act5& action,
     if (S.n_ops > OPS_MAX) S.status |= LOBSIM_ST_AGENT_OVERFLOW;
     wsync();
     SUBSTAMP(6);
-}
-
-// (The variant that looks at all four entries per lane - a table with live orders beyond its on-chip half - stays INLINE behind its
-// never-taken branch.  As a real function (one call site, plain values in and out, the configuration handed over as eight scalars) it
-// left the specialised step kernel with 44 spilled vector registers and 144 B of scratch where the inlined form has none: a call site
-// constrains the caller's whole allocation.)
-SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, int32_t desired, bool want_info = false) {
-    if constexpr (AE > 2) {
-        if (UNLIKELY(!ag_upper_free(L))) { build_agent_ops_r<AE>(L, S, C, action, desired, want_info); return; }
-    }
-    build_agent_ops_r<2>(L, S, C, action, desired, want_info);
 }
 
 // per-lane binary search of a price in the sorted ladder of one side; -1 if there is no such level
