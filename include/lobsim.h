@@ -152,6 +152,11 @@ typedef struct lobsim_cfg {
     lobsim_reward per_step_reward;
     lobsim_reward terminal_reward;
     lobsim_feature features[LOBSIM_MAX_FEATURES];
+    int32_t queue_pages; /* 1 KiB pages (64 order slots) of queue memory per env: a level's queue takes 1, 4 or 16 of them by the orders it
+                            holds.  0 = auto: two pages per level of the budget (2 x max_levels levels), at least 1280 - 2304 at the default
+                            budget, which a 30-minute trending day on a thick book (300 levels of ~180 orders) fills to 1300.  Otherwise
+                            rounded up to 256 + a multiple of 16, at most 4352.  What a handle got: lobsim_limits.queue_pages (ignored by the oracle) */
+    int32_t reserved1;
 } lobsim_cfg;
 
 typedef struct lobsim_env_state {

@@ -75,6 +75,8 @@ class Cfg(C.Structure):
         ("per_step_reward", RewardDesc),
         ("terminal_reward", RewardDesc),
         ("features", FeatureDesc * MAX_FEATURES),
+        ("queue_pages", C.c_int32),
+        ("reserved1", C.c_int32),
     ]
 
 
@@ -229,6 +231,7 @@ def make_cfg(
     ladder_levels: int = 0,
     max_levels: int = 0,
     agent_orders: int = 0,
+    queue_pages: int = 0,
 ) -> Cfg:
     cfg = Cfg()
     cfg.n_envs, cfg.n_levels, cfg.tick_size, cfg.outer_levels = n_envs, n_levels, tick_size, outer_levels
@@ -258,6 +261,7 @@ def make_cfg(
     cfg.ladder_levels = ladder_levels
     cfg.max_levels = max_levels
     cfg.agent_orders = agent_orders
+    cfg.queue_pages = queue_pages
     return cfg
 
 

@@ -582,6 +582,7 @@ class HistoricalOrderbookVectorEnv(_RayVectorEnv):
         obs_dtype=np.float64,
         agent_orders: int = 0,
         stream_budget_mb: float = 0.0,
+        queue_pages: int = 0,
     ):
         # action space, HistoricalOrderbookEnvironment.py:85-94
         if concentration is not None:
@@ -630,6 +631,7 @@ class HistoricalOrderbookVectorEnv(_RayVectorEnv):
                                     # reference keeps stale levels that left LOBSTER's visible range for the rest of the episode - one per tick of
                                     # price drift; beyond the budget an env stops with LOBSIM_ST_LEVEL_OVERFLOW (env.limits tells what the handle has)
             agent_orders=agent_orders,  # the env's table of live agent orders: 0 = 256, which cannot overflow (include/lobsim.h); 128 = smaller, a little faster
+            queue_pages=queue_pages,  # KiB of order-queue memory per env (0 = two pages per level of the budget: 2304 at the default; up to 4352 for thick AND drifting books)
         )  # fmt: skip
         # observations as the reference returns them are float64 (np.array of Python floats, HistoricalOrderbookEnvironment.py:189-194); its
         # observation_space is float32 (:131-135), which is what RLlib casts to anyway: obs_dtype=np.float32 has the kernel write that
@@ -1072,7 +1074,7 @@ def env_creator(env_config: dict, catalog: StreamCatalog = None, num_envs: Optio
     tickers[i mod T]), and what places and sizes the envs on the GPU - ``device_id`` (default: by the rollout worker's index,
     ``default_device_id``: with ``num_workers=8`` on an 8-GPU node every worker's envs land on their own device instead of all on
     device 0), ``obs_dtype`` ("float32": the kernel writes the observation_space's dtype, 10 - 15 % faster through the array path),
-    ``max_levels``, ``ladder_levels``, ``outer_levels``, ``agent_orders``, ``stream_budget_mb``."""
+    ``max_levels``, ``ladder_levels``, ``outer_levels``, ``agent_orders``, ``stream_budget_mb``, ``queue_pages``."""
     catalog = catalog if catalog is not None else env_config.get("catalog")
     episode_length = timedelta(minutes=env_config["episode_length"])
     step_size = timedelta(seconds=env_config["step_size"])
@@ -1094,7 +1096,7 @@ def env_creator(env_config: dict, catalog: StreamCatalog = None, num_envs: Optio
     )  # fmt: skip
     dev = env_config.get("device_id")
     kw["device_id"] = default_device_id(env_config) if dev is None else int(dev)
-    for key in ("max_levels", "ladder_levels", "outer_levels", "agent_orders", "stream_budget_mb"):
+    for key in ("max_levels", "ladder_levels", "outer_levels", "agent_orders", "stream_budget_mb", "queue_pages"):
         if env_config.get(key) is not None:
             kw[key] = env_config[key]
     if env_config.get("obs_dtype") is not None:

@@ -26,7 +26,7 @@ def test_struct_sizes_match_header():
 
     assert C.sizeof(_capi.FeatureDesc) == 56
     assert C.sizeof(_capi.RewardDesc) == 24
-    assert C.sizeof(_capi.Cfg) == 16 * 4 + 3 * 8 + 2 * 8 + 2 * 24 + 16 * 56
+    assert C.sizeof(_capi.Cfg) == 16 * 4 + 3 * 8 + 2 * 8 + 2 * 24 + 16 * 56 + 2 * 4
     assert C.sizeof(_capi.EnvState) == 11 * 8 + 6 * 4 + 7 * 8
     assert C.sizeof(_capi.OrderView) == 24
 

@@ -206,6 +206,11 @@ def test_limits_and_default_level_budget():
         if max_levels == 0:
             assert lim["queue_pages"] == 256 + 2048 and lim["bytes_per_env"] < 2.8 * 2**20  # (16.5 MiB until round 5: every level owned 16 KiB)
         s.close()
+    s = _lib.new_sim(_capi.make_cfg(4, 10, feats, queue_pages=4000))  # an explicit pool: 256 + a multiple of 16 pages
+    assert s.limits()["queue_pages"] == 256 + 16 * 234 and s.limits()["level_slabs"] == 1024
+    s.close()
+    with pytest.raises(_capi.LobsimError):
+        _lib.new_sim(_capi.make_cfg(4, 10, feats, queue_pages=100))
     assert _lib.binding().fn["abi_version"]() == _capi.ABI_VERSION
 
 
