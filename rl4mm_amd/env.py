@@ -1004,6 +1004,14 @@ class HistoricalOrderbookVectorEnv(_RayVectorEnv):
     def get_sub_environments(self):
         return []
 
+    def restart_at(self, index: Optional[int] = None) -> None:
+        """RLlib (ray >= 2.0) calls this for a sub-environment that raised, before it resets it: the env's device state is rebuilt by
+        the reset that follows, so there is nothing to tear down here (the reference env is a CPU object that RLlib would re-create)."""
+        return None
+
+    def try_render_at(self, index: Optional[int] = None):
+        return None  # the reference's render() is a no-op too (HistoricalOrderbookEnvironment.py:353-358)
+
     def portfolios(self):
         """(inventory int64[N], cash int64[N], price f64[N]) straight from device state."""
         return self.sim.portfolios()
