@@ -53,7 +53,9 @@ enum lobsim_error {
 };
 
 /* Per-env status bits (sticky until the env is reset).  They stand in for the Python exceptions the reference
- * raises on the same conditions; an env with any bit set reports done=1 and stops advancing. */
+ * raises on the same conditions; an env with any bit set reports done=1, reward 0 and stops advancing.  The reference has no
+ * observation for such a step (the exception leaves `step` / `reset`): the observation row of an env whose status is nonzero is
+ * unspecified - compare statuses, not rows (the env facade raises / puts the condition into info["error"]). */
 enum lobsim_status {
     LOBSIM_ST_EMPTY_BOOK = 1,      /* EmptyOrderbookError, rl4mm/orderbook/Exchange.py:180-186 */
     LOBSIM_ST_BAD_MESSAGE = 2,     /* cross_trade assert / trading_halt crash, HistoricalOrderGenerator.py:54-56 */

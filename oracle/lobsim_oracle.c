@@ -1040,6 +1040,8 @@ void oracle_rolling_sharpe(int max_window, int min_window, const double* aum, in
 int oracle_create(const lobsim_cfg* cfg, oracle_t** out) {
     if (!cfg || !out || cfg->n_envs <= 0 || cfg->n_features > LOBSIM_MAX_FEATURES) return LOBSIM_ERR_ARG;
     if (cfg->max_quote_level - cfg->min_quote_level > 128 || cfg->max_quote_level <= cfg->min_quote_level) return LOBSIM_ERR_ARG;
+    /* reset_episode asserts that the replay starts on the second (OrderbookSimulator.py:61); it starts `warm-up` before the episode */
+    if (cfg->warmup_us < 0 || cfg->warmup_us % 1000000 != 0 || cfg->step_us <= 0) return LOBSIM_ERR_ARG;
     const lobsim_reward* rw[2] = {&cfg->per_step_reward, &cfg->terminal_reward};
     for (int i = 0; i < 2; i++) {
         if (rw[i]->kind < LOBSIM_R_PNL || rw[i]->kind > LOBSIM_R_ROLLING_SHARPE) return LOBSIM_ERR_ARG;

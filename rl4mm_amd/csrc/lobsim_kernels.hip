@@ -2805,7 +2805,7 @@ SDI void run_agent_ops(Lds& L, Scal& S, const DevCfg& C) {
 // on its own, lobsim_forward: the simulator has no notion of a step size or of the env's microprice).
 SDI void advance_one_step(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, int stream_id, int64_t& cursor, int64_t& now_us,
                          Ranges& R, int& n_resyncs, double& price, bool with_ops, const MsgBatch& first, int64_t n_msgs, uint64_t ce_first = 0, bool have_ce = false,
-                         EnvHdr* lazy = nullptr, int64_t until_us = -1, bool lazy_parked = false) {
+                         EnvHdr* lazy = nullptr, int64_t until_us = -1, bool lazy_parked = false, bool* forward_returned = nullptr) {
     if (with_ops) run_agent_ops(L, S, C);
     int64_t until = until_us >= 0 ? until_us : now_us + CFG_STEP_US(C);
     if (stream_id >= 0 && !S.status) replay_messages(L, S, P.streams[stream_id], cursor, until, first, ce_first, have_ce);
@@ -2849,7 +2849,18 @@ SDI void advance_one_step(Lds& L, Scal& S, const DevCfg& C, const DevPtrs& P, in
         }
     }
     if (S.status || until_us >= 0) return;
+    // (forward_step has returned: update_internal_state books the step's fills into the portfolio BEFORE it asks for the new price,
+    // HistoricalOrderbookEnvironment.py:199-204 - a status from here on leaves the portfolio as the step made it)
+    if (forward_returned) *forward_returned = true;
     if (!microprice(L, S, price)) S.status |= LOBSIM_ST_EMPTY_BOOK;
+}
+
+// An exception inside OrderbookSimulator.forward_step (EmptyOrderbookError in the middle of a sweep, `assert order.volume > 0`, ...)
+// leaves env.step before update_internal_state: the fills the step had produced so far never reach the portfolio
+// (HistoricalOrderbookEnvironment.py:180-187), and the portfolio is what survives the next reset (Q7).  The kernels book fills as
+// they happen, so a step that stops inside the simulator puts the portfolio back.
+SDI void portfolio_rollback(Lds& L, int64_t inv0, int64_t cash0) {
+    if (lane() == 0) { L.inv = inv0; L.cash = cash0; }
 }
 
 // get_initial_orderbook_from_orders / _get_initial_orders_from_snapshot (Exchange.py:172-178,
@@ -2968,6 +2979,7 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
     if (!S.status) {
         const int64_t inv0 = cur_inv(L), cash0 = cur_cash(L);
         const double p0 = price;
+        bool forward_returned = false;
         build_agent_ops(L, S, C, act, desired, A.info != nullptr);  // convert_action_to_orders on the pre-step state
         if (ln < F) { L.rstash[ln][0] = rw0; L.rstash[ln][1] = rw1; }
 #if LOBSIM_LAZY_LDS
@@ -2977,10 +2989,11 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
 #ifdef LOBSIM_PROFILE
         if (!S.status) run_agent_ops(L, S, C);
         STAMP(3);
-        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, false, first, n_msgs0, ce_first, have_ce, &H, -1, LOBSIM_LAZY_LDS != 0);
+        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, false, first, n_msgs0, ce_first, have_ce, &H, -1, LOBSIM_LAZY_LDS != 0, &forward_returned);
 #else
-        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true, first, n_msgs0, ce_first, have_ce, &H, -1, LOBSIM_LAZY_LDS != 0);
+        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true, first, n_msgs0, ce_first, have_ce, &H, -1, LOBSIM_LAZY_LDS != 0, &forward_returned);
 #endif
+        if (UNLIKELY(S.status && !forward_returned)) portfolio_rollback(L, inv0, cash0);
         STAMP(4);
         SUBSTAMP(7);
         if (ln < F) fs = P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln];  // loaded late: not live across the order loops
@@ -3020,6 +3033,10 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
         }
     }
     if (S.status) { done = 1; reward = 0.0; }
+    if (UNLIKELY(entry_status != 0)) {  // stepped again after it stopped: the row shows what it showed last (as the multi-step launch does)
+        if (ln < F) fs = P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln];
+        act.v0 = H.prev_action[0]; act.v1 = H.prev_action[1]; act.v2 = H.prev_action[2]; act.v3 = H.prev_action[3]; act.v4 = H.prev_action[4];
+    }
     STAMP(5);
     // outputs
     double val = 0.0;
@@ -3147,7 +3164,9 @@ SDI void rollout_body(const DevCfg& C, const DevPtrs& P, const RolloutArgs& A) {
         const bool want_info = A.info != nullptr || A.trace != nullptr;
         build_agent_ops(L, S, C, act, want_info);
         if (ln == 0) { L.act[0] = act.v0; L.act[1] = act.v1; L.act[2] = act.v2; L.act[3] = act.v3; L.act[4] = act.v4; }
-        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true, first, n_msgs_all, 0, false, &H);
+        bool forward_returned = false;
+        if (!S.status) advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, true, first, n_msgs_all, 0, false, &H, -1, false, &forward_returned);
+        if (UNLIKELY(S.status && !forward_returned)) portfolio_rollback(L, inv0, cash0);
         if (!S.status) {
             StepView v = make_view(L, S, price, now);
             bool ok = true;
@@ -3439,12 +3458,14 @@ SDI void forward_body(const DevCfg& C, const DevPtrs& P, const ForwardArgs& A) {
         return;
     }
     const int n_int = A.n_orders ? A.n_orders[k] : 0;
+    const int64_t inv0 = cur_inv(L), cash0 = cur_cash(L);
     for (int i = 0; i < n_int && !S.status; i++) process_raw_order(L, S, A.orders + ((size_t)k * A.max_orders + i) * 6);
     if (!S.status) {
         MsgBatch first = fetch_messages(msgs0, stream_id >= 0 ? cursor : 0);
         if (stream_id < 0) first.t = INT64_MAX;
         advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, false, first, n_msgs, 0, false, &H, until);
     }
+    if (S.status && !entry_status) portfolio_rollback(L, inv0, cash0);  // (the caller of a forward_step that raised has no fills to book)
     double val = 0.0;
     if ((A.flags & LOBSIM_FWD_UPDATE_FEATURES) && !S.status) {
         if (!microprice(L, S, price)) S.status |= LOBSIM_ST_EMPTY_BOOK;

@@ -1,0 +1,197 @@
+"""Diagnostic (not part of the suite): RANDOM env configurations on RANDOM synthetic days, the HIP library against the CPU oracle,
+every env compared at every step.  The suite's parity tests walk a handful of named configurations; this draws them - quote range
+(`min_quote_level`, `max_quote_level`), concentration mode, market-order clearing, `enter_spread`, previous action in the
+observation, step size, feature subset with random look-backs and clocks, reward kind, `outer_levels`, on-chip ladder width,
+agent-order table, level budget - so that combinations nobody thought of get their chance (mostly on the generic kernels: only the
+default configuration runs the specialised ones).  A case that differs is printed with its seed: `python tests/diag/config_fuzz.py
+<seed> <seed+1>` replays it alone.
+usage: python tests/diag/config_fuzz.py [first_seed=0] [end_seed=40] [envs=96]"""
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import oracle_lib as ol
+from rl4mm_amd import _capi, _lib
+from rl4mm_amd.synth import synthetic_stream
+
+RTOL, ATOL = 1e-12, 1e-9
+STATE_KEYS = ("now_us", "n_agent_orders", "n_resyncs", "min_buy_price", "max_sell_price", "status", "agent_fill_count", "agent_buy_volume", "agent_sell_volume",
+              "ext_buy_count", "ext_sell_count", "ext_buy_volume", "ext_sell_volume", "n_buy_levels", "n_sell_levels", "best_buy", "best_sell")  # fmt: skip
+
+
+def draw_case(seed: int, n: int):
+    r = np.random.Generator(np.random.PCG64(90_000 + seed))
+    F = _capi.make_feature
+    step_us = int(r.choice([50_000, 100_000, 100_000, 100_000, 200_000, 250_000, 500_000, 1_000_000]))
+    ep_steps = int(r.integers(15, 60))
+    episode_us = ep_steps * step_us
+    n_levels = int(r.choice([5, 10, 10, 20, 50]))
+    rate = float(r.choice([40, 120, 200, 400, 900]))
+    clock = lambda: int(r.choice([step_us, step_us, 2 * step_us, 1_000_000 if 1_000_000 % step_us == 0 else step_us]))
+    # every feature's window must end inside the day's first minute and a half (the stream starts 100 s before the first episode)
+    lb = lambda u, hi: int(r.integers(1, max(2, min(hi, 60_000_000 // u))))
+    pool = [
+        lambda: F(_capi.F_SPREAD, 0, clock(), 0, float(r.choice([300, 5000]))),
+        lambda: (lambda u: F(_capi.F_PRICE_MOVE, lb(u, 30), u, -1e4, 1e4))(clock()),
+        lambda: (lambda u: F(_capi.F_VOLATILITY, lb(u, 80), u, 0, 1.0))(clock()),
+        lambda: F(_capi.F_INVENTORY, 0, clock(), -float(r.choice([50, 1e6])), float(r.choice([50, 1e6]))),
+        lambda: F(_capi.F_EPISODE_PROPORTION, 0, step_us, 0, 1.0, dparam=step_us / episode_us),
+        lambda: F(_capi.F_TIME_OF_DAY, 0, int(r.choice([step_us, 60_000_000])), 0, 9, iparam=int(r.choice([1_980_000_000, 7_000_000, 600_000_000]))),
+        lambda: (lambda u: F(_capi.F_TRADE_DIRECTION_IMBALANCE, lb(u, 60), u, -1, 1, iparam=int(r.integers(0, 2))))(clock()),
+        lambda: (lambda u: F(_capi.F_TRADE_VOLUME_IMBALANCE, lb(u, 60), u, -1, 1, iparam=int(r.integers(0, 2))))(clock()),
+        lambda: F(_capi.F_BOOK_IMBALANCE, 0, clock(), -1, 1),
+        lambda: (lambda u: F(_capi.F_PRICE_RANGE, lb(u, 12), u, 0, 1e4))(clock()),
+        lambda: F(_capi.F_PRICE, 0, clock(), 0, 1e8),
+        lambda: (lambda u, s: F(_capi.F_AMIHUD_LAMBDA, s * int(r.integers(2, 6)), u, 0, 1.0, iparam=s))(step_us, int(r.integers(1, 4))),
+    ]
+    k = int(r.integers(2, 13))
+    feats = [pool[i]() for i in sorted(r.choice(len(pool), size=min(k, len(pool)), replace=False))]
+    if r.random() < 0.3:
+        feats += [pool[int(r.integers(1, 3))]() for _ in range(int(r.integers(1, 4)))]  # second and third windows of the same kind
+    feats = feats[: _capi.MAX_FEATURES]
+    # the longest window is the warm-up, and an episode's replay starts `warm-up` before a whole second: the reference asserts that
+    # this is a whole second too (OrderbookSimulator.py:61), so the longest window is stretched to one
+    w = max(range(len(feats)), key=lambda i: feats[i].lookback * feats[i].update_us)
+    while (feats[w].lookback * feats[w].update_us) % 1_000_000 != 0 or any(f.lookback * f.update_us > feats[w].lookback * feats[w].update_us for f in feats):
+        feats[w].lookback += int(feats[w].iparam) if feats[w].kind == _capi.F_AMIHUD_LAMBDA else 1
+    minq = int(r.choice([0, 0, 1, 2]))
+    q = int(r.choice([2, 3, 5, 8, 10, 10, 12, 16, 18]))
+    conc = float(r.choice([5.0, 11.0, 30.0])) if r.random() < 0.3 else None
+    moc = bool(r.random() < 0.35)
+    rewards = [(_capi.R_PNL, 0, 0.0), (_capi.R_INVENTORY_ADJUSTED, 1, 0.1), (_capi.R_INVENTORY_ADJUSTED, 0, float(r.choice([0.01, 0.5])))]
+    table = int(r.choice([0, 0, 128, 256])) if q <= 10 else int(r.choice([0, 256]))
+    kw = dict(step_us=step_us, episode_us=episode_us, outer_levels=int(r.choice([3, 10, 20, 40])), min_quote_level=minq, max_quote_level=minq + q, concentration=conc,
+              market_order_clearing=moc, market_order_fraction_of_inventory=float(r.choice([0.25, 0.5, 1.0])) if moc else 0.0, enter_spread=bool(r.random() < 0.4),
+              inc_prev_action_in_obs=bool(r.random() < 0.4), per_step_reward=rewards[int(r.integers(0, 3))], terminal_reward=rewards[int(r.integers(0, 3))],
+              ladder_levels=int(r.choice([0, 0, 64, 128])) if n_levels <= 64 else int(r.choice([0, 128])), max_levels=int(r.choice([0, 0, 64, 256])), agent_orders=table)  # fmt: skip
+    cfg = _capi.make_cfg(n, n_levels, feats, **kw)
+    warm_s = -(-cfg.warmup_us // 1_000_000)
+    t0 = 35_600  # 09:53:20
+    total_s = warm_s + 3 * (episode_us // 1_000_000 + 2) + 40  # (an env that stops early - a clearing order of volume 0 is the reference's `assert order.volume > 0` - restarts somewhere in here)
+    if r.random() < 0.25:  # a day whose price walks away: far levels, outer-level resyncs (tests/drift_stream.py)
+        from drift_stream import drift_stream, ramp_path, triangle_path
+
+        path = ramp_path(float(r.choice([0.2, 0.5, 2.0])), int(r.choice([-1, 1]))) if r.random() < 0.5 else triangle_path(int(r.choice([15, 40, 120])), float(r.choice([0.1, 0.3, 1.0])))
+        stream = drift_stream(7_000 + seed, path, n_levels=n_levels, start_s=t0, duration_s=total_s + 5, noise_per_s=float(r.choice([12.0, 60.0])), max_excursion=int((total_s + 5) / 0.1) + 200)
+        rate = -1.0
+    else:
+        stream = synthetic_stream(7_000 + seed, n_levels=n_levels, msgs_per_s=rate, start_s=t0, end_s=t0 + total_s + 5, mid_price=int(r.choice([60_000, 2_700_000, 2_700_000, 9_990_000])))
+    first = t0 + warm_s + 2
+    starts = (first + r.integers(0, 30, size=n)) * 1_000_000
+    amax = float(r.choice([10.0, 10.0, 3.0, 50.0]))  # (max_distribution_param of the Box: the reference default is 10)
+    desc = dict(kw, n_levels=n_levels, rate=rate, feats=[(f.kind, f.lookback, f.update_us) for f in feats], amax=amax, ep_steps=ep_steps)
+    return cfg, stream, starts, amax, ep_steps, desc, r, (first, total_s - warm_s - episode_us // 1_000_000 - 6)
+
+
+def run_case(seed: int, n: int):
+    cfg, stream, starts, amax, ep_steps, desc, r, (first, span) = draw_case(seed, n)
+    gpu, cpu = (ol.oracle_sim(cfg) if os.environ.get("FUZZ_SELF") else _lib.new_sim(cfg)), ol.oracle_sim(cfg)  # (FUZZ_SELF=1: the harness against itself, no GPU)
+    try:
+        inv0 = int(r.integers(-20, 20))
+        for s in (gpu, cpu):
+            s.add_stream(stream)
+            s.set_portfolio(inv0, 10**9)
+        og, oc = gpu.reset(starts, 0), cpu.reset(starts, 0)
+        sg, sc = gpu.status(), cpu.status()
+        lost = ((sg & 28) != 0) & (sc == 0)  # (a warm-up that outgrew a capacity of the HIP layout: see below)
+        reset_failed = sc != 0
+        if not np.array_equal(sg[~lost], sc[~lost]):
+            return f"first reset: status differs: {sg.tolist()} vs {sc.tolist()}", desc
+        og[lost | reset_failed], oc[lost | reset_failed] = 0.0, 0.0
+        if not np.allclose(og, oc, rtol=RTOL, atol=ATOL):
+            return f"reset obs differ by {np.abs(og - oc).max()}", desc
+        A = cfg.action_dim
+        high = np.full(A, amax)
+        if cfg.market_order_clearing:
+            high[-1] = float(r.choice([5.0, 60.0, 400.0]))
+        steps = 2 * ep_steps + 8
+        resets = flagged_steps = 0
+        capacity_stops = int(lost.sum())
+        for t in range(steps):
+            act = r.uniform(0, high, size=(n, A))
+            m = r.random(n)
+            act[m < 0.03] = 0.0  # (the Box's corners: the distributor adds EPS)
+            act[(m >= 0.03) & (m < 0.06)] = high
+            og, rg, dg = gpu.step(act)
+            oc, rc, dc = cpu.step(act)
+            sg, sc = gpu.status(), cpu.status()
+            # a capacity of the HIP layout (level budget, queue pages, agent table: bits 4 / 8 / 16) is not a difference: the oracle
+            # has none (include/lobsim.h).  Such an env leaves the comparison until its next reset
+            lost |= ((sg & 28) != 0) & (sc == 0)
+            capacity_stops += int((((sg & 28) != 0) & (sc == 0)).sum())
+            if not np.array_equal(sg[~lost], sc[~lost]):
+                e = int(np.nonzero((sg != sc) & ~lost)[0][0])
+                return f"step {t}: status differs in env {e}: {sg[e]} vs {sc[e]}", desc
+            skip = lost | reset_failed  # (an env whose RESET failed has no observation at all: include/lobsim.h)
+            for a in (og, oc, rg, rc): a[skip] = 0.0
+            dg[lost], dc[lost] = 0, 0
+            flagged_steps += int((sg != 0).sum())
+            ig, cg, pg = gpu.portfolios()
+            ic, cc, pc = cpu.portfolios()
+            for what, a, b in (("inventory", ig, ic), ("cash", cg, cc), ("done", dg, dc), ("microprice", pg, pc)):
+                a, b = np.where(lost, 0, a), np.where(lost, 0, b)
+                if not np.array_equal(a, b):
+                    e = int(np.nonzero(a != b)[0][0])
+                    return f"step {t}: {what} differs in env {e}: {a[e]} vs {b[e]} (status gpu {gpu.env_state(e)['status']} / oracle {cpu.env_state(e)['status']})", desc
+            if not np.allclose(og, oc, rtol=RTOL, atol=ATOL):
+                e, f = np.unravel_index(np.argmax(np.abs(og - oc)), og.shape)
+                return f"step {t}: obs differ by {np.abs(og - oc).max()} (env {e}, entry {f}; status gpu {gpu.status()[e]} / oracle {cpu.status()[e]})\n       gpu    {og[e].tolist()}\n       oracle {oc[e].tolist()}", desc
+            if not np.allclose(rg, rc, rtol=0, atol=ATOL):
+                return f"step {t}: reward differs by {np.abs(rg - rc).max()}", desc
+            if dg.any() or lost.any():
+                ids = np.nonzero((dg != 0) | lost)[0].astype(np.int32)
+                resets += len(ids)
+                st_before = sg
+                starts[ids] = (first + r.integers(0, span, size=len(ids))) * 1_000_000
+                if lost.any():  # (the portfolio outlives the episode, Q7: an env that left the comparison re-enters it with the oracle's)
+                    li = np.nonzero(lost)[0].astype(np.int32)
+                    gpu.set_portfolio(ic[li], cc[li], li)
+                o1, o2 = gpu.reset(starts[ids], 0, ids), cpu.reset(starts[ids], 0, ids)
+                s1, s2 = gpu.status()[ids], cpu.status()[ids]
+                if not np.array_equal(s1, s2):
+                    return f"step {t}: status after the reset differs: {s1.tolist()} vs {s2.tolist()}", desc
+                o1[s1 != 0], o2[s1 != 0] = 0.0, 0.0
+                lost[ids] = False
+                reset_failed[ids] = s1 != 0
+                if not np.allclose(o1, o2, rtol=RTOL, atol=ATOL):
+                    k, f = np.unravel_index(np.argmax(np.abs(o1 - o2)), o1.shape)
+                    return f"step {t}: obs after reset differ by {np.abs(o1 - o2).max()} (env {ids[k]}, entry {f}; status before the reset {st_before[ids[k]]})\n       gpu    {o1[k].tolist()}\n       oracle {o2[k].tolist()}", desc
+        for e in np.nonzero(~lost)[0]:
+            sg, sc = gpu.env_state(int(e)), cpu.env_state(int(e))
+            for k in STATE_KEYS:
+                if sg[k] != sc[k]:
+                    return f"end: env {e} {k} {sg[k]} vs {sc[k]}", desc
+        for e in range(0, n, 7):
+            if not lost[e] and not np.array_equal(gpu.queues(e), cpu.queues(e)):
+                return f"end: env {e}: per-order book contents differ", desc
+        st = np.array([gpu.env_state(e)["status"] for e in range(n)])
+        desc = dict(desc, resets=resets, flagged=flagged_steps, capacity_stops=capacity_stops, max_agent_orders=max(gpu.env_state(e)["n_agent_orders"] for e in range(n)), inv_max=int(np.abs(ig).max()))
+        return None, desc
+    finally:
+        gpu.close()
+        cpu.close()
+
+
+if __name__ == "__main__":
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    end = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    n = int(sys.argv[3]) if len(sys.argv) > 3 else 96
+    bad = 0
+    for seed in range(first, end):
+        t = time.time()
+        try:
+            err, desc = run_case(seed, n)
+        except Exception as ex:  # a configuration one side refuses: both must refuse it (reported, not counted as a difference)
+            err, desc = f"EXCEPTION {type(ex).__name__}: {ex}", {}
+        short = {k: desc[k] for k in ("step_us", "n_levels", "rate", "min_quote_level", "max_quote_level", "concentration", "market_order_clearing", "enter_spread", "ladder_levels",
+                                        "agent_orders", "max_levels", "outer_levels", "resets", "flagged", "capacity_stops", "max_agent_orders", "inv_max") if k in desc}  # fmt: skip
+        print(f"seed {seed:4d} {'OK  ' if err is None else 'DIFF'} {time.time() - t:5.1f}s {short}" + (f"\n    -> {err}\n    {desc}" if err else ""), flush=True)
+        bad += err is not None
+    print(f"{end - first} cases, {bad} with a difference or an exception")
+    sys.exit(1 if bad else 0)

@@ -1,0 +1,130 @@
+"""Steps that STOP (the reference raises out of `env.step`) and drawn configurations, the HIP path against the oracle.
+Needs a real MI355X: `pytest -m gpu`.
+
+`tests/diag/config_fuzz.py` draws env configurations (quote range, concentration, market-order clearing, enter_spread, step size,
+feature subsets with random windows and clocks, rewards, outer_levels, ladder width, agent table, level budget) and synthetic days
+(steady and drifting) and compares every env at every step.  Its first long run on the GPU found what the named configurations of
+the suite had not: a step that raises inside `OrderbookSimulator.forward_step` - an `EmptyOrderbookError` in the middle of a sweep -
+leaves `env.step` before `update_internal_state` (HistoricalOrderbookEnvironment.py:180-187, 199-204), so the fills it had produced
+never reach the portfolio, and the portfolio is what survives the reset that follows (Q7).  The kernels book fills as they happen
+and had kept them.  The cases below pin that, and a bounded sample of the drawn configurations runs with the suite."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from rl4mm_amd import _capi, _lib
+from rl4mm_amd.stream import SIDE_SHIFT, TYPE_SHIFT, PackedStream
+
+sys.path.insert(0, str(Path(__file__).resolve().parent / "diag"))
+import config_fuzz  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _thin_stream(bid_vol=100, n_seconds=30):
+    """Three levels a side with `bid_vol` shares each and one small external limit order a second far from the touch."""
+    t0, mid, tick, lv = 36_000, 1_000_000, 100, 3
+    rows = [((t0 + s) * 1_000_000 + 500_000, 1_000 + s, mid - 3 * tick, 10 | (1 << TYPE_SHIFT) | (0 << SIDE_SHIFT)) for s in range(n_seconds)]
+    secs = np.arange(t0, t0 + n_seconds + 1)
+    snaps = np.zeros((len(secs), 2 + 4 * lv), dtype=np.int64)
+    snaps[:, 0], snaps[:, 1] = secs * 1_000_000, np.arange(len(secs))
+    for i in range(lv):
+        snaps[:, 2 + 4 * i], snaps[:, 3 + 4 * i] = mid + tick * (i + 1), 400
+        snaps[:, 4 + 4 * i], snaps[:, 5 + 4 * i] = mid - tick * (i + 1), bid_vol
+    return PackedStream("THIN", "2018-02-21", lv, np.array(rows, dtype=np.int64).reshape(-1, 4), snaps)
+
+
+def _moc_cfg(n):
+    F = _capi.make_feature
+    feats = [F(_capi.F_INVENTORY, 0, 100_000, -1e6, 1e6), F(_capi.F_SPREAD, 0, 100_000, 0, 5000), F(_capi.F_PRICE, 0, 100_000, 0, 1e8)]
+    return _capi.make_cfg(n, 3, feats, step_us=100_000, episode_us=2_000_000, market_order_clearing=True, market_order_fraction_of_inventory=1.0,
+                          inc_prev_action_in_obs=True, max_quote_level=3)  # fmt: skip
+
+
+@pytest.mark.parametrize("launch", ["step", "rollout"])
+def test_a_sweep_that_empties_the_book_leaves_the_portfolio_untouched(launch):
+    """inventory 500 against 300 shares of bids, clearing threshold 0: the step's market order sells 300, then finds no bid -
+    EmptyOrderbookError (Exchange.py:180-186).  The reference's portfolio still says 500 / the old cash (the exception left `step`
+    before `_update_portfolio`), the env is done; after a reset it trades on from 500.  An env next to it whose order the book can
+    fill is booked as always."""
+    n = 4
+    cfg = _moc_cfg(n)
+    gpu, cpu = _lib.new_sim(cfg), ol.oracle_sim(cfg)
+    inv = np.array([500, 120, -700, 0], dtype=np.int64)  # 500: more than the bids hold; 120: fits; -700: fits the asks (1200); 0: no order
+    for s in (gpu, cpu):
+        s.add_stream(_thin_stream())
+        s.set_portfolio(inv, np.full(n, 10**9, dtype=np.int64))
+    starts = np.full(n, 36_002_000_000, dtype=np.int64)
+    og, oc = gpu.reset(starts, 0), cpu.reset(starts, 0)
+    assert np.array_equal(og, oc)
+    act = np.tile(np.array([1.0, 1.0, 1.0, 1.0, 0.0]), (n, 1))  # |inventory| > 0 -> cancel everything, market order for round(|inv| * 1.0)
+    if launch == "step":
+        og, rg, dg = gpu.step(act)
+    else:
+        import torch
+
+        dev = torch.device("cuda", 0)
+        d_act = torch.from_numpy(act[None].copy()).to(dev)
+        d_obs, d_rew, d_done = torch.zeros((n, gpu.obs_dim), dtype=torch.float64, device=dev), torch.zeros(n, dtype=torch.float64, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev)
+        gpu.rollout_device(_capi.POLICY_GIVEN, [], 1, d_act.data_ptr(), 0, d_obs.data_ptr(), 0, d_rew.data_ptr(), d_done.data_ptr())
+        gpu.sync()
+        og, rg, dg = d_obs.cpu().numpy(), d_rew.cpu().numpy(), d_done.cpu().numpy()
+    oc, rc, dc = cpu.step(act)
+    sg, sc = gpu.status(), cpu.status()
+    assert np.array_equal(sg, sc) and sg[0] == _capi.ST_EMPTY_BOOK and not sg[1:].any(), (sg, sc)
+    assert np.array_equal(dg, dc) and dg[0] == 1
+    ig, cg, _ = gpu.portfolios()
+    ic, cc, _ = cpu.portfolios()
+    assert np.array_equal(ig, ic) and np.array_equal(cg, cc), (ig, ic, cg, cc)
+    assert ig[0] == 500 and cg[0] == 10**9, "the step that raised must not reach the portfolio"
+    assert ig[1] == 0 and ig[2] == 0 and cg[1] > 10**9 and cg[2] < 10**9  # the envs whose orders were filled
+    assert np.array_equal(og, oc) and np.array_equal(rg, rc) and rg[0] == 0.0
+    # the book of the stopped env is what the sweep left (the reference's exchange is mutated up to the exception)
+    assert np.array_equal(gpu.queues(0), cpu.queues(0))
+    # stepped again it stays done and shows its last row; reset, it carries the 500 shares into the next episode (Q7)
+    o2g, r2g, d2g = gpu.step(act)
+    o2c, r2c, d2c = cpu.step(act)
+    assert d2g[0] == 1 and np.array_equal(d2g, d2c) and np.array_equal(o2g, o2c) and np.array_equal(r2g, r2c)
+    ids = np.array([0], dtype=np.int32)
+    o3g, o3c = gpu.reset(starts[:1] + 4_000_000, 0, ids), cpu.reset(starts[:1] + 4_000_000, 0, ids)
+    assert np.array_equal(o3g, o3c) and o3g[0, 0] == 500.0  # the inventory feature of the new episode
+    assert not gpu.status()[0]
+    gpu.close()
+    cpu.close()
+
+
+def test_forward_step_that_raises_books_nothing():
+    """The same through OrderbookSimulator.forward_step (lobsim_forward): internal market order for more than the side holds."""
+    cfg = _moc_cfg(2)
+    gpu, cpu = _lib.new_sim(cfg), ol.oracle_sim(cfg)
+    for s in (gpu, cpu):
+        s.add_stream(_thin_stream())
+        s.set_portfolio(7, 1000)
+        s.reset_episode(np.full(2, 36_002_000_000, dtype=np.int64), 0)
+    orders = np.zeros((2, 1, 6), dtype=np.int64)
+    orders[0, 0] = (4, 1, 0, 350, 0, 0)  # {LOBSIM_MARKET, LOBSIM_SELL, price, volume, id, is_external}  # 300 shares of bids
+    orders[1, 0] = (4, 1, 0, 250, 0, 0)
+    until = np.full(2, 36_002_100_000, dtype=np.int64)
+    gpu.forward(until, orders)
+    cpu.forward(until, orders)
+    assert np.array_equal(gpu.status(), cpu.status()) and gpu.status()[0] == _capi.ST_EMPTY_BOOK and gpu.status()[1] == 0
+    ig, cg, _ = gpu.portfolios()
+    ic, cc, _ = cpu.portfolios()
+    assert np.array_equal(ig, ic) and np.array_equal(cg, cc)
+    assert ig[0] == 7 and cg[0] == 1000 and ig[1] == 7 - 250
+    gpu.close()
+    cpu.close()
+
+
+# seeds of tests/diag/config_fuzz.py: the first eleven are the ones whose drifting days stop envs in the middle of a sweep (they
+# differed before the portfolio was put back); the rest is a plain sample
+FUZZ_SEEDS = [40, 77, 84, 93, 121, 125, 159, 192, 201, 237, 254] + list(range(300, 324))
+
+
+@pytest.mark.parametrize("seed", FUZZ_SEEDS)
+def test_drawn_configuration_against_oracle(seed):
+    err, desc = config_fuzz.run_case(seed, 64)
+    assert err is None, f"{err}\n{desc}"
