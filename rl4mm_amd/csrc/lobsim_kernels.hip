@@ -290,6 +290,7 @@ struct Scal {
     bool ahead = false;     // ... and does this kernel squeeze ahead of time at all (the per-step kernel does: it is the one whose
                             // launches end with their slowest env; a multi-step launch only pays for the extra squeezes)
     int64_t q_buy, q_sell;  // best prices the current op list was built against (_get_best_prices)
+    bool quotes_cross = false;  // enter_spread only: a quote of the current op list would execute against the book as it stands (see build_agent_ops)
     Slot* slots;            // this env's slabs
     uint64_t* idc;          // this env's position cache of external orders (see IDC_N)
 #ifdef LOBSIM_PROFILE_MSG
@@ -1457,9 +1458,16 @@ SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, i
     if (S.n_lv[LOBSIM_SELL] == 0) { S.status |= LOBSIM_ST_EMPTY_BOOK; return; }  // np.arange(inf) raises
     int64_t best_buy = S.n_lv[LOBSIM_BUY] ? uni64(L.price[LOBSIM_BUY][0]) : 0, best_sell = uni64(L.price[LOBSIM_SELL][0]);
     if (CFG_SPREAD(C)) {
+        const int64_t book_buy = best_buy, book_sell = best_sell;
         double mid = ((double)best_sell + (double)best_buy) / 2;
         best_buy = (int64_t)(floor(mid / (double)tick) * (double)tick);
         best_sell = (int64_t)(ceil(mid / (double)tick) * (double)tick);
+        // On a CROSSED book (best bid >= best ask: update_outer_levels puts snapshot levels back without matching them against what
+        // rests on the other side, OrderbookSimulator.py:99-135) the midprice's floor / ceil lie between the two bests in the wrong
+        // order: the highest buy quote is at or above the best ask - submit_order executes it (Exchange.py:71-83) - while the quotes
+        // themselves are still ordered (best_buy < best_sell here), which is all the lane-parallel path of run_agent_ops asks when the
+        // quotes ARE the book's best prices.
+        S.quotes_cross = !(lt64(best_buy, book_sell) && lt64(book_buy, best_sell));
     }
     S.q_buy = best_buy; S.q_sell = best_sell;
     SUBSTAMP(3);
@@ -2506,8 +2514,13 @@ SDI double feature_normalise(double* hist, int cap, double value) {
     return (value - mean) / sqrt(var);
 }
 
-SDI bool feature_reset(const lobsim_feature& d, FeatState& f, int64_t* ring, const StepView& v, int64_t first_usage, double* hist) {  // _reset, :92-96
+// `carried`: the feature's current_value from before the reset.  Feature objects outlive the episode and neither reset() nor _reset()
+// touches current_value (Features.py:88-96): _update assigns it for every kind but one - AmihudLambda between two of its slow
+// updates (slowing_factor > 1, :287-290) leaves it alone, so the first steps of the new episode still show (and, with
+// normalisation_on, append to the fresh history and z-score: update() normalises whatever current_value holds, :80-86) the old one.
+SDI bool feature_reset(const lobsim_feature& d, FeatState& f, int64_t* ring, const StepView& v, int64_t first_usage, double* hist, double carried) {  // _reset, :92-96
     if (hist) reinterpret_cast<int64_t*>(hist)[0] = 0;  // history.clear()
+    f.current_value = carried;
     f.count = 0; f.pos = 0; f.total = 0; f.diff = 0; f.acc = 0.0; f.p_first = 0.0; f.p_last = 0.0;
     f.first_usage_us = first_usage;
     if (d.kind == LOBSIM_F_AMIHUD_LAMBDA) f.diff = d.iparam - 1;  // steps_until_update (Features.py:278-283)
@@ -2782,7 +2795,10 @@ SDI void run_agent_ops(Lds& L, Scal& S, const DevCfg& C) {
     uint64_t todo = S.n_ops >= 64 ? ~0ull : (1ull << S.n_ops) - 1;
     bool has_market = false;
     if (S.n_ops > 0) has_market = (uni(L.ops[S.n_ops - 1].code) & 0xf) == LOBSIM_MARKET;  // the clearing order is last
-    if (S.n_ops <= 64 && !has_market && S.q_buy < S.q_sell) todo = apply_agent_ops_parallel(L, S, C);
+    // (the lane-parallel path books limit orders without asking whether they execute: only when none can - the quotes are ordered and,
+    // with enter_spread, on their own sides of the book's best prices)
+    const bool resting_only = S.q_buy < S.q_sell && !(CFG_SPREAD(C) && S.quotes_cross);
+    if (S.n_ops <= 64 && !has_market && resting_only) todo = apply_agent_ops_parallel(L, S, C);
     if (S.n_ops <= 64) {
         while (todo && !S.status) {
             int k = ffs64(todo); todo &= todo - 1; EVENT(ev_serial_ops);
@@ -3263,12 +3279,14 @@ SDI void reset_body(const DevCfg& C, const DevPtrs& P, const ResetArgs& A) {
     FeatState fs = FeatState();
     int64_t* ring = nullptr;
     if (ln < F) ring = P.rings + (size_t)env * C.ring_words + C.ring_off[ln];
+    const double carried_value = ln < F ? P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln].current_value : 0.0;  // (zero until the env's first reset: lobsim_create)
+    fs.current_value = carried_value;  // (a reset that fails before it reaches the features leaves them what they showed)
     if (!S.status) {
         StepView v = make_view(L, S, price, now);
         bool ok = true;
         if (ln < F) {
             const lobsim_feature& d = C.c.features[ln];
-            ok = feature_reset(d, fs, ring, v, start - (int64_t)d.lookback * d.update_us, norm_history(C, P, env, ln));
+            ok = feature_reset(d, fs, ring, v, start - (int64_t)d.lookback * d.update_us, norm_history(C, P, env, ln), carried_value);
         }
         if (ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
     }
@@ -3504,7 +3522,8 @@ SDI void features_reset_body(const DevCfg& C, const DevPtrs& P, const int32_t* e
         bool ok = true;
         if (ln < F) {
             FeatState fs = FeatState();
-            ok = feature_reset(C.c.features[ln], fs, P.rings + (size_t)env * C.ring_words + C.ring_off[ln], v, now, norm_history(C, P, env, ln));
+            ok = feature_reset(C.c.features[ln], fs, P.rings + (size_t)env * C.ring_words + C.ring_off[ln], v, now, norm_history(C, P, env, ln),
+                               P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln].current_value);
             P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln] = fs;
         }
         if (ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;

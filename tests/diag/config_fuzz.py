@@ -2,7 +2,8 @@
 every env compared at every step.  The suite's parity tests walk a handful of named configurations; this draws them - quote range
 (`min_quote_level`, `max_quote_level`), concentration mode, market-order clearing, `enter_spread`, previous action in the
 observation, step size, feature subset with random look-backs and clocks, reward kind, `outer_levels`, on-chip ladder width,
-agent-order table, level budget - so that combinations nobody thought of get their chance (mostly on the generic kernels: only the
+agent-order table, level budget, z-score normalisation, RollingSharpe rewards, per-step or multi-step launches, a few malformed
+messages in the day - so that combinations nobody thought of get their chance (mostly on the generic kernels: only the
 default configuration runs the specialised ones).  A case that differs is printed with its seed: `python tests/diag/config_fuzz.py
 <seed> <seed+1>` replays it alone.
 usage: python tests/diag/config_fuzz.py [first_seed=0] [end_seed=40] [envs=96]"""
@@ -55,6 +56,12 @@ def draw_case(seed: int, n: int):
     if r.random() < 0.3:
         feats += [pool[int(r.integers(1, 3))]() for _ in range(int(r.integers(1, 4)))]  # second and third windows of the same kind
     feats = feats[: _capi.MAX_FEATURES]
+    extras = r.random()  # (drawn for every case so that a seed's other draws do not depend on the mode)
+    norm_lens = r.choice([2, 7, 40, 600], size=len(feats))
+    norm_on = r.random(len(feats)) < 0.5
+    if 0.70 <= extras < 0.85:  # normalisation_on (Features.py:60-74): some features z-scored against a history that wraps or only grows
+        for f, ln_, on in zip(feats, norm_lens, norm_on):
+            if on: f.norm_len = int(ln_)
     # the longest window is the warm-up, and an episode's replay starts `warm-up` before a whole second: the reference asserts that
     # this is a whole second too (OrderbookSimulator.py:61), so the longest window is stretched to one
     w = max(range(len(feats)), key=lambda i: feats[i].lookback * feats[i].update_us)
@@ -65,11 +72,17 @@ def draw_case(seed: int, n: int):
     conc = float(r.choice([5.0, 11.0, 30.0])) if r.random() < 0.3 else None
     moc = bool(r.random() < 0.35)
     rewards = [(_capi.R_PNL, 0, 0.0), (_capi.R_INVENTORY_ADJUSTED, 1, 0.1), (_capi.R_INVENTORY_ADJUSTED, 0, float(r.choice([0.01, 0.5])))]
+    rs = (_capi.R_ROLLING_SHARPE, 0, 0.0, int(r.choice([8, 32, 120])), int(r.choice([2, 5, 8])))  # (kind, -, -, max_window, min_window)
+    sharpe = extras >= 0.85
     table = int(r.choice([0, 0, 128, 256])) if q <= 10 else int(r.choice([0, 256]))
     kw = dict(step_us=step_us, episode_us=episode_us, outer_levels=int(r.choice([3, 10, 20, 40])), min_quote_level=minq, max_quote_level=minq + q, concentration=conc,
               market_order_clearing=moc, market_order_fraction_of_inventory=float(r.choice([0.25, 0.5, 1.0])) if moc else 0.0, enter_spread=bool(r.random() < 0.4),
               inc_prev_action_in_obs=bool(r.random() < 0.4), per_step_reward=rewards[int(r.integers(0, 3))], terminal_reward=rewards[int(r.integers(0, 3))],
               ladder_levels=int(r.choice([0, 0, 64, 128])) if n_levels <= 64 else int(r.choice([0, 128])), max_levels=int(r.choice([0, 0, 64, 256])), agent_orders=table)  # fmt: skip
+    if sharpe:  # RollingSharpe per step, at the end, or both (RewardFunctions.py:38-94)
+        which = int(r.integers(0, 3))
+        if which != 1: kw["per_step_reward"] = rs
+        if which != 0: kw["terminal_reward"] = rs
     cfg = _capi.make_cfg(n, n_levels, feats, **kw)
     warm_s = -(-cfg.warmup_us // 1_000_000)
     t0 = 35_600  # 09:53:20
@@ -82,15 +95,48 @@ def draw_case(seed: int, n: int):
         rate = -1.0
     else:
         stream = synthetic_stream(7_000 + seed, n_levels=n_levels, msgs_per_s=rate, start_s=t0, end_s=t0 + total_s + 5, mid_price=int(r.choice([60_000, 2_700_000, 2_700_000, 9_990_000])))
+    bad_msgs = 0
+    if r.random() < 0.12 and stream.n_msgs > 2000:  # a cross trade / trading halt / zero-volume message somewhere in the day: the reference
+        from rl4mm_amd.stream import TYPE_SHIFT  # asserts (HistoricalOrderGenerator.py:54-56, Exchange.py:59-60), every env that replays it stops
+
+        for k in r.integers(stream.n_msgs // 3, stream.n_msgs, size=int(r.integers(1, 3))):
+            kind = int(r.integers(0, 3))
+            if kind == 2: stream.msgs[k, 3] &= ~((1 << TYPE_SHIFT) - 1)  # volume 0
+            else: stream.msgs[k, 3] = (stream.msgs[k, 3] & ~(0xF << TYPE_SHIFT)) | ((6 + kind) << TYPE_SHIFT)
+            bad_msgs += 1
     first = t0 + warm_s + 2
     starts = (first + r.integers(0, 30, size=n)) * 1_000_000
     amax = float(r.choice([10.0, 10.0, 3.0, 50.0]))  # (max_distribution_param of the Box: the reference default is 10)
-    desc = dict(kw, n_levels=n_levels, rate=rate, feats=[(f.kind, f.lookback, f.update_us) for f in feats], amax=amax, ep_steps=ep_steps)
-    return cfg, stream, starts, amax, ep_steps, desc, r, (first, total_s - warm_s - episode_us // 1_000_000 - 6)
+    chunk = int(r.integers(2, 8)) if r.random() < 0.35 else 0  # steps per multi-step launch (lobsim_rollout_device); 0 = one launch per step
+    desc = dict(kw, n_levels=n_levels, rate=rate, feats=[(f.kind, f.lookback, f.update_us, f.norm_len) for f in feats], amax=amax, ep_steps=ep_steps, chunk=chunk, bad_msgs=bad_msgs,
+                sharpe=sharpe, normalised=int(sum(f.norm_len > 0 for f in feats)))
+    return cfg, stream, starts, amax, ep_steps, desc, r, (first, total_s - warm_s - episode_us // 1_000_000 - 6), chunk
+
+
+def _rollout(sim, acts):
+    """acts [T, n, A] through one multi-step launch (policy GIVEN) -> (obs, reward, done, (steps taken, return))."""
+    T, n = acts.shape[0], acts.shape[1]
+    if sim.b.prefix == "oracle_":
+        out = ol.oracle_rollout(sim, _capi.POLICY_GIVEN, [], T, acts, want_actions=False)
+        return out["obs"], out["reward"], out["done"], (out["steps"], out["ret"])
+    import torch
+
+    dev = torch.device("cuda", 0)
+    d_act = torch.from_numpy(np.ascontiguousarray(acts)).to(dev)
+    obs, rew, done = torch.zeros((n, sim.obs_dim), dtype=torch.float64, device=dev), torch.zeros(n, dtype=torch.float64, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev)
+    ret, steps = torch.zeros(n, dtype=torch.float64, device=dev), torch.zeros(n, dtype=torch.int32, device=dev)
+    sim.rollout_device(_capi.POLICY_GIVEN, [], T, d_act.data_ptr(), 0, obs.data_ptr(), 0, rew.data_ptr(), done.data_ptr(), ret.data_ptr(), steps.data_ptr())
+    sim.sync()
+    return obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy(), (steps.cpu().numpy(), ret.cpu().numpy())
 
 
 def run_case(seed: int, n: int):
-    cfg, stream, starts, amax, ep_steps, desc, r, (first, span) = draw_case(seed, n)
+    cfg, stream, starts, amax, ep_steps, desc, r, (first, span), chunk = draw_case(seed, n)
+    # RollingSharpe is mean / std of a window's log returns.  With a portfolio of 1e9 in cash and a few shares the AUM moves by O(1) a
+    # step: log returns of 1e-9, which f64 resolves to 1e-7 relative - the last bits in which ocml's exp / log differ from libm's (and
+    # both from the reference's numpy: 4.4e-8 on the recorded trajectory, tests/test_gpu_parity.py) show at 1e-6 in the ratio.  That is
+    # the formula's conditioning, not a difference of the paths: every other reward is compared to 1e-9 absolute
+    r_rtol, r_atol = (1e-5, 1e-6) if desc["sharpe"] else (0.0, ATOL)
     gpu, cpu = (ol.oracle_sim(cfg) if os.environ.get("FUZZ_SELF") else _lib.new_sim(cfg)), ol.oracle_sim(cfg)  # (FUZZ_SELF=1: the harness against itself, no GPU)
     try:
         inv0 = int(r.integers(-20, 20))
@@ -99,36 +145,43 @@ def run_case(seed: int, n: int):
             s.set_portfolio(inv0, 10**9)
         og, oc = gpu.reset(starts, 0), cpu.reset(starts, 0)
         sg, sc = gpu.status(), cpu.status()
-        lost = ((sg & 28) != 0) & (sc == 0)  # (a warm-up that outgrew a capacity of the HIP layout: see below)
+        lost = (sg & 28) != 0  # (a warm-up that outgrew a capacity of the HIP layout: see below)
         reset_failed = sc != 0
         if not np.array_equal(sg[~lost], sc[~lost]):
             return f"first reset: status differs: {sg.tolist()} vs {sc.tolist()}", desc
         og[lost | reset_failed], oc[lost | reset_failed] = 0.0, 0.0
-        if not np.allclose(og, oc, rtol=RTOL, atol=ATOL):
-            return f"reset obs differ by {np.abs(og - oc).max()}", desc
+        if not np.allclose(og, oc, rtol=RTOL, atol=ATOL, equal_nan=True):
+            return f"reset obs differ by {np.nanmax(np.abs(og - oc))}", desc
         A = cfg.action_dim
         high = np.full(A, amax)
         if cfg.market_order_clearing:
             high[-1] = float(r.choice([5.0, 60.0, 400.0]))
         steps = 2 * ep_steps + 8
+        if chunk: steps = -(-steps // chunk)
         resets = flagged_steps = 0
         capacity_stops = int(lost.sum())
         for t in range(steps):
-            act = r.uniform(0, high, size=(n, A))
-            m = r.random(n)
+            T = chunk or 1
+            act = r.uniform(0, high, size=(T, n, A))
+            m = r.random((T, n))
             act[m < 0.03] = 0.0  # (the Box's corners: the distributor adds EPS)
             act[(m >= 0.03) & (m < 0.06)] = high
-            og, rg, dg = gpu.step(act)
-            oc, rc, dc = cpu.step(act)
+            if chunk:
+                (og, rg, dg, xg), (oc, rc, dc, xc) = _rollout(gpu, act), _rollout(cpu, act)
+            else:
+                og, rg, dg = gpu.step(act[0])
+                oc, rc, dc = cpu.step(act[0])
             sg, sc = gpu.status(), cpu.status()
             # a capacity of the HIP layout (level budget, queue pages, agent table: bits 4 / 8 / 16) is not a difference: the oracle
             # has none (include/lobsim.h).  Such an env leaves the comparison until its next reset
-            lost |= ((sg & 28) != 0) & (sc == 0)
-            capacity_stops += int((((sg & 28) != 0) & (sc == 0)).sum())
+            capacity_stops += int((((sg & 28) != 0) & ~lost).sum())
+            lost |= (sg & 28) != 0
             if not np.array_equal(sg[~lost], sc[~lost]):
                 e = int(np.nonzero((sg != sc) & ~lost)[0][0])
                 return f"step {t}: status differs in env {e}: {sg[e]} vs {sc[e]}", desc
             skip = lost | reset_failed  # (an env whose RESET failed has no observation at all: include/lobsim.h)
+            if chunk and (not np.array_equal(xg[0][~lost], xc[0][~lost]) or not np.allclose(xg[1][~lost], xc[1][~lost], rtol=max(r_rtol, 1e-12), atol=max(r_atol, 1e-6), equal_nan=True)):
+                return f"launch {t}: steps taken / returns of the multi-step launch differ: envs {np.nonzero((xg[0] != xc[0]) & ~lost)[0][:6].tolist()}, {np.nanmax(np.abs(xg[1] - xc[1])[~lost])}", desc
             for a in (og, oc, rg, rc): a[skip] = 0.0
             dg[lost], dc[lost] = 0, 0
             flagged_steps += int((sg != 0).sum())
@@ -139,10 +192,10 @@ def run_case(seed: int, n: int):
                 if not np.array_equal(a, b):
                     e = int(np.nonzero(a != b)[0][0])
                     return f"step {t}: {what} differs in env {e}: {a[e]} vs {b[e]} (status gpu {gpu.env_state(e)['status']} / oracle {cpu.env_state(e)['status']})", desc
-            if not np.allclose(og, oc, rtol=RTOL, atol=ATOL):
-                e, f = np.unravel_index(np.argmax(np.abs(og - oc)), og.shape)
+            if not np.allclose(og, oc, rtol=RTOL, atol=ATOL, equal_nan=True):  # (NaN: the z-score of a constant history, both sides)
+                e, f = np.unravel_index(np.nanargmax(np.abs(og - oc)), og.shape)
                 return f"step {t}: obs differ by {np.abs(og - oc).max()} (env {e}, entry {f}; status gpu {gpu.status()[e]} / oracle {cpu.status()[e]})\n       gpu    {og[e].tolist()}\n       oracle {oc[e].tolist()}", desc
-            if not np.allclose(rg, rc, rtol=0, atol=ATOL):
+            if not np.allclose(rg, rc, rtol=r_rtol, atol=r_atol, equal_nan=True):  # (NaN: a RollingSharpe window of equal values, both sides)
                 return f"step {t}: reward differs by {np.abs(rg - rc).max()}", desc
             if dg.any() or lost.any():
                 ids = np.nonzero((dg != 0) | lost)[0].astype(np.int32)
@@ -154,13 +207,15 @@ def run_case(seed: int, n: int):
                     gpu.set_portfolio(ic[li], cc[li], li)
                 o1, o2 = gpu.reset(starts[ids], 0, ids), cpu.reset(starts[ids], 0, ids)
                 s1, s2 = gpu.status()[ids], cpu.status()[ids]
-                if not np.array_equal(s1, s2):
+                cap = (s1 & 28) != 0  # (a warm-up that outgrew a capacity)
+                capacity_stops += int(cap.sum())
+                if not np.array_equal(s1[~cap], s2[~cap]):
                     return f"step {t}: status after the reset differs: {s1.tolist()} vs {s2.tolist()}", desc
-                o1[s1 != 0], o2[s1 != 0] = 0.0, 0.0
-                lost[ids] = False
-                reset_failed[ids] = s1 != 0
-                if not np.allclose(o1, o2, rtol=RTOL, atol=ATOL):
-                    k, f = np.unravel_index(np.argmax(np.abs(o1 - o2)), o1.shape)
+                o1[(s1 != 0) | (s2 != 0)], o2[(s1 != 0) | (s2 != 0)] = 0.0, 0.0
+                lost[ids] = cap | (lost[ids] & desc["sharpe"])  # (the RollingSharpe window outlives the episode - env.reset never resets the reward function - so an env that left the comparison cannot re-enter it)
+                reset_failed[ids] = s2 != 0
+                if not np.allclose(o1, o2, rtol=RTOL, atol=ATOL, equal_nan=True):
+                    k, f = np.unravel_index(np.nanargmax(np.abs(o1 - o2)), o1.shape)
                     return f"step {t}: obs after reset differ by {np.abs(o1 - o2).max()} (env {ids[k]}, entry {f}; status before the reset {st_before[ids[k]]})\n       gpu    {o1[k].tolist()}\n       oracle {o2[k].tolist()}", desc
         for e in np.nonzero(~lost)[0]:
             sg, sc = gpu.env_state(int(e)), cpu.env_state(int(e))
@@ -190,7 +245,7 @@ if __name__ == "__main__":
         except Exception as ex:  # a configuration one side refuses: both must refuse it (reported, not counted as a difference)
             err, desc = f"EXCEPTION {type(ex).__name__}: {ex}", {}
         short = {k: desc[k] for k in ("step_us", "n_levels", "rate", "min_quote_level", "max_quote_level", "concentration", "market_order_clearing", "enter_spread", "ladder_levels",
-                                        "agent_orders", "max_levels", "outer_levels", "resets", "flagged", "capacity_stops", "max_agent_orders", "inv_max") if k in desc}  # fmt: skip
+                                        "agent_orders", "max_levels", "outer_levels", "chunk", "bad_msgs", "sharpe", "normalised", "resets", "flagged", "capacity_stops", "max_agent_orders", "inv_max") if k in desc}  # fmt: skip
         print(f"seed {seed:4d} {'OK  ' if err is None else 'DIFF'} {time.time() - t:5.1f}s {short}" + (f"\n    -> {err}\n    {desc}" if err else ""), flush=True)
         bad += err is not None
     print(f"{end - first} cases, {bad} with a difference or an exception")
