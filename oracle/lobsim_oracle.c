@@ -854,7 +854,15 @@ static double np_pairwise_sum(const double* a, int n) { /* numpy add.reduce on a
 
 /* BetaOrderDistributor.convert_action/_convert_action, OrderDistributors.py:23-25,39-56.  scipy's beta.pdf is
  * x^(a-1) (1-x)^(b-1) / B(a,b); the 1/B cancels in the normalisation. */
-static void beta_volumes(const lobsim_cfg* cfg, const double* action, int64_t* buy, int64_t* sell) {
+/* Returns nonzero where the reference's distribution is NaN: scipy's beta.pdf of a shape parameter <= 0 (concentration mode with an
+ * action at or above the concentration, :43-44; in the four-parameter mode that needs an action below the Box), or a pdf that sums to
+ * nothing / overflows (0 / 0, inf / inf at :52-53).  np.round(nan * 100).astype(int) is then the most negative integer at every level
+ * and _volume_diff_to_orders looks up orders to cancel at a price that holds none: KeyError, the step raises
+ * (HistoricalOrderbookEnvironment.py:238-240) - unless the step clears the inventory, which replaces the volumes by zeros first
+ * (:208-209).  Recognised the way the kernels do: a side whose volumes are all zero (no distribution gives that: the largest of Q <= 32
+ * shares of 100 rounds to 3 at least).  The pdf here drops the 1 / B(a, b) that cancels in the normalisation, so shape parameters in
+ * the hundreds (no Box of the reference's configurations holds them) underflow where scipy's would not: out of range, same marker. */
+static int beta_volumes(const lobsim_cfg* cfg, const double* action, int64_t* buy, int64_t* sell) {
     const double EPS = 0.000001;
     int Q = cfg->max_quote_level - cfg->min_quote_level;
     double a[LOBSIM_MAX_ACTION_DIM];
@@ -869,10 +877,16 @@ static void beta_volumes(const lobsim_cfg* cfg, const double* action, int64_t* b
         ps[i] = pow(x, as - 1.0) * pow(1.0 - x, bs - 1.0);
     }
     double sb = np_pairwise_sum(pb, Q), ss = np_pairwise_sum(ps, Q);
+    const int nan_b = (cfg->use_concentration && !(bb > 0.0)) || !(sb > 0.0 && sb < INFINITY);
+    const int nan_s = (cfg->use_concentration && !(bs > 0.0)) || !(ss > 0.0 && ss < INFINITY);
+    int64_t tb = 0, ts = 0;
     for (int i = 0; i < Q; i++) {
-        buy[i] = (int64_t)rint(pb[i] / sb * 100.0); /* np.round: half to even */
-        sell[i] = (int64_t)rint(ps[i] / ss * 100.0);
+        double qb = pb[i] / sb * 100.0, qs = ps[i] / ss * 100.0;
+        buy[i] = nan_b || qb != qb ? 0 : (int64_t)rint(qb); /* np.round: half to even */
+        sell[i] = nan_s || qs != qs ? 0 : (int64_t)rint(qs);
+        tb += buy[i]; ts += sell[i];
     }
+    return tb == 0 || ts == 0;
 }
 
 static int64_t internal_volume_at(const Book* ib, int side, int64_t price) { /* _get_volumes_at_prices, :324-331 */
@@ -895,13 +909,14 @@ static void convert_action_to_orders(const oracle_t* h, Env* e, const double* ac
     int Q = cfg->max_quote_level - cfg->min_quote_level;
     int64_t tick = cfg->tick_size;
     int64_t desired[2][128];
-    beta_volumes(cfg, action, desired[0], desired[1]);
+    const int nan_volumes = beta_volumes(cfg, action, desired[0], desired[1]);
     int64_t abs_inv = e->inventory < 0 ? -e->inventory : e->inventory;
     int clearing = cfg->market_order_clearing && (double)abs_inv > action[cfg->action_dim - 1];
     if (clearing) for (int i = 0; i < Q; i++) desired[0][i] = desired[1][i] = 0;
     const Book* cb = &e->ex.central;
     double bb = book_best_buy(cb), bs = book_best_sell(cb);
     if (!(bs < INFINITY)) { e->status |= LOBSIM_ST_EMPTY_BOOK; return; } /* np.arange(inf) raises */
+    if (nan_volumes && !clearing) { e->status |= LOBSIM_ST_ASSERT; return; } /* (beta_volumes) the KeyError of :238-240 */
     int64_t best_buy, best_sell;
     if (cfg->enter_spread) { /* :300-309 */
         double mid = (bs + bb) / 2;
@@ -1360,7 +1375,7 @@ void oracle_set_threads(int n) {
 
 /* test-only helpers --------------------------------------------------------------------------------------- */
 /* Beta action -> integer volumes (pinned against scipy in tests/golden/beta_table.npz). */
-void oracle_beta_volumes(const lobsim_cfg* cfg, const double* action, int64_t* buy, int64_t* sell) { beta_volumes(cfg, action, buy, sell); }
+void oracle_beta_volumes(const lobsim_cfg* cfg, const double* action, int64_t* buy, int64_t* sell) { (void)beta_volumes(cfg, action, buy, sell); }
 
 /* FilledOrders of the last step / forward: out [max_rows][4] = {list (0 internal, 1 external), side, price, volume} (lobsim.h). */
 int oracle_get_fills(oracle_t* h, int32_t env, int64_t* out, int32_t max_rows, int32_t* n_out) {

@@ -1405,9 +1405,10 @@ SDI int32_t beta_volumes(Lds& L, const DevCfg& C, const Act5& action, const Beta
     const double EPS = 0.000001;
     int my_side = ln / Q, my_k = ln - my_side * Q;
     bool quoting = ln < 2 * Q;
+    bool shape_ok = true;
     {
         double a, b;
-        if (CFG_CONC(C)) { a = (my_side ? action.v1 : action.v0) + EPS; b = c.concentration - a + EPS; }
+        if (CFG_CONC(C)) { a = (my_side ? action.v1 : action.v0) + EPS; b = c.concentration - a + EPS; shape_ok = b > 0.0; }
         else { a = (my_side ? action.v2 : action.v0) + EPS; b = (my_side ? action.v3 : action.v1) + EPS; }
         // beta.pdf up to the 1/B(a,b) that cancels in the normalisation below; x^(a-1) (1-x)^(b-1) as one exp over
         // host-tabulated logs (two pow() calls were a quarter of this kernel's fixed VALU work).  Only the integer
@@ -1424,6 +1425,11 @@ SDI int32_t beta_volumes(Lds& L, const DevCfg& C, const Act5& action, const Beta
     if (quoting) {
         double s = np_pairwise_sum(pdf_area(L) + my_side * QMAX, Q);
         desired = (int32_t)rint(pdf_area(L)[my_side * QMAX + my_k] / s * 100.0);  // np.round(dist * active_volume).astype(int)
+        // Where the reference's distribution is NaN - a pdf that sums to nothing or overflows (0 / 0, inf / inf: the conversion above
+        // turns NaN into 0), scipy's beta.pdf of a shape parameter <= 0 (concentration mode, an action at or above the concentration;
+        // in the four-parameter mode that needs an action below the Box: not looked for) - this side's volumes are ALL ZERO, which no
+        // distribution gives (the largest of Q <= 32 shares of 100 rounds to 3 at least): build_agent_ops reads that as the marker.
+        if (CFG_CONC(C) && !shape_ok) desired = 0;
     }
     wsync();  // (the pdf area is reused by build_agent_ops)
     return desired;
@@ -1453,9 +1459,16 @@ SDI void build_agent_ops(Lds& L, Scal& S, const DevCfg& C, const Act5& action, i
     const int64_t inv = cur_inv(L);
     int64_t abs_inv = inv < 0 ? -inv : inv;
     bool clearing = CFG_MOC(C) && (double)abs_inv > act_at(action, CFG_ADIM(C) - 1);
+    // NaN volumes (beta_volumes: a side without a single share): np.round(nan).astype(int) is the most negative integer at every level and
+    // the step raises when _volume_diff_to_orders looks for orders to cancel at a price that holds none
+    // (HistoricalOrderbookEnvironment.py:238-240) - unless it clears the inventory and never looks at the volumes (:208-209)
+    const bool nan_volumes = !clearing && (ballot(quoting && my_side == 0 && desired > 0) == 0 || ballot(quoting && my_side == 1 && desired > 0) == 0);
     if (clearing) desired = 0;
     // ---- _get_best_prices (:298-322)
     if (S.n_lv[LOBSIM_SELL] == 0) { S.status |= LOBSIM_ST_EMPTY_BOOK; return; }  // np.arange(inf) raises
+    // the KeyError of :238-240, behind _get_best_prices' own exception.  (No early exit: the list built from the marker - cancellations
+    // of what rests at the quoted levels, at most - is never run, and a second way out of this routine cost the multi-step kernel 6 %.)
+    S.status |= nan_volumes ? LOBSIM_ST_ASSERT : 0;
     int64_t best_buy = S.n_lv[LOBSIM_BUY] ? uni64(L.price[LOBSIM_BUY][0]) : 0, best_sell = uni64(L.price[LOBSIM_SELL][0]);
     if (CFG_SPREAD(C)) {
         const int64_t book_buy = best_buy, book_sell = best_sell;

@@ -108,16 +108,31 @@ def draw_case(seed: int, n: int):
     starts = (first + r.integers(0, 30, size=n)) * 1_000_000
     amax = float(r.choice([10.0, 10.0, 3.0, 50.0]))  # (max_distribution_param of the Box: the reference default is 10)
     chunk = int(r.integers(2, 8)) if r.random() < 0.35 else 0  # steps per multi-step launch (lobsim_rollout_device); 0 = one launch per step
+    # dimensions added later draw from a generator of their own: the cases of the seeds that found something stay what they were
+    r2 = np.random.Generator(np.random.PCG64(190_000 + seed))
+    streams = [stream]
+    for k in range(int(r2.choice([0, 0, 0, 1, 2]))):  # more days on the handle: every env replays one of them, redrawn at its resets
+        streams.append(synthetic_stream(17_000 + 10 * seed + k, n_levels=n_levels, msgs_per_s=float(r2.choice([40, 200, 600])), start_s=t0, end_s=t0 + total_s + 5,
+                                        mid_price=int(r2.choice([60_000, 2_700_000])), book_snapshot_freq=str(r2.choice(["S", "S", "100ms"]))))
+    policy = (_capi.POLICY_GIVEN, [])
+    if chunk and r2.random() < 0.4:  # the policy of a multi-step launch computed on the device (baseline_agents.py:21-115)
+        if r2.random() < 0.5: policy = (_capi.POLICY_FIXED, r2.uniform(0.2, amax, size=cfg.action_dim).tolist())
+        else:
+            inv_idx = next((i for i, f in enumerate(feats) if f.kind == _capi.F_INVENTORY), 0)
+            mi = float(r2.choice([20, 150, 1000]))
+            policy = (_capi.POLICY_TERADACTYL, [mi, float(r2.uniform(3, 9)), float(r2.choice([0.3, 0.5, 0.8])), float(r2.uniform(9, 12)), float(r2.choice([1.0, 2.0])), inv_idx, float(moc), mi])
+    masked = (not chunk) and r2.random() < 0.2  # lobsim_step's `active` mask: a tenth of the envs sits a step out
     desc = dict(kw, n_levels=n_levels, rate=rate, feats=[(f.kind, f.lookback, f.update_us, f.norm_len) for f in feats], amax=amax, ep_steps=ep_steps, chunk=chunk, bad_msgs=bad_msgs,
-                sharpe=sharpe, normalised=int(sum(f.norm_len > 0 for f in feats)))
-    return cfg, stream, starts, amax, ep_steps, desc, r, (first, total_s - warm_s - episode_us // 1_000_000 - 6), chunk
+                sharpe=sharpe, normalised=int(sum(f.norm_len > 0 for f in feats)), days=len(streams), policy=policy[0], masked=masked)
+    extra = dict(streams=streams, policy=policy, masked=masked, r2=r2)
+    return cfg, extra, starts, amax, ep_steps, desc, r, (first, total_s - warm_s - episode_us // 1_000_000 - 6), chunk
 
 
-def _rollout(sim, acts):
-    """acts [T, n, A] through one multi-step launch (policy GIVEN) -> (obs, reward, done, (steps taken, return))."""
+def _rollout(sim, acts, policy=(_capi.POLICY_GIVEN, [])):
+    """acts [T, n, A] through one multi-step launch -> (obs, reward, done, (steps taken, return))."""
     T, n = acts.shape[0], acts.shape[1]
     if sim.b.prefix == "oracle_":
-        out = ol.oracle_rollout(sim, _capi.POLICY_GIVEN, [], T, acts, want_actions=False)
+        out = ol.oracle_rollout(sim, policy[0], policy[1], T, acts if policy[0] == _capi.POLICY_GIVEN else None, want_actions=False)
         return out["obs"], out["reward"], out["done"], (out["steps"], out["ret"])
     import torch
 
@@ -125,13 +140,15 @@ def _rollout(sim, acts):
     d_act = torch.from_numpy(np.ascontiguousarray(acts)).to(dev)
     obs, rew, done = torch.zeros((n, sim.obs_dim), dtype=torch.float64, device=dev), torch.zeros(n, dtype=torch.float64, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev)
     ret, steps = torch.zeros(n, dtype=torch.float64, device=dev), torch.zeros(n, dtype=torch.int32, device=dev)
-    sim.rollout_device(_capi.POLICY_GIVEN, [], T, d_act.data_ptr(), 0, obs.data_ptr(), 0, rew.data_ptr(), done.data_ptr(), ret.data_ptr(), steps.data_ptr())
+    sim.rollout_device(policy[0], policy[1], T, d_act.data_ptr() if policy[0] == _capi.POLICY_GIVEN else 0, 0, obs.data_ptr(), 0, rew.data_ptr(), done.data_ptr(), ret.data_ptr(), steps.data_ptr())
     sim.sync()
     return obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy(), (steps.cpu().numpy(), ret.cpu().numpy())
 
 
 def run_case(seed: int, n: int):
-    cfg, stream, starts, amax, ep_steps, desc, r, (first, span), chunk = draw_case(seed, n)
+    cfg, extra, starts, amax, ep_steps, desc, r, (first, span), chunk = draw_case(seed, n)
+    streams, policy, masked, r2 = extra["streams"], extra["policy"], extra["masked"], extra["r2"]
+    sids = r2.integers(0, len(streams), size=n).astype(np.int32)
     # RollingSharpe is mean / std of a window's log returns.  With a portfolio of 1e9 in cash and a few shares the AUM moves by O(1) a
     # step: log returns of 1e-9, which f64 resolves to 1e-7 relative - the last bits in which ocml's exp / log differ from libm's (and
     # both from the reference's numpy: 4.4e-8 on the recorded trajectory, tests/test_gpu_parity.py) show at 1e-6 in the ratio.  That is
@@ -141,9 +158,9 @@ def run_case(seed: int, n: int):
     try:
         inv0 = int(r.integers(-20, 20))
         for s in (gpu, cpu):
-            s.add_stream(stream)
+            for st_ in streams: s.add_stream(st_)
             s.set_portfolio(inv0, 10**9)
-        og, oc = gpu.reset(starts, 0), cpu.reset(starts, 0)
+        og, oc = gpu.reset(starts, sids), cpu.reset(starts, sids)
         sg, sc = gpu.status(), cpu.status()
         lost = (sg & 28) != 0  # (a warm-up that outgrew a capacity of the HIP layout: see below)
         reset_failed = sc != 0
@@ -166,11 +183,15 @@ def run_case(seed: int, n: int):
             m = r.random((T, n))
             act[m < 0.03] = 0.0  # (the Box's corners: the distributor adds EPS)
             act[(m >= 0.03) & (m < 0.06)] = high
+            active = None
             if chunk:
-                (og, rg, dg, xg), (oc, rc, dc, xc) = _rollout(gpu, act), _rollout(cpu, act)
+                (og, rg, dg, xg), (oc, rc, dc, xc) = _rollout(gpu, act, policy), _rollout(cpu, act, policy)
             else:
-                og, rg, dg = gpu.step(act[0])
-                oc, rc, dc = cpu.step(act[0])
+                if masked: active = (r2.random(n) >= 0.1).astype(np.uint8)
+                og, rg, dg = gpu.step(act[0], active)
+                oc, rc, dc = cpu.step(act[0], active)
+                if masked:  # (an env that sits the step out has no row in it)
+                    for a in (og, oc, rg, rc, dg, dc): a[active == 0] = 0
             sg, sc = gpu.status(), cpu.status()
             # a capacity of the HIP layout (level budget, queue pages, agent table: bits 4 / 8 / 16) is not a difference: the oracle
             # has none (include/lobsim.h).  Such an env leaves the comparison until its next reset
@@ -205,7 +226,8 @@ def run_case(seed: int, n: int):
                 if lost.any():  # (the portfolio outlives the episode, Q7: an env that left the comparison re-enters it with the oracle's)
                     li = np.nonzero(lost)[0].astype(np.int32)
                     gpu.set_portfolio(ic[li], cc[li], li)
-                o1, o2 = gpu.reset(starts[ids], 0, ids), cpu.reset(starts[ids], 0, ids)
+                sids[ids] = r2.integers(0, len(streams), size=len(ids))
+                o1, o2 = gpu.reset(starts[ids], sids[ids], ids), cpu.reset(starts[ids], sids[ids], ids)
                 s1, s2 = gpu.status()[ids], cpu.status()[ids]
                 cap = (s1 & 28) != 0  # (a warm-up that outgrew a capacity)
                 capacity_stops += int(cap.sum())
@@ -245,7 +267,7 @@ if __name__ == "__main__":
         except Exception as ex:  # a configuration one side refuses: both must refuse it (reported, not counted as a difference)
             err, desc = f"EXCEPTION {type(ex).__name__}: {ex}", {}
         short = {k: desc[k] for k in ("step_us", "n_levels", "rate", "min_quote_level", "max_quote_level", "concentration", "market_order_clearing", "enter_spread", "ladder_levels",
-                                        "agent_orders", "max_levels", "outer_levels", "chunk", "bad_msgs", "sharpe", "normalised", "resets", "flagged", "capacity_stops", "max_agent_orders", "inv_max") if k in desc}  # fmt: skip
+                                        "agent_orders", "max_levels", "outer_levels", "chunk", "bad_msgs", "sharpe", "normalised", "days", "policy", "masked", "resets", "flagged", "capacity_stops", "max_agent_orders", "inv_max") if k in desc}  # fmt: skip
         print(f"seed {seed:4d} {'OK  ' if err is None else 'DIFF'} {time.time() - t:5.1f}s {short}" + (f"\n    -> {err}\n    {desc}" if err else ""), flush=True)
         bad += err is not None
     print(f"{end - first} cases, {bad} with a difference or an exception")

@@ -11,12 +11,16 @@ import oracle_lib as ol
 from rl4mm_amd import _lib
 seed, n = int(sys.argv[1]), int(sys.argv[2]) if len(sys.argv) > 2 else 96
 watch = int(sys.argv[3]) if len(sys.argv) > 3 else -1
-cfg, stream, starts, amax, ep_steps, desc, r, (first, span), chunk = cf.draw_case(seed, n)
+cfg, extra, starts, amax, ep_steps, desc, r, (first, span), chunk = cf.draw_case(seed, n)
+streams, policy, masked, r2 = extra['streams'], extra['policy'], extra['masked'], extra['r2']
+sids = r2.integers(0, len(streams), size=n).astype(np.int32)
 print(desc)
 gpu, cpu = _lib.new_sim(cfg), ol.oracle_sim(cfg)
 inv0 = int(r.integers(-20, 20))
-for s in (gpu, cpu): s.add_stream(stream); s.set_portfolio(inv0, 10**9)
-og, oc = gpu.reset(starts, 0), cpu.reset(starts, 0)
+for s in (gpu, cpu):
+    for st_ in streams: s.add_stream(st_)
+    s.set_portfolio(inv0, 10**9)
+og, oc = gpu.reset(starts, sids), cpu.reset(starts, sids)
 A = cfg.action_dim; high = np.full(A, amax)
 if cfg.market_order_clearing: high[-1] = float(r.choice([5.0, 60.0, 400.0]))
 steps = 2 * ep_steps + 8
@@ -31,8 +35,12 @@ for t in range(steps):
     T = chunk or 1
     act = r.uniform(0, high, size=(T, n, A)); m = r.random((T, n)); act[m < 0.03] = 0.0; act[(m >= 0.03) & (m < 0.06)] = high
     peek = ol.oracle_peek_orders(cpu, act[0, watch], watch) if watch >= 0 and not chunk else None
-    if chunk: (og, rg, dg, xg), (oc, rc, dc, xc) = cf._rollout(gpu, act), cf._rollout(cpu, act)
-    else: og, rg, dg = gpu.step(act[0]); oc, rc, dc = cpu.step(act[0])
+    active = (r2.random(n) >= 0.1).astype(np.uint8) if masked and not chunk else None
+    if chunk: (og, rg, dg, xg), (oc, rc, dc, xc) = cf._rollout(gpu, act, policy), cf._rollout(cpu, act, policy)
+    else:
+        og, rg, dg = gpu.step(act[0], active); oc, rc, dc = cpu.step(act[0], active)
+        if masked:
+            for a in (og, oc, rg, rc, dg, dc): a[active == 0] = 0
     sg, sc = gpu.status(), cpu.status()
     ig, cg, pg = gpu.portfolios(); ic, cc, pc = cpu.portfolios()
     bad = (sg != sc) | (ig != ic) | (cg != cc) | (dg != dc) | ~np.isclose(og, oc, rtol=1e-12, atol=1e-9, equal_nan=True).all(axis=1)
@@ -54,7 +62,8 @@ for t in range(steps):
     if dg.any():
         ids = np.nonzero(dg)[0].astype(np.int32)
         starts[ids] = (first + r.integers(0, span, size=len(ids))) * 1_000_000
-        o1, o2 = gpu.reset(starts[ids], 0, ids), cpu.reset(starts[ids], 0, ids)
+        sids[ids] = r2.integers(0, len(streams), size=len(ids))
+        o1, o2 = gpu.reset(starts[ids], sids[ids], ids), cpu.reset(starts[ids], sids[ids], ids)
         badr = ~np.isclose(o1, o2, rtol=1e-12, atol=1e-9, equal_nan=True)
         s1 = gpu.status()[ids]
         badr[s1 != 0] = False

@@ -11,7 +11,8 @@ and had kept them.  Longer runs with more dimensions found two more: with `enter
 snapshot levels back without matching them) the highest buy quote sits at or above the best ask and executes, which the lane-parallel
 path for the agent's orders did not ask about; and a feature's `current_value` outlives `reset()` (Features.py:88-96) - AmihudLambda
 between two of its slow updates does not assign it, so with `normalisation_on` the first steps of a new episode z-score and record the
-OLD value.  The cases below pin all three, and a bounded sample of the drawn configurations runs with the suite."""
+OLD value.  A fourth: Beta volumes that are NaN in the reference (the step raises) were quietly zero.  The cases below pin them,
+and a bounded sample of the drawn configurations runs with the suite."""
 import sys
 from pathlib import Path
 
@@ -189,6 +190,42 @@ def test_a_feature_value_outlives_the_reset():
     assert n_resets >= 2 * n and seen_nonzero  # episodes ended on a nonzero Amihud value: there was something to carry
     gpu.close()
     cpu.close()
+
+
+def test_nan_volumes_raise_unless_the_step_clears_the_inventory():
+    """Concentration mode with an action at or above the concentration: Beta's second shape parameter c - a + EPS is <= 0, scipy's pdf
+    is NaN, np.round(nan).astype(int) the most negative integer at every level - the step raises when `_volume_diff_to_orders` looks for
+    orders to cancel at a price that holds none (HistoricalOrderbookEnvironment.py:238-240), unless the inventory is being cleared:
+    then the volumes are replaced by zeros before anybody looks at them (:208-209).  The same for a pdf that underflows (shape
+    parameters in the hundreds, what an on-device Teradactyl asks for at fifty times its maximum inventory)."""
+    n = 6
+    F = _capi.make_feature
+    feats = [F(_capi.F_INVENTORY, 0, 100_000, -1e6, 1e6), F(_capi.F_PRICE, 0, 100_000, 0, 1e8)]
+    stream = ol.golden_stream("synth_small")
+    starts = np.full(n, 35_800_000_000, dtype=np.int64)
+    for conc, acts, inv, want in (
+        (5.0, [[2.0, 3.0, 60.0], [5.0, 3.0, 60.0], [2.0, 7.5, 60.0], [5.0, 3.0, 10.0], [4.999, 4.999, 60.0], [0.0, 0.0, 60.0]], 30, [0, 64, 64, 0, 0, 0]),
+        (None, [[2.0, 3.0, 4.0, 5.0, 60.0], [900.0, 900.0, 2.0, 2.0, 60.0], [2.0, 2.0, 1e4, 3.0, 60.0], [900.0, 900.0, 2.0, 2.0, 10.0], [200.0, 200.0, 200.0, 200.0, 60.0], [0.0, 0.0, 0.0, 0.0, 60.0]], 30, [0, 64, 0, 0, 0, 0]),  # (env 2: 0.95 ** 9999 is 1e-223, still a number)
+    ):
+        cfg = _capi.make_cfg(n, 10, feats, step_us=100_000, episode_us=5_000_000, concentration=conc, market_order_clearing=True, market_order_fraction_of_inventory=0.5)
+        gpu, cpu = _lib.new_sim(cfg), ol.oracle_sim(cfg)
+        for s_ in (gpu, cpu):
+            s_.add_stream(stream)
+            s_.set_portfolio(inv, 10**9)  # |inventory| 30: above the clearing threshold of env 3 only
+            s_.reset(starts, 0)
+        act = np.array(acts)
+        og, rg, dg = gpu.step(act)
+        oc, rc, dc = cpu.step(act)
+        assert np.array_equal(gpu.status(), cpu.status()) and gpu.status().tolist() == want, (conc, gpu.status(), cpu.status())
+        assert np.array_equal(dg, dc) and np.array_equal(rg, rc)
+        ok = gpu.status() == 0
+        assert np.array_equal(og[ok], oc[ok])
+        for a, b in zip(gpu.portfolios(), cpu.portfolios()):
+            assert np.array_equal(a, b)
+        for e in range(n):
+            assert np.array_equal(gpu.queues(e), cpu.queues(e)), (conc, e)
+        gpu.close()
+        cpu.close()
 
 
 # seeds of tests/diag/config_fuzz.py.  The first eight stop envs in the middle of a sweep (they differed before the portfolio was put
