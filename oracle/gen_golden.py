@@ -318,7 +318,7 @@ def reward_from_spec(spec):
 
 def run_trajectory(name, db, ticker, date, n_levels, features, agent_fn, n_episodes, starts, episode_s, step_s=0.1,
                    step_reward="PnL", terminal_reward="PnL", enter_spread=False, inc_prev=False, moc=False, mofi=0.0,
-                   concentration=None, minq=0, maxq=10, initial=(0, 1000), outer_levels=20, top_k=12, stream_file=None, info=False):  # fmt: skip
+                   concentration=None, minq=0, maxq=10, initial=(0, 1000), outer_levels=20, top_k=12, stream_file=None, info=False, continue_after_crash=False):  # fmt: skip
     if ONLY and name not in ONLY:
         return
     step = timedelta(seconds=step_s)
@@ -373,6 +373,9 @@ def run_trajectory(name, db, ticker, date, n_levels, features, agent_fn, n_episo
             except (AssertionError, Exception) as exc:  # the reference crashes here; pin where and why
                 rec["crash"] = (len(rec["reward"]), type(exc).__name__)
                 rec["crash_action"] = action
+                # (every crash of the run, by episode: the env object survives the exception - its portfolio, its features' values -
+                # and the next episode's reset shows what it kept)
+                rec.setdefault("crashes", []).append((ep, len(rec["reward"]), type(exc).__name__, action, int(env.state.portfolio.inventory), int(env.state.portfolio.cash)))
                 break
             rec["actions"].append(action)
             if info:
@@ -420,6 +423,11 @@ def run_trajectory(name, db, ticker, date, n_levels, features, agent_fn, n_episo
         crash_step=np.array(rec["crash"][0] if "crash" in rec else -1), crash_type=np.array(rec["crash"][1] if "crash" in rec else ""),
         crash_action=np.array(rec.get("crash_action", np.zeros(A))), info=np.array(rec.get("info", np.zeros((0, 10)))),
     )  # fmt: skip
+    if continue_after_crash:
+        cr = rec.get("crashes", [])
+        out.update(crash_eps=np.array([c[0] for c in cr], dtype=np.int64), crash_ks=np.array([c[1] for c in cr], dtype=np.int64), crash_types=np.array([c[2] for c in cr]),
+                   crash_actions=np.array([c[3] for c in cr], dtype=np.float64).reshape(len(cr), A), crash_inventory=np.array([c[4] for c in cr], dtype=np.int64),
+                   crash_cash=np.array([c[5] for c in cr], dtype=np.int64))  # fmt: skip
     np.savez_compressed(GOLD / f"traj_{name}.npz", **out)
     print(f"traj_{name}: {len(rec['reward'])} steps, final inv {rec['inventory'][-1]} cash {rec['cash'][-1]}, "
           f"{len(rec['fills'])} fills, resyncs {rec['n_resyncs'][-1]}, max agent orders {max(rec['n_agent'])}")  # fmt: skip
@@ -436,6 +444,36 @@ def random_agent(seed, high=10.0):
         return lambda obs: rng.uniform(low, hi)
 
     return make
+
+
+def scripted_agent(per_episode):
+    """per_episode[ep] = list of actions; the last one repeats."""
+    def make(env, ep):
+        acts, k = per_episode[min(ep, len(per_episode) - 1)], [0]
+
+        def act(obs):
+            a = acts[min(k[0], len(acts) - 1)]
+            k[0] += 1
+            return np.array(a, dtype=float)
+
+        return act
+
+    return make
+
+
+def thin_day(crossed):
+    """A hand-made 3-level day for the steps that raise: 100 shares a level on the bid side, 400 on the ask side, one small buy order
+    a second three ticks below the touch (so that the book rows repeat); `crossed`: the best bid two ticks ABOVE the best ask in
+    every row - what update_outer_levels can leave behind, here straight from the snapshot (get_initial_orderbook_from_orders
+    builds levels, it matches nothing)."""
+    t0, mid, tick, lv, n = 36_000, 1_000_000, 100, 3, 30
+    row = []
+    for i in range(lv):
+        row += [mid + tick * (i + 1), 400, mid - tick * (i + 1) + (3 * tick if crossed and i == 0 else 0), 100]
+    g = dict(time_ns=np.array([(t0 + s) * 10**9 + 5 * 10**8 for s in range(n)], dtype=np.int64), type=np.ones(n, dtype=np.int64), id=np.arange(1000, 1000 + n, dtype=np.int64),
+             size=np.full(n, 10, dtype=np.int64), price=np.full(n, mid - 3 * tick, dtype=np.int64), direction=np.ones(n, dtype=np.int64), books=np.tile(np.array(row, dtype=np.int64), (n, 1)))  # fmt: skip
+    g["time_s"] = g["time_ns"] / 1e9
+    return g
 
 
 def teradactyl_agent(inventory_index, **kw):
@@ -638,8 +676,45 @@ def main():
                        inc_prev=True, stream_file="synth_small")  # fmt: skip
         run_trajectory("synth_step5s", db_s, "SYN", sdate, 10, per_second(5.0, 60), random_agent(53), 2, [35975, 36040], 60.0, step_s=5.0, enter_spread=True,
                        initial=(0, 10**9), stream_file="synth_small")  # fmt: skip
+        # ---- round 5: what tests/diag/config_fuzz.py found, pinned on the reference itself -------------------------------------
+        # (c) a feature's current_value outlives reset(): AmihudLambda between two slow updates does not assign it, and with
+        # normalisation_on the new episode's first updates record and z-score the old value (Features.py:80-96, 280-290)
+        amihud_n = lambda: [Spread(), Inventory(), AmihudLambda(normalisation_on=True, max_norm_len=600, lookback_periods=3, slowing_factor=2),  # noqa: E731
+                            AmihudLambda(name="al2", update_frequency=timedelta(seconds=0.2), lookback_periods=4, slowing_factor=5, normalisation_on=True, max_norm_len=40),
+                            AmihudLambda(name="al3", lookback_periods=2, slowing_factor=3), Volatility(name="v", update_frequency=timedelta(seconds=0.1), lookback_periods=10)]
+        run_trajectory("synth_amihud_norm", db_s, "SYN", sdate, 10, amihud_n(), random_agent(61), 3, [35950, 35960, 35970], 6.0, stream_file="synth_small", initial=(0, 10**9))
+        # (d) NaN volumes: concentration 12 with an action of 13 -> Beta's second shape parameter is negative, scipy's pdf is nan -> the
+        # step raises KeyError when it looks for orders to cancel at a price that holds none; the env is reset and goes on (the second
+        # episode also visits the Box's corner, action == concentration: c - (c + EPS) + EPS in floating point).  With market-order
+        # clearing on and the inventory above the threshold the nan volumes are replaced by zeros before anybody looks: no exception
+        run_trajectory("synth_conc_nan", db_s, "SYN", sdate, 10, short(), scripted_agent([[[2, 3], [2, 3], [13, 3]], [[3, 2], [3, 2], [12, 3], [3, 2]]]), 2, [35960, 35990], 20.0,
+                       concentration=12.0, initial=(0, 10**9), stream_file="synth_small", continue_after_crash=True)  # fmt: skip
+        run_trajectory("synth_conc_nan_moc", db_s, "SYN", sdate, 10, short(), scripted_agent([[[13, 2, 10], [2, 3, 60], [13, 2, 60]], [[3, 2, 60]]]), 2, [35960, 35990], 20.0,
+                       concentration=12.0, moc=True, mofi=0.5, initial=(30, 10**9), stream_file="synth_small", continue_after_crash=True)  # fmt: skip
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+    # (a) a sweep that empties the book: EmptyOrderbookError in the middle of the clearing order - the 300 shares it had sold never
+    # reach the portfolio, which the next episode starts from; (b) enter_spread quotes on a crossed book execute on submission
+    for crossed in (False, True):
+        tmp = Path(tempfile.mkdtemp(prefix="golden_thin_"))
+        try:
+            tdate = datetime(2018, 2, 21)
+            tick_name = "THX" if crossed else "THN"
+            mpath, bpath = write_lobster_csv(thin_day(crossed), tmp, tick_name, "2018-02-21", 3)
+            ps = pack_lobster(mpath, bpath, tick_name, "2018-02-21", 3, "S")
+            name = "thin_crossed" if crossed else "thin"
+            if not ONLY or f"stream_{name}" in ONLY or any(o.startswith("thin") for o in ONLY):
+                ps.save(GOLD / f"{name}.npz")
+            db_t = make_db(tmp, tick_name, tdate, 3, "S")
+            feats_t = lambda: [Inventory(), Spread(), Price(update_frequency=timedelta(seconds=0.1))]  # noqa: E731
+            if not crossed:
+                run_trajectory("thin_sweep_crash", db_t, tick_name, tdate, 3, feats_t(), scripted_agent([[[1, 1, 1, 1, 1000], [2, 1, 1, 2, 1000], [1, 1, 1, 1, 0]], [[1, 2, 2, 1, 1000]]]), 2,
+                               [36002, 36008], 2.0, moc=True, mofi=1.0, maxq=3, initial=(500, 10**9), stream_file="thin", top_k=8, continue_after_crash=True)  # fmt: skip
+            else:
+                run_trajectory("thin_crossed_spread", db_t, tick_name, tdate, 3, feats_t(), random_agent(71, high=6.0), 1, [36002], 2.0, enter_spread=True, maxq=4,
+                               initial=(0, 10**9), stream_file="thin_crossed", top_k=8)  # fmt: skip
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
 
 
 if __name__ == "__main__":

@@ -800,7 +800,9 @@ class HistoricalOrderbookVectorEnv(_RayVectorEnv):
         if status & _capi.ST_EMPTY_BOOK:
             parts.append("EmptyOrderbookError: Trying take liquidity from empty side of the book.")  # Exchange.py:186
         if status & _capi.ST_ASSERT:
-            parts.append("AssertionError: Order volume must be positive.")  # Exchange.py:60 (and RollingSharpe's non-positive AUM)
+            # Exchange.py:60; also RollingSharpe's non-positive AUM (RewardFunctions.py) and the KeyError of a step whose Beta volumes are
+            # NaN (an action at or above the concentration, shape parameters whose pdf underflows: HistoricalOrderbookEnvironment.py:238-240)
+            parts.append("AssertionError: Order volume must be positive (or: the action's Beta distribution is NaN; or: RollingSharpe met a non-positive AUM).")
         if status & _capi.ST_BAD_MESSAGE:
             parts.append("AssertionError: cross_trade / trading_halt message in the stream")  # HistoricalOrderGenerator.py:54-56
         if status & _capi.ST_LEVEL_OVERFLOW:
@@ -1051,8 +1053,8 @@ class HistoricalOrderbookEnvironment(_GymEnv):
     def _raise(status: int):  # the exceptions the reference raises on the same conditions
         if status & _capi.ST_EMPTY_BOOK:
             raise EmptyOrderbookError("Trying take liquidity from empty side of the book.")
-        if status & _capi.ST_ASSERT:
-            raise AssertionError("Order volume must be positive.")
+        if status & _capi.ST_ASSERT:  # (the reference's exception type differs by cause - AssertionError, KeyError, Exception -; the status word has one bit for them)
+            raise AssertionError("Order volume must be positive (or: the action's Beta distribution is NaN; or: RollingSharpe met a non-positive AUM).")
         raise RuntimeError(f"env stopped with status {status} (include/lobsim.h: enum lobsim_status): " + HistoricalOrderbookVectorEnv.error_text(status))
 
     def seed(self, seed=42):

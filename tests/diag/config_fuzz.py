@@ -90,11 +90,15 @@ def draw_case(seed: int, n: int):
     if r.random() < 0.25:  # a day whose price walks away: far levels, outer-level resyncs (tests/drift_stream.py)
         from drift_stream import drift_stream, ramp_path, triangle_path
 
-        path = ramp_path(float(r.choice([0.2, 0.5, 2.0])), int(r.choice([-1, 1]))) if r.random() < 0.5 else triangle_path(int(r.choice([15, 40, 120])), float(r.choice([0.1, 0.3, 1.0])))
-        stream = drift_stream(7_000 + seed, path, n_levels=n_levels, start_s=t0, duration_s=total_s + 5, noise_per_s=float(r.choice([12.0, 60.0])), max_excursion=int((total_s + 5) / 0.1) + 200)
+        if r.random() < 0.5: drift = ("ramp", float(r.choice([0.2, 0.5, 2.0])), int(r.choice([-1, 1])))
+        else: drift = ("triangle", int(r.choice([15, 40, 120])), float(r.choice([0.1, 0.3, 1.0])))
+        path = ramp_path(drift[1], drift[2]) if drift[0] == "ramp" else triangle_path(drift[1], drift[2])
+        drift += (float(r.choice([12.0, 60.0])), int((total_s + 5) / 0.1) + 200, t0, total_s + 5)  # noise per second, max excursion, start, duration
+        stream = drift_stream(7_000 + seed, path, n_levels=n_levels, start_s=t0, duration_s=drift[6], noise_per_s=drift[3], max_excursion=drift[4])
         rate = -1.0
     else:
         stream = synthetic_stream(7_000 + seed, n_levels=n_levels, msgs_per_s=rate, start_s=t0, end_s=t0 + total_s + 5, mid_price=int(r.choice([60_000, 2_700_000, 2_700_000, 9_990_000])))
+    drift = locals().get("drift")
     bad_msgs = 0
     if r.random() < 0.12 and stream.n_msgs > 2000:  # a cross trade / trading halt / zero-volume message somewhere in the day: the reference
         from rl4mm_amd.stream import TYPE_SHIFT  # asserts (HistoricalOrderGenerator.py:54-56, Exchange.py:59-60), every env that replays it stops
@@ -123,7 +127,7 @@ def draw_case(seed: int, n: int):
             policy = (_capi.POLICY_TERADACTYL, [mi, float(r2.uniform(3, 9)), float(r2.choice([0.3, 0.5, 0.8])), float(r2.uniform(9, 12)), float(r2.choice([1.0, 2.0])), inv_idx, float(moc), mi])
     masked = (not chunk) and r2.random() < 0.2  # lobsim_step's `active` mask: a tenth of the envs sits a step out
     desc = dict(kw, n_levels=n_levels, rate=rate, feats=[(f.kind, f.lookback, f.update_us, f.norm_len) for f in feats], amax=amax, ep_steps=ep_steps, chunk=chunk, bad_msgs=bad_msgs,
-                sharpe=sharpe, normalised=int(sum(f.norm_len > 0 for f in feats)), days=len(streams), policy=policy[0], masked=masked)
+                sharpe=sharpe, normalised=int(sum(f.norm_len > 0 for f in feats)), days=len(streams), policy=policy[0], masked=masked, drift=drift)
     extra = dict(streams=streams, policy=policy, masked=masked, r2=r2)
     return cfg, extra, starts, amax, ep_steps, desc, r, (first, total_s - warm_s - episode_us // 1_000_000 - 6), chunk
 

@@ -18,7 +18,10 @@ pytestmark = pytest.mark.gpu
 RTOL, ATOL = 1e-12, 1e-9
 TRAJ = ["msft_fixed", "msft_teradactyl_ad", "msft_random_allfeat", "synth_default_random", "synth_teradactyl_ad_spread", "synth_amihud", "synth_info_moc", "synth_info_spread",
         "synth_moc_conc", "synth_moc_crash", "synth_q5_fixed", "synth_norm", "synth_track_internal",
-        "synth_step50ms_default", "synth_step1s", "synth_step5s"]  # fmt: skip  (the last three: step_size 0.05 s / 1 s / 5 s)
+        "synth_step50ms_default", "synth_step1s", "synth_step5s",  # (step_size 0.05 s / 1 s / 5 s)
+        # round 5, what tests/diag/config_fuzz.py found, recorded from the reference: a feature value outliving reset(), NaN volumes
+        # (with and without market-order clearing), a sweep that empties the book, enter_spread quotes on a crossed book
+        "synth_amihud_norm", "synth_conc_nan", "synth_conc_nan_moc", "thin_sweep_crash", "thin_crossed_spread"]  # fmt: skip
 
 
 def _small_cfg(n_envs=1, n_levels=8, **kw):

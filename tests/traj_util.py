@@ -14,13 +14,27 @@ def replay_and_check(sim, g, z, stream_id, obs_rtol=0.0, obs_atol=0.0, check_fil
     crash_step = int(z["crash_step"])
     sim.set_portfolio(g["initial_inventory"], g["initial_cash"])
     n_eps = len(g["starts_us"])
+    # (round 5) trajectories that go on after the reference raised: the env object survives the exception - its portfolio, its
+    # features' values, the exchange as the exception left it - and the next episode's reset shows what it kept
+    by_ep = {int(e): i for i, e in enumerate(z["crash_eps"])} if "crash_eps" in z.files else None
     for ep in range(n_eps):
         if k >= n_steps and crash_step < 0:
             break
         obs0 = sim.reset(g["starts_us"][ep], stream_id)
         _close(obs0[0], z["reset_obs"][ep], obs_rtol, obs_atol, f"{label} reset obs ep {ep}")
+        crashed = False
         while True:
-            if k == crash_step:  # the reference raised here: we must flag the env instead
+            if by_ep is not None and ep in by_ep and k == int(z["crash_ks"][by_ep[ep]]):
+                i = by_ep[ep]
+                obs, reward, done = sim.step(z["crash_actions"][i][None, :])
+                st = sim.env_state(0)
+                ctx = f"{label}: the reference raised {z['crash_types'][i]} at step {k} (episode {ep})"
+                assert done[0] == 1 and reward[0] == 0.0 and st["status"] != 0, f"{ctx}, status {st['status']}"
+                # the portfolio the reference's env object holds after the exception: the step's fills never reached it
+                assert st["inventory"] == int(z["crash_inventory"][i]) and st["cash"] == int(z["crash_cash"][i]), f"{ctx}: portfolio {st['inventory']} / {st['cash']} != {z['crash_inventory'][i]} / {z['crash_cash'][i]}"
+                crashed = True
+                break
+            if by_ep is None and k == crash_step:  # the reference raised here: we must flag the env instead
                 obs, reward, done = sim.step(z["crash_action"][None, :])
                 st = sim.env_state(0)
                 assert done[0] == 1 and st["status"] != 0, f"{label}: reference crashed ({z['crash_type']}) at step {k}, status {st['status']}"
@@ -57,7 +71,8 @@ def replay_and_check(sim, g, z, stream_id, obs_rtol=0.0, obs_atol=0.0, check_fil
                 break
         q = sim.queues(0)
         qe = z["queues"][z["queue_off"][ep] : z["queue_off"][ep + 1]]
-        assert np.array_equal(q, qe), f"{label}: full queue dump differs at end of episode {ep}"
+        # (after an exception too: the exchange is what the step had made of it when it raised)
+        assert np.array_equal(q, qe), f"{label}: full queue dump differs at end of episode {ep}" + (" (after the exception)" if crashed else "")
     assert k == n_steps
 
 
