@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Build container only: RANDOM env configurations on small days, the upstream reference itself against the CPU oracle.
+
+Run:  PYTHONPATH=oracle/refshim:/root/reference PYTHONDONTWRITEBYTECODE=1 python oracle/fuzz_reference.py [first_seed=0] [end_seed=100]
+
+The golden trajectories (oracle/gen_golden.py -> tests/golden/) pin the oracle on ~30 configurations somebody chose.  This draws them:
+day (steady 5- and 10-level synthetic days, a day whose price walks away with a resync every second, hand-made thin and crossed
+books), step size, feature subset with random windows / clocks / normalisation (reference classes, reference defaults), reward (PnL,
+AD, SD, RollingSharpe windows), quote range, concentration, market-order clearing, enter_spread, previous action in the observation,
+outer_levels, starting portfolio, agent (uniform over the Box, uniform beyond it - the reference raises on NaN volumes -, Teradactyl),
+two episodes on one env object (what a reset keeps), and goes on after an exception like the reference's caller would.  Each case
+is recorded from the reference (run_trajectory of gen_golden.py, nothing written) and replayed through the oracle with the checks
+of tests/traj_util.py: every step's fills, book, portfolio, observation, reward, done flag; the book and the portfolio after an
+exception.  Nothing of the reference is stored; a seed that differs is printed with its configuration."""
+import sys
+import tempfile
+import time
+import traceback
+from datetime import datetime, timedelta
+from pathlib import Path
+
+import numpy as np
+
+sys.argv = [a for a in sys.argv if a != "--only"]
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO / "oracle"))
+sys.path.insert(0, str(REPO / "tests"))
+import gen_golden as gg  # noqa: E402  (imports the reference through oracle/refshim)
+import oracle_lib as ol  # noqa: E402
+from drift_stream import drift_lobster, triangle_path  # noqa: E402
+from gen_golden import (AmihudLambda, BookImbalance, EpisodeProportion, Inventory, Price, PriceMove, PriceRange, Spread, TimeOfDay,  # noqa: E402
+                        TradeDirectionImbalance, TradeVolumeImbalance, Volatility)
+from rl4mm_amd.stream import pack_lobster  # noqa: E402
+from rl4mm_amd.synth import generate_lobster, write_lobster_csv  # noqa: E402
+from traj_util import replay_and_check  # noqa: E402
+
+
+class Z(dict):  # an in-memory stand-in for the np.load() of a golden file
+    @property
+    def files(self):
+        return list(self.keys())
+
+
+DATE = datetime(2018, 2, 21)
+_days = {}
+
+
+def day(kind):
+    """-> (db, packed stream, ticker, n_levels, first valid start second, last second)."""
+    if kind in _days:
+        return _days[kind]
+    tmp = Path(tempfile.mkdtemp(prefix="fuzzref_"))
+    if kind == "syn10": g, L, t0, t1 = generate_lobster(424242, 10, 200.0, 35_690, 35_800), 10, 35_690, 35_800
+    elif kind == "syn5": g, L, t0, t1 = generate_lobster(515151, 5, 60.0, 35_690, 35_800, mid_price=60_000), 5, 35_690, 35_800
+    elif kind == "drift":
+        g = drift_lobster(7612, triangle_path(120, 0.1), n_levels=10, start_s=35_600, duration_s=70, noise_per_s=12.0, max_excursion=900)
+        g["time_ns"] = np.round(g["time_s"] * 1e9).astype(np.int64)
+        L, t0, t1 = 10, 35_600, 35_670
+    else: g, L, t0, t1 = gg.thin_day(kind == "thinx"), 3, 36_000, 36_029
+    tick = kind.upper()
+    mpath, bpath = write_lobster_csv(g, tmp, tick, "2018-02-21", L)
+    ps = pack_lobster(mpath, bpath, tick, "2018-02-21", L, "S")
+    db = gg.make_db(tmp, tick, DATE, L, "S")
+    _days[kind] = (db, ps, tick, L, t0, t1)
+    return _days[kind]
+
+
+def draw(seed):
+    r = np.random.Generator(np.random.PCG64(31_000 + seed))
+    kind = str(r.choice(["syn10", "syn10", "syn5", "drift", "drift", "thin", "thinx"]))
+    db, ps, tick, L, t0, t1 = day(kind)
+    thin = kind.startswith("thin")
+    step_s = float(r.choice([0.05, 0.1, 0.1, 0.2, 0.5, 1.0]))
+    us = lambda s: timedelta(seconds=s)  # noqa: E731
+    warm_s = int(r.choice([0, 1])) if thin else int(r.choice([1, 2, 3]))
+    ep_steps = int(r.integers(6, 24))
+    episode_s = ep_steps * step_s
+    clock = lambda: float(r.choice([step_s, step_s, 2 * step_s, 1.0 if step_s <= 1.0 and (1.0 / step_s) == int(1.0 / step_s) else step_s]))  # noqa: E731
+    norm_case = r.random() < 0.2
+
+    def normed(cls, **kw):  # (not every feature class takes the normalisation arguments)
+        extra = dict(normalisation_on=True, max_norm_len=int(r.choice([2, 7, 40, 600]))) if norm_case and r.random() < 0.5 else {}
+        try:
+            return cls(**kw, **extra)
+        except TypeError:
+            return cls(**kw)
+
+    def lb(u, hi):
+        return int(r.integers(1, max(2, min(hi, int(warm_s / u) + 1)))) if warm_s else 1
+
+    def amihud():
+        u, s_ = step_s, int(r.integers(1, 4))
+        k = max(1, min(int(r.integers(1, 5)), int(warm_s / (u * s_)) - 1)) if warm_s else 1
+        return normed(AmihudLambda, name=f"al{r.integers(1 << 30)}", update_frequency=us(u), lookback_periods=k, slowing_factor=s_)
+
+    pool = [
+        lambda: normed(Spread, update_frequency=us(clock())),
+        lambda: (lambda u: normed(PriceMove, name=f"pm{r.integers(1 << 30)}", update_frequency=us(u), lookback_periods=lb(u, 12)))(clock()),
+        lambda: (lambda u: normed(Volatility, name=f"v{r.integers(1 << 30)}", update_frequency=us(u), lookback_periods=lb(u, 25)))(clock()),
+        lambda: normed(Inventory, update_frequency=us(clock())),
+        lambda: normed(EpisodeProportion, update_frequency=us(step_s), episode_length=us(episode_s)),
+        lambda: normed(TimeOfDay),
+        lambda: (lambda u: normed(TradeDirectionImbalance, name=f"tdi{r.integers(1 << 30)}", update_frequency=us(u), lookback_periods=lb(u, 20), track_internal=bool(r.random() < 0.5)))(clock()),
+        lambda: (lambda u: normed(TradeVolumeImbalance, name=f"tvi{r.integers(1 << 30)}", update_frequency=us(u), lookback_periods=lb(u, 20), track_internal=bool(r.random() < 0.5)))(clock()),
+        lambda: normed(BookImbalance, update_frequency=us(clock())),
+        lambda: (lambda u: normed(PriceRange, name=f"pr{r.integers(1 << 30)}", update_frequency=us(u), lookback_periods=lb(u, 8)))(clock()),
+        lambda: normed(Price, update_frequency=us(clock())),
+        amihud,
+    ]
+    feats = [pool[i]() for i in sorted(r.choice(len(pool), size=int(r.integers(2, 9)), replace=False))]
+    if not any(isinstance(f, Inventory) for f in feats): feats.append(Inventory())
+    if warm_s:  # the longest window is the warm-up and must be whole seconds (OrderbookSimulator.py:61): one feature spans it exactly
+        feats = [f for f in feats if f.window_size <= us(warm_s)]
+        feats.append(PriceMove(name="span", update_frequency=us(1.0), lookback_periods=warm_s))
+    else:
+        feats = [f for f in feats if f.window_size == us(0)] or [Inventory(), Spread()]
+    inv_idx = next(i for i, f in enumerate(feats) if isinstance(f, Inventory)) if any(isinstance(f, Inventory) for f in feats) else 0
+    conc = float(r.choice([10.0, 12.0, 30.0])) if r.random() < 0.3 else None
+    moc = bool(r.random() < 0.35)
+    minq = int(r.choice([0, 0, 1, 2]))
+    q = int(r.choice([2, 3, 5, 8, 10, 10, 12])) if not thin else int(r.choice([2, 3, 4]))
+    rew = lambda: [("PnL"), ("AD"), ("SD"), ("RS", int(r.choice([8, 32])), int(r.choice([2, 5, 8])))][int(r.integers(0, 4))]  # noqa: E731
+    high = float(r.choice([10.0, 10.0, 6.0, 40.0]))
+    if r.random() < 0.2 and conc is None and not moc: agent = gg.teradactyl_agent(inv_idx, max_inventory=int(r.choice([20, 150])), default_kappa=float(r.uniform(3, 9)), max_kappa=float(r.uniform(9, 12)))
+    else: agent = gg.random_agent(seed, high=high)
+    first = t0 + warm_s + 2
+    last = t1 - int(np.ceil(episode_s)) - 2
+    starts = [int(x) for x in r.integers(first, max(first + 1, last), size=2)]
+    kw = dict(step_s=step_s, step_reward=rew(), terminal_reward=rew(), enter_spread=bool(r.random() < 0.4), inc_prev=bool(r.random() < 0.4), moc=moc,
+              mofi=float(r.choice([0.25, 0.5, 1.0])) if moc else 0.0, concentration=conc, minq=minq, maxq=minq + q, initial=(int(r.choice([0, 0, 25, -10, 500])), 10**9),
+              outer_levels=int(r.choice([5, 20, 40])), top_k=8, continue_after_crash=True, save=False)  # fmt: skip
+    return kind, feats, agent, starts, episode_s, kw
+
+
+def run(seed):
+    kind, feats, agent, starts, episode_s, kw = draw(seed)
+    db, ps, tick, L, _, _ = day(kind)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):  # ("Clamping value of ..." once per clamped update)
+        try:
+            cfg, out = gg.run_trajectory(f"fuzz{seed}", db, tick, DATE, L, feats, agent, 2, starts, episode_s, **kw)
+        except OverflowError:
+            return dict(day=kind, skipped=["OverflowError"])
+    types = [str(t) for t in out.get("crash_types", [])]
+    if "AttributeError" in types or "OverflowError" in types:
+        # not the simulator's behaviour but the harness's / pandas': an episode without a single message leaves the reference with an
+        # empty DataFrame that has no `timestamp` column (HistoricalOrderGenerator.py:38); NaN volumes at levels that all hold orders
+        # become limit orders of 9.2e18 shares (int64 overflow of INT64_MIN - volume) that the dump cannot hold
+        return dict(day=kind, skipped=types)
+    sim = ol.oracle_sim(ol.cfg_from_golden(cfg))
+    sid = sim.add_stream(ps)
+    z = Z(out)
+    sharpe = any(isinstance(kw[k], tuple) for k in ("step_reward", "terminal_reward"))
+
+    def check_fills(k, fl):
+        got = ol.oracle_fills(sim)
+        assert np.array_equal(got, fl), f"step {k}: fill lists differ\n{got}\n{fl}"
+
+    replay_and_check(sim, cfg, z, sid, check_fills=check_fills, label=f"seed {seed}", reward_rtol=1e-5 if sharpe else None, reward_atol=1e-9)
+    # (RollingSharpe: mean / std of differences of log(AUM) - with 1e9 in cash and a few shares the differences are 1e-9, of which f64
+    # keeps six digits after log(1e9) = 20.7: a last-bit difference between libm's and numpy's log moves the ratio by up to 1e-3 of
+    # itself.  The state that produces the AUM is compared bit for bit.)
+    sim.close()
+    return dict(day=kind, steps=len(out["reward"]), crashes=[str(t) for t in out.get("crash_types", [])] + [f"reset:{t}" for t in out.get("reset_crash_types", [])], fills=len(out["fills"]), step_s=kw["step_s"], feats=len(feats), moc=kw["moc"], conc=kw["concentration"],
+                spread=kw["enter_spread"], rewards=(kw["step_reward"], kw["terminal_reward"]), resyncs=int(out["n_resyncs"][-1]) if len(out["n_resyncs"]) else 0)  # fmt: skip
+
+
+if __name__ == "__main__":
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    end = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    bad, t_all = 0, time.time()
+    for seed in range(first, end):
+        t = time.time()
+        try:
+            info = run(seed)
+            print(f"seed {seed:4d} OK   {time.time() - t:5.1f}s {info}", flush=True)
+        except AssertionError as ex:
+            bad += 1
+            print(f"seed {seed:4d} DIFF {time.time() - t:5.1f}s\n    -> {str(ex)[:1500]}", flush=True)
+        except Exception:
+            bad += 1
+            print(f"seed {seed:4d} ERROR {time.time() - t:5.1f}s\n{traceback.format_exc()[-1800:]}", flush=True)
+    print(f"{end - first} cases, {bad} with a difference or an error, {time.time() - t_all:.0f} s")
+    sys.exit(1 if bad else 0)

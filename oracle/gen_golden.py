@@ -318,8 +318,8 @@ def reward_from_spec(spec):
 
 def run_trajectory(name, db, ticker, date, n_levels, features, agent_fn, n_episodes, starts, episode_s, step_s=0.1,
                    step_reward="PnL", terminal_reward="PnL", enter_spread=False, inc_prev=False, moc=False, mofi=0.0,
-                   concentration=None, minq=0, maxq=10, initial=(0, 1000), outer_levels=20, top_k=12, stream_file=None, info=False, continue_after_crash=False):  # fmt: skip
-    if ONLY and name not in ONLY:
+                   concentration=None, minq=0, maxq=10, initial=(0, 1000), outer_levels=20, top_k=12, stream_file=None, info=False, continue_after_crash=False, save=True):  # fmt: skip
+    if save and ONLY and name not in ONLY:
         return
     step = timedelta(seconds=step_s)
     episode = timedelta(seconds=episode_s)
@@ -337,6 +337,7 @@ def run_trajectory(name, db, ticker, date, n_levels, features, agent_fn, n_episo
     )  # fmt: skip
     captured = {}
     orig_convert = env.convert_action_to_orders
+    A = env.action_space.shape[0]
 
     def convert(action):
         orders = orig_convert(action)
@@ -363,7 +364,16 @@ def run_trajectory(name, db, ticker, date, n_levels, features, agent_fn, n_episo
         env.min_start_timedelta = timedelta(seconds=start)
         env.max_end_timedelta = timedelta(seconds=start) + episode
         resyncs["n"] = 0
-        obs = env.reset()
+        try:
+            obs = env.reset()
+        except (AssertionError, Exception) as exc:  # (only oracle/fuzz_reference.py gets here: a warm-up that raises)
+            if not continue_after_crash:
+                raise
+            rec.setdefault("reset_crashes", []).append((ep, type(exc).__name__))
+            rec["reset_obs"].append(np.full(len(features) + (A if inc_prev else 0), np.nan))
+            rec["queues"].append(np.zeros((0, 5), dtype=np.int64))
+            rec["queue_off"].append(rec["queue_off"][-1])
+            continue
         rec["reset_obs"].append(np.asarray(obs, dtype=np.float64))
         agent = agent_fn(env, ep)
         while True:
@@ -427,7 +437,10 @@ def run_trajectory(name, db, ticker, date, n_levels, features, agent_fn, n_episo
         cr = rec.get("crashes", [])
         out.update(crash_eps=np.array([c[0] for c in cr], dtype=np.int64), crash_ks=np.array([c[1] for c in cr], dtype=np.int64), crash_types=np.array([c[2] for c in cr]),
                    crash_actions=np.array([c[3] for c in cr], dtype=np.float64).reshape(len(cr), A), crash_inventory=np.array([c[4] for c in cr], dtype=np.int64),
-                   crash_cash=np.array([c[5] for c in cr], dtype=np.int64))  # fmt: skip
+                   crash_cash=np.array([c[5] for c in cr], dtype=np.int64), reset_crash_eps=np.array([c[0] for c in rec.get("reset_crashes", [])], dtype=np.int64),
+                   reset_crash_types=np.array([c[1] for c in rec.get("reset_crashes", [])]))  # fmt: skip
+    if not save:  # (oracle/fuzz_reference.py: the record goes straight to the comparison)
+        return cfg, out
     np.savez_compressed(GOLD / f"traj_{name}.npz", **out)
     print(f"traj_{name}: {len(rec['reward'])} steps, final inv {rec['inventory'][-1]} cash {rec['cash'][-1]}, "
           f"{len(rec['fills'])} fills, resyncs {rec['n_resyncs'][-1]}, max agent orders {max(rec['n_agent'])}")  # fmt: skip
@@ -683,6 +696,13 @@ def main():
                             AmihudLambda(name="al2", update_frequency=timedelta(seconds=0.2), lookback_periods=4, slowing_factor=5, normalisation_on=True, max_norm_len=40),
                             AmihudLambda(name="al3", lookback_periods=2, slowing_factor=3), Volatility(name="v", update_frequency=timedelta(seconds=0.1), lookback_periods=10)]
         run_trajectory("synth_amihud_norm", db_s, "SYN", sdate, 10, amihud_n(), random_agent(61), 3, [35950, 35960, 35970], 6.0, stream_file="synth_small", initial=(0, 10**9))
+        # (e, found by oracle/fuzz_reference.py) Feature.clamp is max(min(number, max_value), min_value) with Python's min / max: a NaN
+        # - the z-score of a history of two equal values, max_norm_len=2 - comes back as NaN, and Volatility's running sum /
+        # AmihudLambda between slow updates carry it on for the rest of the episode
+        tiny_hist = lambda: [Volatility(name="v", update_frequency=timedelta(seconds=0.2), lookback_periods=5, normalisation_on=True, max_norm_len=2), Inventory(),  # noqa: E731
+                             AmihudLambda(name="al", lookback_periods=2, slowing_factor=2, normalisation_on=True, max_norm_len=2),
+                             Price(update_frequency=timedelta(seconds=0.1), normalisation_on=True, max_norm_len=7), Spread(normalisation_on=True, max_norm_len=2)]
+        run_trajectory("synth_norm_tiny", db_s, "SYN", sdate, 10, tiny_hist(), random_agent(62), 2, [35950, 35958], 5.0, stream_file="synth_small", initial=(0, 10**9))
         # (d) NaN volumes: concentration 12 with an action of 13 -> Beta's second shape parameter is negative, scipy's pdf is nan -> the
         # step raises KeyError when it looks for orders to cancel at a price that holds none; the env is reset and goes on (the second
         # episode also visits the Box's corner, action == concentration: c - (c + EPS) + EPS in floating point).  With market-order

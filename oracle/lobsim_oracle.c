@@ -610,7 +610,11 @@ static void reset_episode(oracle_t* h, Env* e, int64_t start_us, const int64_t* 
 /* ------------------------------------------------------------------------------------------------------------
  * Features (rl4mm/features/Features.py)
  * ---------------------------------------------------------------------------------------------------------- */
-static double clampd(double x, double lo, double hi) { double m = x < hi ? x : hi; return m > lo ? m : lo; } /* :99-100 */
+/* Feature.clamp, :99-100: max(min(number, max_value), min_value) with PYTHON's min / max - the first argument unless the second is
+ * strictly smaller / larger - so a NaN (the z-score of a constant history) comes back as NaN, not as a bound: the features whose
+ * update reads current_value (Volatility's running sum, AmihudLambda between slow updates) carry it on */
+static double clampd(double x, double lo, double hi) { double m = hi < x ? hi : x; return lo > m ? lo : m; }
+static double (*volatile libm_pow)(double, double) = pow;
 
 static void feature_alloc(Feature* f) {
     int lb = f->d.lookback;
@@ -678,8 +682,10 @@ static int feature_raw_update(const oracle_t* h, Env* e, Feature* f) {
             double last = f->prices[lb - 1];
             double new_ret = (e->price - last) / last;
             f->prices[lb] = e->price;
-            /* float ** 2 in CPython is libm pow(x, 2.0) */
-            double ss = f->current_value * lb - pow(old_ret, 2.0) + pow(new_ret, 2.0);
+            /* float ** 2 in CPython is libm's pow(x, 2.0), called at run time - through a volatile pointer here: the compiler folds a
+             * literal pow(x, 2.0) into x * x, which is the correctly rounded square and libm's pow, good to 1 ulp, is not always
+             * (found by oracle/fuzz_reference.py: one last bit in 90 000 steps) */
+            double ss = f->current_value * lb - libm_pow(old_ret, 2.0) + libm_pow(new_ret, 2.0);
             f->current_value = ss / lb;
         }
         return 1;

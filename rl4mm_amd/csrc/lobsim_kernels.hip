@@ -2316,7 +2316,10 @@ struct StepView {  // what Feature._update reads from State
     bool book_ok;
 };
 
-SDI double clampd(double x, double lo, double hi) { double m = x < hi ? x : hi; return m > lo ? m : lo; }
+// Feature.clamp (Features.py:99-100): max(min(number, max_value), min_value) with PYTHON's min / max - the first argument unless the
+// second is strictly smaller / larger: a NaN (the z-score of a constant history) stays NaN instead of becoming a bound, and the features
+// whose update reads current_value (Volatility's running sum, AmihudLambda between slow updates) carry it on
+SDI double clampd(double x, double lo, double hi) { double m = hi < x ? hi : x; return lo > m ? lo : m; }
 
 // Feature._update; returns false where the reference would raise
 // The two ring words the steady-state branches of feature_raw read (word 0, always allocated, where a branch reads none).

@@ -14,7 +14,8 @@ TRAJ = ["msft_fixed", "msft_teradactyl_ad", "msft_random_allfeat", "synth_defaul
         "synth_step50ms_default", "synth_step1s", "synth_step5s",  # (step_size 0.05 s / 1 s / 5 s)
         # round 5, what tests/diag/config_fuzz.py found, recorded from the reference: a feature value outliving reset(), NaN volumes
         # (with and without market-order clearing), a sweep that empties the book, enter_spread quotes on a crossed book
-        "synth_amihud_norm", "synth_conc_nan", "synth_conc_nan_moc", "thin_sweep_crash", "thin_crossed_spread"]  # fmt: skip
+        "synth_amihud_norm", "synth_conc_nan", "synth_conc_nan_moc", "thin_sweep_crash", "thin_crossed_spread",
+        "synth_norm_tiny"]  # fmt: skip  (found by oracle/fuzz_reference.py: Feature.clamp of a NaN is NaN)
 
 
 def _small_cfg(n_levels=8, **kw):

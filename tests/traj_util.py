@@ -4,7 +4,7 @@ import numpy as np
 import oracle_lib as ol
 
 
-def replay_and_check(sim, g, z, stream_id, obs_rtol=0.0, obs_atol=0.0, check_fills=None, label="", reward_rtol=None):
+def replay_and_check(sim, g, z, stream_id, obs_rtol=0.0, obs_atol=0.0, check_fills=None, label="", reward_rtol=None, reward_atol=1e-12):
     """Drives env 0 of `sim` with the golden actions.  Integers must match exactly; floats within
     (rtol, atol) - 0/0 means bit-exact.  `reward_rtol` (RollingSharpe only, whose exp/log are numpy's SIMD
     routines in the reference) relaxes the reward comparison alone."""
@@ -21,6 +21,9 @@ def replay_and_check(sim, g, z, stream_id, obs_rtol=0.0, obs_atol=0.0, check_fil
         if k >= n_steps and crash_step < 0:
             break
         obs0 = sim.reset(g["starts_us"][ep], stream_id)
+        if by_ep is not None and "reset_crash_eps" in z.files and ep in z["reset_crash_eps"]:  # the reference's reset raised (its warm-up did)
+            assert sim.env_state(0)["status"] != 0, f"{label}: the reference's reset of episode {ep} raised {z['reset_crash_types'][list(z['reset_crash_eps']).index(ep)]}"
+            continue
         _close(obs0[0], z["reset_obs"][ep], obs_rtol, obs_atol, f"{label} reset obs ep {ep}")
         crashed = False
         while True:
@@ -62,7 +65,7 @@ def replay_and_check(sim, g, z, stream_id, obs_rtol=0.0, obs_atol=0.0, check_fil
             _close(st["price"], z["price"][k], obs_rtol, obs_atol, f"{ctx} price")
             _close(obs[0], z["obs"][k], obs_rtol, obs_atol, f"{ctx} obs")
             if reward_rtol is not None:
-                _close(reward[0], z["reward"][k], reward_rtol, 1e-12, f"{ctx} reward")
+                _close(reward[0], z["reward"][k], reward_rtol, reward_atol, f"{ctx} reward")
             else:
                 _close(reward[0], z["reward"][k], 0.0, max(obs_atol, 1e-9) if obs_atol or obs_rtol else 0.0, f"{ctx} reward")
             assert bool(done[0]) == bool(z["done"][k]), f"{ctx}: done"
