@@ -581,6 +581,49 @@ def test_env_facade_reproduces_reference_trajectory():
     e.close()
 
 
+def test_env_facade_raises_and_goes_on_like_the_reference():
+    """The reference's trajectory thin_sweep_crash through the Gym surface: the third step's clearing order sells the 300 shares the
+    bids hold and raises EmptyOrderbookError out of `step`; the caller resets the env and goes on - from the portfolio the failed step
+    did not touch (Q7)."""
+    from datetime import datetime, timedelta
+
+    from rl4mm_amd import env as E
+
+    g, z = ol.load_traj("thin_sweep_crash")
+    cat = E.StreamCatalog().add(ol.golden_stream("thin"))
+    ms = timedelta(seconds=0.1)
+    e = E.HistoricalOrderbookEnvironment(
+        catalog=cat, features=[E.Inventory(), E.Spread(), E.Price(update_frequency=ms)], ticker="THN", step_size=ms, episode_length=timedelta(seconds=2),
+        min_date=datetime(2018, 2, 21), max_date=datetime(2018, 2, 21), min_start_timedelta=timedelta(microseconds=g["starts_us"][0]),
+        max_end_timedelta=timedelta(microseconds=g["starts_us"][0]) + timedelta(seconds=2), n_levels=3, max_quote_level=3, market_order_clearing=True,
+        market_order_fraction_of_inventory=1.0, initial_portfolio=E.Portfolio(inventory=500, cash=10**9),
+        per_step_reward_function=E.get_reward_function("PnL"), terminal_reward_function=E.get_reward_function("PnL"),
+    )  # fmt: skip
+    obs = e.reset()
+    assert np.array_equal(obs, z["reset_obs"][0])
+    for k in range(int(z["crash_ks"][0])):
+        obs, reward, done, _ = e.step(z["actions"][k])
+        assert np.array_equal(obs, z["obs"][k]) and reward == z["reward"][k] and not done
+    with pytest.raises(E.EmptyOrderbookError):
+        e.step(z["crash_actions"][0])
+    inv, cash, _ = e._venv.portfolios()
+    assert inv[0] == int(z["crash_inventory"][0]) == 500 and cash[0] == int(z["crash_cash"][0])
+    e._venv.min_start_timedelta = timedelta(microseconds=g["starts_us"][1])  # (the recording's second episode: oracle/gen_golden.py moves the window the same way)
+    e._venv.max_end_timedelta = e._venv.min_start_timedelta + timedelta(seconds=2)
+    obs = e.reset()
+    assert e._venv.sim.env_state(0)["now_us"] == g["starts_us"][1]
+    assert np.array_equal(obs, z["reset_obs"][1]) and obs[0] == 500.0
+    k = int(z["crash_ks"][0])
+    while True:
+        obs, reward, done, _ = e.step(z["actions"][k])
+        assert np.array_equal(obs, z["obs"][k]) and reward == z["reward"][k] and done == bool(z["done"][k])
+        k += 1
+        if done:
+            break
+    assert k == len(z["reward"])
+    e.close()
+
+
 def test_env_facade_normalised_features_and_sharpe_reward():
     """`-n True` and `-psr RS` through the Gym surface: feature classes built with normalisation_on=True (history sized by
     the env to warm-up + episode), the reference's normalised trajectory replayed action by action; then an env with the
