@@ -56,6 +56,7 @@ def day(kind):
         g = drift_lobster(7612, triangle_path(120, 0.1), n_levels=10, start_s=35_600, duration_s=70, noise_per_s=12.0, max_excursion=900)
         g["time_ns"] = np.round(g["time_s"] * 1e9).astype(np.int64)
         L, t0, t1 = 10, 35_600, 35_670
+    elif kind == "syn50": g, L, t0, t1 = generate_lobster(505050, 50, 300.0, 35_690, 35_790), 50, 35_690, 35_790
     else: g, L, t0, t1 = gg.thin_day(kind == "thinx"), 3, 36_000, 36_029
     tick = kind.upper()
     mpath, bpath = write_lobster_csv(g, tmp, tick, "2018-02-21", L)
@@ -68,11 +69,14 @@ def day(kind):
 def draw(seed):
     r = np.random.Generator(np.random.PCG64(31_000 + seed))
     kind = str(r.choice(["syn10", "syn10", "syn5", "drift", "drift", "thin", "thinx"]))
+    r2 = np.random.Generator(np.random.PCG64(131_000 + seed))  # (dimensions added later)
+    if seed >= 10_000 and r2.random() < 0.3: kind = "syn50"
     db, ps, tick, L, t0, t1 = day(kind)
     thin = kind.startswith("thin")
     step_s = float(r.choice([0.05, 0.1, 0.1, 0.2, 0.5, 1.0]))
     us = lambda s: timedelta(seconds=s)  # noqa: E731
     warm_s = int(r.choice([0, 1])) if thin else int(r.choice([1, 2, 3]))
+    if seed >= 10_000 and not thin and r2.random() < 0.3: warm_s = int(r2.choice([5, 8, 12]))  # (the default set's windows are minutes: these are at least longer than an episode)
     ep_steps = int(r.integers(6, 24))
     episode_s = ep_steps * step_s
     clock = lambda: float(r.choice([step_s, step_s, 2 * step_s, 1.0 if step_s <= 1.0 and (1.0 / step_s) == int(1.0 / step_s) else step_s]))  # noqa: E731

@@ -750,6 +750,10 @@ static int feature_raw_update(const oracle_t* h, Env* e, Feature* f) {
             f->current_value = sum / tlb;
         } else {
             double oldest = f->prices[0];
+            /* Python floats: a division by 0.0 raises ZeroDivisionError (:306, :309).  The averaged price is 0.0 exactly when
+             * slowing_factor is 1 - the partial sum is only added to between slow updates (:287-290), of which there are none - so
+             * such a feature raises at its (lookback + 2)-th update: the env stops (found by oracle/fuzz_reference.py) */
+            if (oldest == 0.0 || f->prices[tlb] == 0.0) return 0;
             memmove(f->prices, f->prices + 1, sizeof(double) * (size_t)tlb);
             double old_ret = (f->prices[0] - oldest) / oldest;
             int64_t old_dv = f->dvols[0];

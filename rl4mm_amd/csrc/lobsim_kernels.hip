@@ -2427,6 +2427,9 @@ SDI bool feature_raw(const lobsim_feature& d, FeatState& f, int64_t* ring, const
         } else {
             const int po = n % cap;  // oldest price (the slot the new one overwrites)
             const double oldest = pr[po], next_oldest = pr[(po + 1) % cap], newest = pr[(po + cap - 1) % cap];
+            // Python floats: a division by 0.0 raises ZeroDivisionError (:306, :309).  The averaged price is 0.0 exactly when slowing_factor
+            // is 1 (the partial sum is only added to BETWEEN slow updates, :287-290): such a feature raises at its (lookback + 2)-th update
+            if (oldest == 0.0 || newest == 0.0) return false;
             const double old_ret = (next_oldest - oldest) / oldest;
             const int64_t old_dv = dv[n % tlb];
             const double new_ret = (new_price - newest) / newest;

@@ -18,7 +18,7 @@ def replay_and_check(sim, g, z, stream_id, obs_rtol=0.0, obs_atol=0.0, check_fil
     # features' values, the exchange as the exception left it - and the next episode's reset shows what it kept
     by_ep = {int(e): i for i, e in enumerate(z["crash_eps"])} if "crash_eps" in z.files else None
     for ep in range(n_eps):
-        if k >= n_steps and crash_step < 0:
+        if k >= n_steps and crash_step < 0 and not ("reset_crash_eps" in z.files and len(z["reset_crash_eps"])):
             break
         obs0 = sim.reset(g["starts_us"][ep], stream_id)
         if by_ep is not None and "reset_crash_eps" in z.files and ep in z["reset_crash_eps"]:  # the reference's reset raised (its warm-up did)
