@@ -1,5 +1,5 @@
 set -u
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r5c; mkdir -p $OUT; cd $R
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r5h; mkdir -p $OUT; cd $R
 python3 bench.py > $OUT/bench_random.json 2> /dev/null
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_random_20steps.json 2>/dev/null
 python3 bench.py --agent-orders 128 --no-cpu-baseline --no-facade > $OUT/bench_random_agent128.json 2>/dev/null
