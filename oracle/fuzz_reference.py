@@ -133,6 +133,7 @@ def draw(seed):
     kw = dict(step_s=step_s, step_reward=rew(), terminal_reward=rew(), enter_spread=bool(r.random() < 0.4), inc_prev=bool(r.random() < 0.4), moc=moc,
               mofi=float(r.choice([0.25, 0.5, 1.0])) if moc else 0.0, concentration=conc, minq=minq, maxq=minq + q, initial=(int(r.choice([0, 0, 25, -10, 500])), 10**9),
               outer_levels=int(r.choice([5, 20, 40])), top_k=8, continue_after_crash=True, save=False)  # fmt: skip
+    if seed >= 10_000 and r2.random() < 0.4: kw["info"] = True  # SimpleInfoCalculator's dict of every step (InfoCalculators.py:17-89)
     return kind, feats, agent, starts, episode_s, kw
 
 
@@ -156,11 +157,24 @@ def run(seed):
     z = Z(out)
     sharpe = any(isinstance(kw[k], tuple) for k in ("step_reward", "terminal_reward"))
 
+    calc = None
+    if kw.get("info"):
+        from rl4mm_amd.env import SimpleInfoCalculator
+
+        # (the reference's calculator brings its own BetaOrderDistributor with the DEFAULT ten quote levels, whatever the env quotes:
+        # InfoCalculators.py:29 - so does the mirror)
+        calc = SimpleInfoCalculator(kw["mofi"], kw["enter_spread"], concentration=kw["concentration"])
+    cols = ["asset_price", "inventory", "cash", "aum", "market_spread", "agent_spread", "midprice_offset", "weighted_midprice_offset", "market_order_count", "market_order_total_volume"]
+
     def check_fills(k, fl):
         got = ol.oracle_fills(sim)
         assert np.array_equal(got, fl), f"step {k}: fill lists differ\n{got}\n{fl}"
+        if calc is not None:  # the info dict from the oracle's state through the package's mirror of SimpleInfoCalculator
+            arr = calc.calculate_arrays(sim, z["actions"][k][None, :])
+            mine = np.array([float(arr[c][0]) for c in cols])
+            assert np.array_equal(mine, z["info"][k], equal_nan=True), f"step {k}: info differs\n{mine}\n{z['info'][k]}"
 
-    replay_and_check(sim, cfg, z, sid, check_fills=check_fills, label=f"seed {seed}", reward_rtol=1e-5 if sharpe else None, reward_atol=1e-9)
+    replay_and_check(sim, cfg, z, sid, check_fills=check_fills, label=f"seed {seed}", reward_rtol=1e-5 if sharpe else None, reward_atol=2e-8 if sharpe else 1e-12)
     # (RollingSharpe: mean / std of differences of log(AUM) - with 1e9 in cash and a few shares the differences are 1e-9, of which f64
     # keeps six digits after log(1e9) = 20.7: a last-bit difference between libm's and numpy's log moves the ratio by up to 1e-3 of
     # itself.  The state that produces the AUM is compared bit for bit.)

@@ -313,9 +313,16 @@ def beta_volumes(actions: np.ndarray, quote_levels: int = 10, concentration: Opt
     x = 1 / quote_levels * np.array([i + 0.5 for i in range(quote_levels)])
     out = []
     for al, be in ((ab, bb), (as_, bs)):
-        pdf = np.power(x[None, :], al[:, None] - 1.0) * np.power(1.0 - x[None, :], be[:, None] - 1.0)
-        pdf = pdf / np.array([row.sum() for row in pdf])[:, None]  # per-row np.sum = the reference's summation order
-        out.append(np.round(pdf * active_volume).astype(np.int64))
+        with np.errstate(all="ignore"):
+            pdf = np.power(x[None, :], al[:, None] - 1.0) * np.power(1.0 - x[None, :], be[:, None] - 1.0)
+            tot = np.array([row.sum() for row in pdf])  # per-row np.sum = the reference's summation order
+            q = pdf / tot[:, None] * active_volume
+        # where the reference's distribution is NaN (scipy's pdf of a shape parameter <= 0: concentration mode, an action at or above
+        # the concentration; a pdf that sums to nothing) its volumes are np.round(nan).astype(int), which no caller can use - the step
+        # raises unless it clears the inventory, and the info calculator's argmax over their signs is 0: the kernels and this function
+        # say "no volume at any level" there
+        nan = ~((tot > 0) & np.isfinite(tot)) | ((be <= 0) if concentration is not None else np.zeros(len(tot), dtype=bool))
+        out.append(np.where(nan[:, None] | ~np.isfinite(q), 0, np.round(np.where(np.isfinite(q), q, 0.0))).astype(np.int64))
     return out[0], out[1]
 
 

@@ -126,9 +126,12 @@ def draw_case(seed: int, n: int):
             mi = float(r2.choice([20, 150, 1000]))
             policy = (_capi.POLICY_TERADACTYL, [mi, float(r2.uniform(3, 9)), float(r2.choice([0.3, 0.5, 0.8])), float(r2.uniform(9, 12)), float(r2.choice([1.0, 2.0])), inv_idx, float(moc), mi])
     masked = (not chunk) and r2.random() < 0.2  # lobsim_step's `active` mask: a tenth of the envs sits a step out
+    # SimpleInfoCalculator's arrays written by the step kernel's epilogue (lobsim_set_info_buffer) against the package's host mirror of
+    # the calculator working on the ORACLE's state (InfoCalculators.py:17-89); the kernel takes the env's own quote range, so level 0 up
+    with_info = (not chunk) and (not masked) and minq == 0 and r2.random() < 0.35
     desc = dict(kw, n_levels=n_levels, rate=rate, feats=[(f.kind, f.lookback, f.update_us, f.norm_len) for f in feats], amax=amax, ep_steps=ep_steps, chunk=chunk, bad_msgs=bad_msgs,
-                sharpe=sharpe, normalised=int(sum(f.norm_len > 0 for f in feats)), days=len(streams), policy=policy[0], masked=masked, drift=drift)
-    extra = dict(streams=streams, policy=policy, masked=masked, r2=r2)
+                sharpe=sharpe, normalised=int(sum(f.norm_len > 0 for f in feats)), days=len(streams), policy=policy[0], masked=masked, drift=drift, with_info=with_info)
+    extra = dict(streams=streams, policy=policy, masked=masked, r2=r2, with_info=with_info)
     return cfg, extra, starts, amax, ep_steps, desc, r, (first, total_s - warm_s - episode_us // 1_000_000 - 6), chunk
 
 
@@ -173,6 +176,15 @@ def run_case(seed: int, n: int):
         og[lost | reset_failed], oc[lost | reset_failed] = 0.0, 0.0
         if not np.allclose(og, oc, rtol=RTOL, atol=ATOL, equal_nan=True):
             return f"reset obs differ by {np.nanmax(np.abs(og - oc))}", desc
+        calc_dev = calc_host = None
+        if extra["with_info"] and not os.environ.get("FUZZ_SELF"):
+            from rl4mm_amd.env import SimpleInfoCalculator
+
+            ikw = dict(concentration=cfg.concentration if cfg.use_concentration else None, quote_levels=cfg.max_quote_level - cfg.min_quote_level)
+            calc_dev = SimpleInfoCalculator(cfg.market_order_fraction_of_inventory, bool(cfg.enter_spread), **ikw).attach(gpu)
+            calc_host = SimpleInfoCalculator(cfg.market_order_fraction_of_inventory, bool(cfg.enter_spread), **ikw)
+            if calc_dev._device_rows is None:
+                return "the info calculator did not attach to the device", desc
         A = cfg.action_dim
         high = np.full(A, amax)
         if cfg.market_order_clearing:
@@ -220,6 +232,14 @@ def run_case(seed: int, n: int):
             if not np.allclose(og, oc, rtol=RTOL, atol=ATOL, equal_nan=True):  # (NaN: the z-score of a constant history, both sides)
                 e, f = np.unravel_index(np.nanargmax(np.abs(og - oc)), og.shape)
                 return f"step {t}: obs differ by {np.abs(og - oc).max()} (env {e}, entry {f}; status gpu {gpu.status()[e]} / oracle {cpu.status()[e]})\n       gpu    {og[e].tolist()}\n       oracle {oc[e].tolist()}", desc
+            if calc_dev is not None:
+                a_dev, a_host = calc_dev.calculate_arrays(gpu, act[0]), calc_host.calculate_arrays(cpu, act[0])
+                live = (sg == 0) & ~skip
+                for col in ("asset_price", "inventory", "cash", "aum", "market_spread", "agent_spread", "agent_weighted_spread_value", "midprice_offset", "weighted_midprice_offset"):
+                    x, y = np.asarray(a_dev[col], dtype=np.float64)[live], np.asarray(a_host[col], dtype=np.float64)[live]
+                    if not np.allclose(x, y, rtol=1e-12, atol=1e-9, equal_nan=True):
+                        e = int(np.nonzero(live)[0][np.nanargmax(np.abs(x - y))])
+                        return f"step {t}: info column {col} differs in env {e}: device {a_dev[col][e]!r} vs host mirror on the oracle {a_host[col][e]!r}", desc
             if not np.allclose(rg, rc, rtol=r_rtol, atol=r_atol, equal_nan=True):  # (NaN: a RollingSharpe window of equal values, both sides)
                 return f"step {t}: reward differs by {np.abs(rg - rc).max()}", desc
             if dg.any() or lost.any():
@@ -271,7 +291,7 @@ if __name__ == "__main__":
         except Exception as ex:  # a configuration one side refuses: both must refuse it (reported, not counted as a difference)
             err, desc = f"EXCEPTION {type(ex).__name__}: {ex}", {}
         short = {k: desc[k] for k in ("step_us", "n_levels", "rate", "min_quote_level", "max_quote_level", "concentration", "market_order_clearing", "enter_spread", "ladder_levels",
-                                        "agent_orders", "max_levels", "outer_levels", "chunk", "bad_msgs", "sharpe", "normalised", "days", "policy", "masked", "resets", "flagged", "capacity_stops", "max_agent_orders", "inv_max") if k in desc}  # fmt: skip
+                                        "agent_orders", "max_levels", "outer_levels", "chunk", "bad_msgs", "sharpe", "normalised", "days", "policy", "masked", "with_info", "resets", "flagged", "capacity_stops", "max_agent_orders", "inv_max") if k in desc}  # fmt: skip
         print(f"seed {seed:4d} {'OK  ' if err is None else 'DIFF'} {time.time() - t:5.1f}s {short}" + (f"\n    -> {err}\n    {desc}" if err else ""), flush=True)
         bad += err is not None
     print(f"{end - first} cases, {bad} with a difference or an exception")
