@@ -57,14 +57,21 @@ enum lobsim_error {
  * observation for such a step (the exception leaves `step` / `reset`): the observation row of an env whose status is nonzero is
  * unspecified - compare statuses, not rows (the env facade raises / puts the condition into info["error"]). */
 enum lobsim_status {
-    LOBSIM_ST_EMPTY_BOOK = 1,      /* EmptyOrderbookError, rl4mm/orderbook/Exchange.py:180-186 */
+    LOBSIM_ST_EMPTY_BOOK = 1,      /* EmptyOrderbookError, rl4mm/orderbook/Exchange.py:180-186; np.arange(inf) of a book without asks
+                                      (HistoricalOrderbookEnvironment.py:298-322); a feature's _update that raises: the
+                                      ZeroDivisionError of BookImbalance / microprice on a side of volume 0, of AmihudLambda with
+                                      slowing_factor 1 (Features.py:306) */
     LOBSIM_ST_BAD_MESSAGE = 2,     /* cross_trade assert / trading_halt crash, HistoricalOrderGenerator.py:54-56 */
     LOBSIM_ST_LEVEL_OVERFLOW = 4,  /* more price levels than cfg.max_levels provides slabs for */
     LOBSIM_ST_QUEUE_OVERFLOW = 8,  /* more live orders at one price than the build holds */
     LOBSIM_ST_AGENT_OVERFLOW = 16, /* more live agent orders than the build holds */
     LOBSIM_ST_STREAM_END = 32,     /* no snapshot at or before the episode's start, or a step that ends 2 s or more beyond the
                                       last message / snapshot of the loaded stream */
-    LOBSIM_ST_ASSERT = 64,         /* `assert order.volume > 0` (Exchange.py:59-60) and similar */
+    LOBSIM_ST_ASSERT = 64,         /* `assert order.volume > 0` (Exchange.py:59-60: a clearing order that rounds to 0 shares, a
+                                      zero-volume message); the KeyError of a step whose Beta volumes are NaN (an action at or above
+                                      the concentration, shape parameters whose pdf underflows) unless it clears the inventory
+                                      (HistoricalOrderbookEnvironment.py:208-209, 238-240); RollingSharpe's non-positive AUM; a
+                                      forward_step that does not advance the clock (OrderbookSimulator.py:71-73) */
     LOBSIM_ST_NOT_RESET = 128
 };
 
