@@ -880,7 +880,7 @@ static int beta_volumes(const lobsim_cfg* cfg, const double* action, int64_t* bu
     double ab, bb, as, bs;
     if (cfg->use_concentration) { ab = a[0]; bb = cfg->concentration - a[0] + EPS; as = a[1]; bs = cfg->concentration - a[1] + EPS; }
     else { ab = a[0]; bb = a[1]; as = a[2]; bs = a[3]; }
-    double pb[128], ps[128];
+    double pb[128] = {0}, ps[128] = {0};
     for (int i = 0; i < Q; i++) {
         double x = 1.0 / Q * (i + 0.5);
         pb[i] = pow(x, ab - 1.0) * pow(1.0 - x, bb - 1.0);
