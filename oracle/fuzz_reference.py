@@ -66,6 +66,12 @@ def day(kind):
     return _days[kind]
 
 
+def _plain(cls, **kw):
+    f = cls(**kw)
+    f._spec = (cls.__name__, dict(kw))
+    return f
+
+
 def draw(seed):
     r = np.random.Generator(np.random.PCG64(31_000 + seed))
     kind = str(r.choice(["syn10", "syn10", "syn5", "drift", "drift", "thin", "thinx"]))
@@ -85,9 +91,12 @@ def draw(seed):
     def normed(cls, **kw):  # (not every feature class takes the normalisation arguments)
         extra = dict(normalisation_on=True, max_norm_len=int(r.choice([2, 7, 40, 600]))) if norm_case and r.random() < 0.5 else {}
         try:
-            return cls(**kw, **extra)
+            f = cls(**kw, **extra)
+            f._spec = (cls.__name__, dict(kw, **extra))  # (oracle/fuzz_facade.py builds the package's mirror class from the same arguments)
         except TypeError:
-            return cls(**kw)
+            f = cls(**kw)
+            f._spec = (cls.__name__, dict(kw))
+        return f
 
     def lb(u, hi):
         return int(r.integers(1, max(2, min(hi, int(warm_s / u) + 1)))) if warm_s else 1
@@ -112,12 +121,12 @@ def draw(seed):
         amihud,
     ]
     feats = [pool[i]() for i in sorted(r.choice(len(pool), size=int(r.integers(2, 9)), replace=False))]
-    if not any(isinstance(f, Inventory) for f in feats): feats.append(Inventory())
+    if not any(isinstance(f, Inventory) for f in feats): feats.append(normed(Inventory)) if False else feats.append(_plain(Inventory))
     if warm_s:  # the longest window is the warm-up and must be whole seconds (OrderbookSimulator.py:61): one feature spans it exactly
         feats = [f for f in feats if f.window_size <= us(warm_s)]
-        feats.append(PriceMove(name="span", update_frequency=us(1.0), lookback_periods=warm_s))
+        feats.append(_plain(PriceMove, name="span", update_frequency=us(1.0), lookback_periods=warm_s))
     else:
-        feats = [f for f in feats if f.window_size == us(0)] or [Inventory(), Spread()]
+        feats = [f for f in feats if f.window_size == us(0)] or [_plain(Inventory), _plain(Spread)]
     inv_idx = next(i for i, f in enumerate(feats) if isinstance(f, Inventory)) if any(isinstance(f, Inventory) for f in feats) else 0
     conc = float(r.choice([10.0, 12.0, 30.0])) if r.random() < 0.3 else None
     moc = bool(r.random() < 0.35)

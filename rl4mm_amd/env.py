@@ -391,7 +391,8 @@ class SimpleInfoCalculator:
             weighted_spread = weighted_spread + spread
         A = actions.shape[1]
         if A in (3, 5):  # :52-56, with the post-step inventory like the reference
-            hit = np.abs(inv) > actions[:, -1]
+            # (an env whose step raised never reaches the calculator in the reference: HistoricalOrderbookEnvironment.py:163-178)
+            hit = (np.abs(inv) > actions[:, -1]) & (np.asarray(sim.status()) == 0)
             self.market_order_count = self.market_order_count + hit
             self.market_order_total_volume = self.market_order_total_volume + np.where(hit, np.round(np.abs(inv) * self.market_order_fraction_of_inventory), 0.0)
         return dict(
@@ -1001,7 +1002,9 @@ class HistoricalOrderbookVectorEnv(_RayVectorEnv):
         self._after_reset()
         self._dones[ids] = False
         self._any_done = bool(self._dones.any())
-        self.status[ids] = 0
+        # (a reset can fail like the reference's - its warm-up replays the day with the features live: an empty side, a feature that
+        # raises, no data at the drawn time - and says so here; the env then reports done at its next step)
+        self.status[ids] = self.sim.status()[ids]
         return obs.astype(self.obs_dtype, copy=False)
 
     def vector_step(self, actions):
@@ -1048,7 +1051,10 @@ class HistoricalOrderbookEnvironment(_GymEnv):
         self.spec = None
 
     def reset(self):
-        return self._venv.reset_at(0)
+        obs = self._venv.reset_at(0)
+        if self._venv.status[0]:  # the reference's reset() raises what its warm-up raised (HistoricalOrderbookEnvironment.py:147-161)
+            self._raise(int(self._venv.status[0]))
+        return obs
 
     def step(self, action: np.ndarray):
         obs, reward, done, info = self._venv.vector_step(np.asarray(action, dtype=np.float64)[None, :])

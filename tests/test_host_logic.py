@@ -360,7 +360,7 @@ def test_info_dicts_feed_the_reference_metrics_callback():
     n = 3
     sim = types.SimpleNamespace(
         portfolios=lambda: (np.array([5, -7, 0]), np.array([10**6, 2 * 10**6, 1000]), np.array([2_700_050.0, 2_700_010.5, 2_699_990.0])),
-        best_prices=lambda: (np.array([2_700_000] * n), np.array([2_700_100] * n)),
+        best_prices=lambda: (np.array([2_700_000] * n), np.array([2_700_100] * n)), status=lambda: np.zeros(n, dtype=np.int32),
     )
     actions = np.array([[1.0, 2.0, 1.0, 2.0, 6.0], [0.5, 0.5, 3.0, 3.0, 6.0], [2.0, 1.0, 2.0, 1.0, 0.0]])
     calc = SimpleInfoCalculator(market_order_fraction_of_inventory=0.5)
