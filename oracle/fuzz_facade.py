@@ -32,31 +32,7 @@ import oracle_lib as ol  # noqa: E402
 from rl4mm_amd import env as E  # noqa: E402
 
 
-class OracleHandle:
-    """The CPU oracle where the facade expects a device handle: everything is forwarded, plus `host_io` / `step_host_io` (the array
-    path writes actions into the handle's buffers and reads the step's outputs from them) over plain numpy arrays."""
-
-    def __init__(self, cfg):
-        self._s = ol.oracle_sim(cfg)
-        n, A, D = self._s.n_envs, self._s.action_dim, self._s.obs_dim
-        self._io = dict(actions=np.zeros((n, A)), active=np.ones(n, dtype=np.uint8), obs=np.zeros((n, D)), obs_f32=np.zeros((n, D), dtype=np.float32),
-                        reward=np.zeros(n), done=np.zeros(n, dtype=np.uint8))  # fmt: skip
-
-    def __getattr__(self, name):
-        return getattr(self._s, name)
-
-    def host_io(self):
-        return self._io
-
-    def step_host_io(self, use_active=False, want_obs=1):
-        o, r, d = self._s.step(self._io["actions"], self._io["active"] if use_active else None)
-        self._io["obs"][:], self._io["obs_f32"][:], self._io["reward"][:], self._io["done"][:] = o, o, r, d
-
-    def limits(self):
-        return dict(level_slabs=1 << 20, ladder_levels=1 << 20, far_levels=1 << 20, queue_slots=1 << 20, agent_orders=1 << 20, fill_log_rows=1 << 20, bytes_per_env=0, queue_pages=0)
-
-    def drop_stream(self, sid):
-        pass
+OracleHandle = ol.OracleHandle  # (tests/oracle_lib.py)
 
 
 REWARDS = {"PnL": lambda: E.get_reward_function("PnL"), "AD": lambda: E.get_reward_function("AD"), "SD": lambda: E.get_reward_function("SD")}

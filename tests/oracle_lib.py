@@ -149,3 +149,32 @@ TERADACTYL_GOLDEN = {  # the agents oracle/gen_golden.py drove the reference wit
     "msft_teradactyl_ad": [100, 7.0, 0.5, 9.0, 1.0, 0, 0, 100],
     "synth_teradactyl_ad_spread": [300, 10.0, 0.5, 10.0, 1.0, 3, 0, 300],
 }
+
+
+class OracleHandle:
+    """The CPU oracle where rl4mm_amd.env expects a device handle (tests and oracle/fuzz_facade.py only: the product has no CPU path).
+    Everything is forwarded to the oracle's Sim; `host_io` / `step_host_io` - the array path writes actions into the handle's pinned
+    buffers and reads the step's outputs from them - work over plain numpy arrays."""
+
+    def __init__(self, cfg):
+        self._s = oracle_sim(cfg)
+        n, A, D = self._s.n_envs, self._s.action_dim, self._s.obs_dim
+        self._io = dict(actions=np.zeros((n, A)), active=np.ones(n, dtype=np.uint8), obs=np.zeros((n, D)), obs_f32=np.zeros((n, D), dtype=np.float32),
+                        reward=np.zeros(n), done=np.zeros(n, dtype=np.uint8))  # fmt: skip
+
+    def __getattr__(self, name):
+        return getattr(self._s, name)
+
+    def host_io(self):
+        return self._io
+
+    def step_host_io(self, use_active=False, want_obs=1):
+        o, r, d = self._s.step(self._io["actions"], self._io["active"] if use_active else None)
+        self._io["obs"][:], self._io["obs_f32"][:], self._io["reward"][:], self._io["done"][:] = o, o, r, d
+
+    def limits(self):
+        big = 1 << 20
+        return dict(level_slabs=big, ladder_levels=big, far_levels=big, queue_slots=big, agent_orders=big, fill_log_rows=big, bytes_per_env=0, queue_pages=0)
+
+    def drop_stream(self, sid):
+        pass

@@ -593,3 +593,42 @@ def test_array_path_output_pool_never_reuses_memory_the_caller_still_holds():
     assert (o4 == 4.0).all()  # (a reshape kept o3's memory out of the pool)
     o5, _, _ = env._out_buffers(np.dtype(np.float32))
     assert o5.dtype == np.float32 and o5.shape == (4, 3)
+
+
+def test_gym_facade_on_the_oracle_replays_the_reference_through_an_exception(monkeypatch):
+    """Everything ABOVE the C-ABI without a GPU: rl4mm_amd.env.HistoricalOrderbookEnvironment with the CPU oracle as its handle
+    (oracle_lib.OracleHandle - test infrastructure, the product has no CPU path) against the reference's trajectory thin_sweep_crash:
+    observations and rewards step by step, EmptyOrderbookError out of `step` where the reference raised it, the portfolio the failed
+    step did not touch, the next episode from it.  (oracle/fuzz_facade.py draws thousands of such cases against the reference itself
+    in the build container; tests/test_gpu_parity.py runs this one on the HIP path.)"""
+    from datetime import datetime, timedelta
+
+    from rl4mm_amd import env as E
+
+    monkeypatch.setattr(E._lib, "new_sim", ol.OracleHandle)
+    g, z = ol.load_traj("thin_sweep_crash")
+    ms = timedelta(seconds=0.1)
+    start = timedelta(microseconds=g["starts_us"][0])
+    e = E.HistoricalOrderbookEnvironment(
+        catalog=E.StreamCatalog().add(ol.golden_stream("thin")), features=[E.Inventory(), E.Spread(), E.Price(update_frequency=ms)], ticker="THN", step_size=ms,
+        episode_length=timedelta(seconds=2), min_date=datetime(2018, 2, 21), max_date=datetime(2018, 2, 21), min_start_timedelta=start, max_end_timedelta=start + timedelta(seconds=2),
+        n_levels=3, max_quote_level=3, market_order_clearing=True, market_order_fraction_of_inventory=1.0, initial_portfolio=E.Portfolio(inventory=500, cash=10**9),
+        per_step_reward_function=E.get_reward_function("PnL"), terminal_reward_function=E.get_reward_function("PnL"),
+    )  # fmt: skip
+    assert np.array_equal(e.reset(), z["reset_obs"][0])
+    k_crash = int(z["crash_ks"][0])
+    for k in range(k_crash):
+        obs, reward, done, _ = e.step(z["actions"][k])
+        assert np.array_equal(obs, z["obs"][k]) and reward == z["reward"][k] and not done
+    with pytest.raises(E.EmptyOrderbookError):
+        e.step(z["crash_actions"][0])
+    inv, cash, _ = e._venv.portfolios()
+    assert inv[0] == int(z["crash_inventory"][0]) == 500 and cash[0] == int(z["crash_cash"][0])
+    e._venv.min_start_timedelta = timedelta(microseconds=g["starts_us"][1])
+    e._venv.max_end_timedelta = e._venv.min_start_timedelta + timedelta(seconds=2)
+    assert np.array_equal(e.reset(), z["reset_obs"][1])
+    for k in range(k_crash, len(z["reward"])):
+        obs, reward, done, _ = e.step(z["actions"][k])
+        assert np.array_equal(obs, z["obs"][k]) and reward == z["reward"][k] and done == bool(z["done"][k])
+    assert done
+    e.close()
