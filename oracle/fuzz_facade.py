@@ -72,6 +72,11 @@ def run(seed):
         enter_spread=kw["enter_spread"], n_levels=L, outer_levels=kw["outer_levels"], info_calculator=calc,
     )  # fmt: skip
     assert env.action_space.shape == (cfg["action_dim"],), (env.action_space.shape, cfg["action_dim"])
+    # the spaces RLlib builds its policy from (HistoricalOrderbookEnvironment.py:85-94, 125-135)
+    for mine, ref, what in ((env.action_space.low, out["act_low"], "action low"), (env.action_space.high, out["act_high"], "action high"),
+                            (env.observation_space.low, out["obs_low"], "observation low"), (env.observation_space.high, out["obs_high"], "observation high")):
+        assert np.array_equal(np.asarray(mine), ref), f"{what}: {np.asarray(mine)} vs {ref}"
+    assert str(np.dtype(env.observation_space.dtype)) == str(out["obs_dtype"]) and str(np.dtype(env.action_space.dtype)) == str(out["act_dtype"]), (env.observation_space.dtype, out["obs_dtype"])
     sharpe = any(isinstance(kw[k], tuple) for k in ("step_reward", "terminal_reward"))
     crash_by_ep = {int(e): i for i, e in enumerate(out["crash_eps"])}
     reset_crash = {int(e) for e in out["reset_crash_eps"]}

@@ -440,6 +440,8 @@ def run_trajectory(name, db, ticker, date, n_levels, features, agent_fn, n_episo
                    crash_cash=np.array([c[5] for c in cr], dtype=np.int64), reset_crash_eps=np.array([c[0] for c in rec.get("reset_crashes", [])], dtype=np.int64),
                    reset_crash_types=np.array([c[1] for c in rec.get("reset_crashes", [])]))  # fmt: skip
     if not save:  # (oracle/fuzz_reference.py: the record goes straight to the comparison)
+        out.update(obs_low=np.asarray(env.observation_space.low), obs_high=np.asarray(env.observation_space.high), act_low=np.asarray(env.action_space.low),
+                   act_high=np.asarray(env.action_space.high), obs_dtype=np.array(str(np.dtype(env.observation_space.dtype))), act_dtype=np.array(str(np.dtype(env.action_space.dtype))))  # fmt: skip
         return cfg, out
     np.savez_compressed(GOLD / f"traj_{name}.npz", **out)
     print(f"traj_{name}: {len(rec['reward'])} steps, final inv {rec['inventory'][-1]} cash {rec['cash'][-1]}, "
