@@ -1,0 +1,126 @@
+"""Diagnostic (not part of the suite): `rl4mm_amd.simulator.OrderbookSimulator` on the HIP library against the same class on the CPU
+oracle under random internal orders - the GPU half of oracle/fuzz_simulator.py (which holds the oracle side against the reference's
+OrderbookSimulator in the build container).  A case: a synthetic day (steady or drifting, 5 / 10 / 50 levels), 25 - 60 `forward_step`
+calls of 50 ms .. 2 s, each with up to four internal orders (limit orders around and through the touch, market orders, cancellations
+and deletions of own orders by id); after every call the FilledOrders lists, both books order by order, the price ranges; an
+exception on one side must be one on the other.
+usage: python tests/diag/simulator_fuzz.py [first_seed=0] [end_seed=100]"""
+import sys
+import time
+import traceback
+from datetime import datetime, timedelta
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import oracle_lib as ol
+from drift_stream import drift_stream, triangle_path
+from rl4mm_amd import simulator as S
+from rl4mm_amd.synth import synthetic_stream
+
+DATE = datetime(2018, 2, 21)
+
+
+def book_rows(book):
+    rows = []
+    for side, d in ((0, book.buy), (1, book.sell)):
+        prices = list(d.keys())
+        for p in (reversed(prices) if side == 0 else prices):
+            rows += [(side, int(p), int(o.volume), bool(o.is_external)) for o in d[p]]
+    return rows
+
+
+_days = {}
+
+
+def day(kind):
+    if kind not in _days:
+        if kind == "drift": _days[kind] = (drift_stream(7612, triangle_path(120, 0.1), n_levels=10, start_s=35_600, duration_s=70, noise_per_s=12.0, max_excursion=900), 10, 35_600, 35_670)
+        else:
+            L, rate, mid = {"syn5": (5, 60.0, 60_000), "syn10": (10, 200.0, 2_700_000), "syn50": (50, 300.0, 2_700_000)}[kind]
+            _days[kind] = (synthetic_stream(424242 + L, n_levels=L, msgs_per_s=rate, start_s=35_690, end_s=35_800, mid_price=mid, ticker="DRIFT" if False else "SYN"), L, 35_690, 35_800)
+    return _days[kind]
+
+
+def run(seed):
+    r = np.random.Generator(np.random.PCG64(88_000 + seed))
+    kind = str(r.choice(["syn10", "syn10", "syn5", "drift", "syn50"]))
+    ps, L, t0, t1 = day(kind)
+    kw = dict(ticker=ps.ticker, n_levels=L, database=ps, episode_length=timedelta(seconds=t1 - t0), outer_levels=int(r.choice([5, 20, 40])),
+              ladder_levels=int(r.choice([0, 0, 128])) if L <= 64 else 0)  # fmt: skip
+    gpu, cpu = S.OrderbookSimulator(**kw), S.OrderbookSimulator(**{k: v for k, v in kw.items() if k != "ladder_levels"}, _new_sim=ol.oracle_sim)
+    try:
+        start = DATE + timedelta(seconds=int(r.integers(t0 + 1, t1 - 25)))
+        assert book_rows(gpu.reset_episode(start)) == book_rows(cpu.reset_episode(start)), "start books differ"
+        now, seen, n_orders, n_fills = start, [], 0, 0
+        n_steps = int(r.integers(25, 60))
+        for step in range(n_steps):
+            until = now + timedelta(seconds=float(r.choice([0.05, 0.1, 0.1, 0.25, 0.5, 1.0, 2.0])))
+            if until > DATE + timedelta(seconds=t1 - 2): break
+            if r.random() < 0.3: until = until.replace(microsecond=0) + timedelta(seconds=1)
+            og, oc = [], []
+            bb, bs = cpu.exchange.best_buy_price, cpu.exchange.best_sell_price
+            for _ in range(int(r.choice([0, 0, 1, 1, 2, 3, 4]))):
+                what = r.random()
+                if what < 0.35 and seen:
+                    id_g, id_c, direction, price, v0 = seen[int(r.integers(0, len(seen)))]
+                    whole = r.random() < 0.5
+                    vol = None if whole and r.random() < 0.5 else int(v0 if whole else max(1, int(r.integers(1, v0 + 1))))
+                    cls = S.Deletion if vol is None else S.Cancellation
+                    k = dict(timestamp=now, direction=direction, ticker=ps.ticker, external_id=None, is_external=False, price=price, volume=vol)
+                    og.insert(0, cls(internal_id=id_g, **k)); oc.insert(0, cls(internal_id=id_c, **k))
+                elif what < 0.85:
+                    side = "buy" if r.random() < 0.5 else "sell"
+                    ref_p = bb if side == "buy" else bs
+                    if not np.isfinite(ref_p) or ref_p <= 0: continue
+                    off = int(r.choice([-3, -2, -1, 0, 0, 1, 2, 4, 8]))
+                    price = int(ref_p - off * 100) if side == "buy" else int(ref_p + off * 100)
+                    if price <= 0: continue
+                    k = dict(timestamp=now, direction=side, ticker=ps.ticker, internal_id=None, external_id=None, is_external=False, price=price, volume=int(r.choice([1, 5, 10, 50, 200])))
+                    og.append(S.LimitOrder(**k)); oc.append(S.LimitOrder(**k))
+                else:
+                    k = dict(timestamp=now, direction="buy" if r.random() < 0.5 else "sell", ticker=ps.ticker, internal_id=None, external_id=None, is_external=False, volume=int(r.choice([1, 10, 100, 1000])))
+                    og.append(S.MarketOrder(**k)); oc.append(S.MarketOrder(**k))
+            n_orders += len(og)
+            eg = ec = None
+            try: fg = gpu.forward_step(until, og)
+            except NotImplementedError: return dict(day=kind, skipped=True)
+            except Exception as ex: eg = type(ex).__name__  # noqa: BLE001
+            try: fc = cpu.forward_step(until, oc)
+            except Exception as ex: ec = type(ex).__name__  # noqa: BLE001
+            assert eg == ec, f"step {step}: HIP {eg}, oracle {ec}; orders {oc}"
+            if eg is not None: return dict(day=kind, steps=step, orders=n_orders, fills=n_fills, raised=eg)
+            for name in ("internal", "external"):
+                a, b = [(o.direction, o.price, o.volume) for o in getattr(fg, name)], [(o.direction, o.price, o.volume) for o in getattr(fc, name)]
+                assert a == b, f"step {step}: {name} fills differ\n{a}\n{b}\norders {oc}"
+                n_fills += len(a)
+            a, b = book_rows(gpu.exchange.central_orderbook), book_rows(cpu.exchange.central_orderbook)
+            assert a == b, f"step {step}: central books differ\norders {oc}"
+            ig, ic = gpu.exchange.internal_orderbook, cpu.exchange.internal_orderbook
+            assert book_rows(ig) == book_rows(ic), f"step {step}: internal books differ\norders {oc}"
+            assert (gpu.min_buy_price, gpu.max_sell_price) == (cpu.min_buy_price, cpu.max_sell_price), f"step {step}: price ranges"
+            alive = [(x.internal_id, y.internal_id, sn, int(p), int(x.volume)) for sn in ("buy", "sell") for p in getattr(ig, sn).keys() for x, y in zip(getattr(ig, sn)[p], getattr(ic, sn)[p])]
+            dead = [e for e in seen if e[0] not in {x[0] for x in alive}]
+            seen = alive + (dead[-3:] if r.random() < 0.3 else [])
+            now = until
+        return dict(day=kind, steps=n_steps, orders=n_orders, fills=n_fills)
+    finally:
+        gpu.close(); cpu.close()
+
+
+if __name__ == "__main__":
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    end = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    bad = 0
+    for seed in range(first, end):
+        t = time.time()
+        try: print(f"seed {seed:4d} OK   {time.time() - t:5.1f}s {run(seed)}", flush=True)
+        except AssertionError as ex:
+            bad += 1; print(f"seed {seed:4d} DIFF\n    -> {str(ex)[:1500]}", flush=True)
+        except Exception:
+            bad += 1; print(f"seed {seed:4d} ERROR\n{traceback.format_exc()[-2000:]}", flush=True)
+    print(f"{end - first} cases, {bad} with a difference or an error")
+    sys.exit(1 if bad else 0)
