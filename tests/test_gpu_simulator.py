@@ -152,3 +152,19 @@ def test_forward_argument_errors_and_fill_log_overflow():
         with pytest.raises(_capi.LobsimError):
             sim.fills(0, cap=4 * lim["fill_log_rows"])
     sim.close()
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_drawn_internal_orders_through_the_simulator_class(seed):
+    """A bounded sample of tests/diag/simulator_fuzz.py: `rl4mm_amd.simulator.OrderbookSimulator` on the HIP library against the same
+    class on the oracle - 25 - 60 forward_step calls with random internal orders (limit orders around and through the touch, market
+    orders, cancellations / deletions by id), FilledOrders lists, both books and the price ranges after every call, the same
+    exception where one is raised.  (oracle/fuzz_simulator.py holds the oracle side against the reference's OrderbookSimulator.)"""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent / "diag"))
+    import simulator_fuzz
+
+    info = simulator_fuzz.run(seed)
+    assert "skipped" not in info, info
