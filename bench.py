@@ -36,7 +36,7 @@ HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md
 ENVS_PER_GPU = 4096
 STEP_US = 100_000
 EPISODE_US = 1_800_000_000  # 30 min, the reference default
-PROFILE_ROUND = "r5"
+PROFILE_ROUND = "r6"
 REPEATS = 5  # timed regions of --steps steps per invocation; `value` is the median region
 
 WORKLOADS = {
@@ -45,15 +45,28 @@ WORKLOADS = {
     "ad": "4096 envs per GPU, synthetic 10-level stream, random actions, AD (asymmetrically dampened) per-step reward (BASELINE.json configs[3] shard)",
     "deep50": "8192 envs per GPU, 50-level books, 4 tickers at 50/150/300/600 msg/s, 100 ms snapshots (BASELINE.json configs[4] shard)",
     "rs": "4096 envs per GPU, synthetic 10-level stream, random actions, RollingSharpe per-step and terminal reward (env_config -psr RS: the kernel variants that carry RollingSharpe / normalisation)",
+    "norm": "4096 envs per GPU, synthetic 10-level stream, random actions, default features with normalisation_on (env_config -n True: every feature update z-scores its value against the feature's whole history, Features.py:60-74 - the one HBM-bound configuration of the path)",
 }
+# max_norm_len of the reference's default features (rl4mm/features/Features.py: Spread 10 000, the others 100 000), in the order of default_features()
+DEFAULT_MAX_NORM_LEN = (10_000, 100_000, 100_000, 100_000, 100_000, 100_000, 100_000, 100_000, 100_000, 100_000)
+WARMUP_US = 300_000_000  # the longest window of the default features (5 min Volatility)
 DEEP50_RATES = (50.0, 150.0, 300.0, 600.0)
 TERADACTYL_PARAMS = [1000, 10.0, 0.5, 10.0, 1.0, 5, 0, 1000]  # max_inventory, kappa, omega, max_kappa, exponent, inventory feature index, no MOC, denom
 
 
-def default_features(capi):
-    """HistoricalOrderbookEnvironment.get_default_features (HistoricalOrderbookEnvironment.py:395-440)."""
+def default_features(capi, normalisation_on=False):
+    """HistoricalOrderbookEnvironment.get_default_features (HistoricalOrderbookEnvironment.py:395-440).  normalisation_on: every feature
+    carries its z-score history, sized like rl4mm_amd/env.py:Feature.desc_for sizes it - what warm-up + episode can append."""
     F = capi.make_feature
     ep = STEP_US / EPISODE_US
+    feats = _default_features(F, capi, ep)
+    if normalisation_on:
+        for f, mx in zip(feats, DEFAULT_MAX_NORM_LEN):
+            f.norm_len = min(mx, (WARMUP_US + EPISODE_US) // f.update_us + 4)
+    return feats
+
+
+def _default_features(F, capi, ep):
     return [
         F(capi.F_SPREAD, 0, STEP_US, 0, 5000),
         F(capi.F_PRICE_MOVE, 1, 100_000, -1e4, 1e4),
@@ -171,7 +184,26 @@ def workload_cfg(capi, workload, n_envs, device_id=0, ladder_levels=0, agent_ord
         kw.update(per_step_reward=(capi.R_INVENTORY_ADJUSTED, 1, 0.1), terminal_reward=(capi.R_INVENTORY_ADJUSTED, 1, 0.1))
     if workload == "rs":  # get_reward_function("RS"): RollingSharpe(max_window_size=120, min_window_size=60)
         kw.update(per_step_reward=(capi.R_ROLLING_SHARPE, 0, 0.0, 120, 60), terminal_reward=(capi.R_ROLLING_SHARPE, 0, 0.0, 120, 60))
-    return capi.make_cfg(n_envs, 50 if workload == "deep50" else 10, default_features(capi), **kw)
+    return capi.make_cfg(n_envs, 50 if workload == "deep50" else 10, default_features(capi, normalisation_on=workload == "norm"), **kw)
+
+
+def norm_history_bytes(cfg, start_us, first_step, n_steps):
+    """Algorithmic bytes per env-step of the z-score histories over steps [first_step, first_step + n_steps) after the reset: every update
+    of a normalised feature reads its history twice (the mean, then the squared deviations), 8 B per element.  The history holds one
+    value per update since the reset's warm-up began (the first append counts twice: Features.py:67-72), up to norm_len."""
+    total = 0
+    t0 = start_us - cfg.warmup_us  # the clock at the top of the warm-up
+    for i in range(cfg.n_features):
+        f = cfg.features[i]
+        if f.norm_len <= 0:
+            continue
+        first_usage = start_us - f.lookback * f.update_us
+        t = t0 + cfg.step_us * np.arange(1, cfg.warmup_us // cfg.step_us + first_step + n_steps + 1)  # the end of every step since the reset
+        upd = (t >= first_usage) & (t % f.update_us == 0)
+        n_hist = np.minimum(np.cumsum(upd) + 1, f.norm_len)  # history length when the update's sums run
+        timed = slice(cfg.warmup_us // cfg.step_us + first_step, None)
+        total += int(np.sum(n_hist[timed][upd[timed]])) * 16
+    return total / n_steps
 
 
 def workload_starts(workload, n_envs, n_streams, seed):
@@ -193,7 +225,7 @@ def pmc_traffic(workload, n_envs):
     f = ROOT / "profiles" / PROFILE_ROUND / ("pmc_step_kernel.csv" if workload == "random" else f"pmc_step_kernel_{workload}.csv")
     try:
         rows = {r.split(",")[1]: float(r.split(",")[2]) for r in f.read_text().splitlines()[1:] if r.count(",") >= 3}
-        if int(rows["SQ_WAVES"]) != n_envs:
+        if int(rows["SQ_WAVES"]) not in (n_envs, n_envs + 16):  # (+ 16: the sorter waves at the head of a step launch, lpt_sort)
             return None, None
         return (2.0 * rows["FETCH_SIZE"] + rows["WRITE_SIZE"]) * 1024.0, str(f.relative_to(ROOT))
     except (OSError, KeyError, ValueError):
@@ -411,6 +443,8 @@ def closed_loop_leg(venv, n_envs, device_id, steps=200):
             obs, _, _ = venv.vector_step_tensors(act)
         torch.cuda.synchronize()
         out["eager"] = n_envs * steps / (time.perf_counter() - t0)
+    # (torch.cuda.graph ends the capture in its __exit__ also when the body raises: a failed capture cannot leave the stream capturing for
+    # the legs that follow; the replays stay inside the try of the caller)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, stream=s):
         think(obs)
@@ -423,6 +457,7 @@ def closed_loop_leg(venv, n_envs, device_id, steps=200):
         g.replay()
     torch.cuda.synchronize()
     out["hip_graph"] = n_envs * steps / (time.perf_counter() - t0)
+    out["hip_graph_note"] = "a replayed graph reads the launch order it was captured with: the longest-job-first order of the step launch (lpt_sort) is stale under replay - valid, not current"
     out["note"] = "2 x 256 tanh MLP (f32) -> sigmoid x 10 -> f64 actions -> vector_step_tensors (f32 observations), per env-step of the closed loop; done envs are skipped on the device, none finishes inside the leg"
     return out
 
@@ -673,13 +708,18 @@ def main():
             n_msgs += int(np.sum(np.searchsorted(s.msgs[:, 0], t_hi[m], side="right") - np.searchsorted(s.msgs[:, 0], t_lo[m], side="right")))
         m_bar = n_msgs / (N * K)
         b_step = 32.0 * m_bar + 105.0
+        norm_bytes = 0.0
+        if wl == "norm":  # + 2 passes x 8 B x history length for every feature update of the timed steps (mean, then squared deviations)
+            norm_bytes = norm_history_bytes(cfg, int(starts[0]), W, K * R)
+            b_step += norm_bytes
         achieved = N * b_step / (kernel_ms * 1e-3)
         sample = range(0, N, max(1, N // 64))
         st_bad = sum(sim.env_state(int(e))["status"] != 0 for e in sample)
         traffic, traffic_src = pmc_traffic(wl, N)
         lim = sim.limits()
-        kernel = "lob_step_kernel<%s, %d, %d, %s>" % ("true" if wl == "rs" else "false", lim["ladder_levels"], lim["agent_orders"],
-                                                     "false" if (wl == "rs" or os.environ.get("LOBSIM_GENERIC_KERNELS")) else "true")  # <EXTRAS, ladder, agent table, SPEC>
+        extras = wl in ("rs", "norm")
+        kernel = "lob_step_kernel<%s, %d, %d, %s>" % ("true" if extras else "false", lim["ladder_levels"], lim["agent_orders"],
+                                                     "false" if (extras or os.environ.get("LOBSIM_GENERIC_KERNELS")) else "true")  # <EXTRAS, ladder, agent table, SPEC>
         # (Teradactyl: lobsim_rollout_device with T = 1 runs the step kernel, the policy in its prologue)
         out = {
             "metric": "env-steps/sec (batched LOB sims)", "value": world * N * K / elapsed, "unit": "env-steps/s",
@@ -687,7 +727,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "int64+f64", "data": "synthetic",
             "config": {
                 "workload": WORKLOADS[wl], "envs_per_gpu": N, "global_envs": world * N, "features": "full_state (10 default features, 5 min warm-up)",
-                "agent_orders": lim["agent_orders"], "device_bytes_per_env": lim["bytes_per_env"], "step_size_s": 0.1, "reward": "AD" if wl == "ad" else "RS" if wl == "rs" else "PnL", "messages_per_env_step": round(m_bar, 2), "messages_per_s": round(world * N * K / elapsed * m_bar), "parallelism": f"env-sharded x{world}",
+                "agent_orders": lim["agent_orders"], "device_bytes_per_env": lim["bytes_per_env"], "step_size_s": 0.1, "reward": "AD" if wl == "ad" else "RS" if wl == "rs" else "PnL", **({"normalisation_on": True, "normalisation_history_bytes_per_env_step": round(norm_bytes)} if wl == "norm" else {}), "messages_per_env_step": round(m_bar, 2), "messages_per_s": round(world * N * K / elapsed * m_bar), "parallelism": f"env-sharded x{world}",
                 "reset_seconds": round(reset_s, 3), "envs_in_error_state_sampled": int(st_bad), "nan_returns": n_bad,
                 "ranks": world, "ms_per_step_per_rank": [round(x, 5) for x in per_rank_ms], "gathered_returns": int(all_returns.numel()),
             },

@@ -72,7 +72,9 @@ enum lobsim_status {
                                       the concentration, shape parameters whose pdf underflows) unless it clears the inventory
                                       (HistoricalOrderbookEnvironment.py:208-209, 238-240); RollingSharpe's non-positive AUM; a
                                       forward_step that does not advance the clock (OrderbookSimulator.py:71-73) */
-    LOBSIM_ST_NOT_RESET = 128
+    LOBSIM_ST_NOT_RESET = 128,
+    LOBSIM_ST_INTERNAL = 256       /* only ever set by the diagnostic build of the library (-DLOBSIM_BOUNDS, liblobsim_bounds.so): a computed index
+                                      left its array; bits 16 - 30 hold the line of lobsim_kernels.hip whose check failed */
 };
 
 enum lobsim_feature_kind { /* rl4mm/features/Features.py */
@@ -193,7 +195,9 @@ typedef struct lobsim_order_view {
                         this price (0 = oldest); snapshot aggregate: -1 */
     int64_t volume;
     int32_t kind;    /* 0 tracked external, 1 agent, 2 snapshot aggregate (internal_id == -1) */
-    int32_t reserved;
+    int32_t reserved; /* agent order: its TAG - the id the caller of lobsim_forward / lobsim_debug_process_orders gave the limit order (row id > 0), else
+                         the env's submission counter at that moment; unique among an env's live agent orders, ascending in submission order
+                         (the role of the reference's internal_id, OrderIDConvertor.py:12-19).  0 for the other kinds */
 } lobsim_order_view;
 
 typedef struct lobsim lobsim_t;
@@ -201,7 +205,7 @@ typedef struct lobsim lobsim_t;
 /* Bumped whenever a struct of this header changes layout or an entry point changes meaning: a binding compares it with the
  * LOBSIM_ABI_VERSION it was written against before it passes a config struct: a stale prebuilt library would otherwise
  * read the struct at the wrong offsets and still produce plausible numbers. */
-#define LOBSIM_ABI_VERSION 5
+#define LOBSIM_ABI_VERSION 6
 int lobsim_abi_version(void);
 
 int lobsim_create(const lobsim_cfg* cfg, lobsim_t** out);
@@ -304,11 +308,11 @@ typedef struct lobsim_limits {
     int32_t level_slabs;     /* price levels an env can hold in all, both sides together (= 2 x the effective max_levels) */
     int32_t ladder_levels;   /* levels per side kept on chip (64 / 128); a performance property, bounds nothing */
     int32_t far_levels;      /* levels per side beyond the on-chip ladder (2048) */
-    int32_t queue_slots;     /* live orders + tombstones at one price (1024) */
+    int32_t queue_slots;     /* live orders + tombstones at one price (4096; 1024 until ABI 6) */
     int32_t agent_orders;    /* live agent orders (cfg.agent_orders: 256 or 128) */
     int32_t fill_log_rows;   /* rows per list of the fill log of lobsim_forward */
     int64_t bytes_per_env;   /* device memory per env */
-    int32_t queue_pages;     /* 1 KiB pages (64 order slots) of queue memory per env.  A level's queue is 1, 4 or 16 pages - it moves up when
+    int32_t queue_pages;     /* 1 KiB pages (64 order slots) of queue memory per env.  A level's queue is 1, 4, 16 or 64 pages - it moves up when
                                 it fills its pages before 128 tombstones have piled up - cut from this pool; with no larger piece left a
                                 level stays where it is (and squeezes its tombstones out more often): LOBSIM_ST_QUEUE_OVERFLOW only when its
                                 pages are full of LIVE orders, LOBSIM_ST_LEVEL_OVERFLOW when a new level finds no page */
@@ -366,12 +370,26 @@ int lobsim_get_level_orders(lobsim_t* h, int32_t env, int32_t side, int64_t pric
 /* Start env from an explicit snapshot row [4 * n_levels] (sell_p, sell_v, buy_p, buy_v per level; pass NULL for an
  * empty book) at time now_us, without a stream. */
 int lobsim_debug_set_book(lobsim_t* h, int32_t env, const int64_t* snapshot_row, int64_t now_us); /* price 0 = absent level */
-/* Process orders [n][6] = {type, side, price, volume (-1 = None), id, is_external} in sequence.  For agent
- * cancellations/deletions `id` is the FIFO rank of the target among the agent's orders at that price (as in
- * lobsim_order_view.id; a rank that does not exist addresses no order).  fills_out [8] (may be
+/*   now_us == -1: the env is a simulator that HAS been reset (lobsim_reset_episode) - its book is replaced by the row, clock, stream and cursor
+ *   stay, the initial price ranges are those of the new book: OrderbookSimulator.reset_episode(start_date, start_book), OrderbookSimulator.py:55-68.
+ *   now_us == -2: nothing but the initial price ranges, worked out again from the book as it is (after lobsim_debug_process_orders added the
+ *   orders a start book holds beyond one per level).  An empty side: LOBSIM_ST_EMPTY_BOOK (the reference's StopIteration, Exchange.py:158-169). */
+/* Process orders [n][6] = {type, side, price, volume (-1 = None), id, who} in sequence.  who = 1: an external order, id = its external id.
+ * who = 0: the agent's own - a limit order with id > 0 is filed under that TAG (lobsim_order_view.reserved; ids must ascend in submission
+ * order, as the reference's internal ids do), id = 0 takes the env's counter; a cancellation / deletion names its target by FIFO RANK among
+ * the agent's orders at that price (as in lobsim_order_view.id; a rank that does not exist addresses no order).  who = 2: the agent's
+ * cancellation / deletion naming its target by TAG - what the reference's Cancellation carries (its internal_id: Exchange.py:196-217); a tag no
+ * live agent order at that side and price holds addresses no order (the reference warns and, if the level's head is a snapshot order, reduces
+ * that: Exchange.py:128-139 - the same here).  fills_out [8] (may be
  * NULL) receives the aggregate fills {agent_fill_count, agent_buy_vol, agent_sell_vol, ext_buy_count,
  * ext_sell_count, ext_buy_vol, ext_sell_vol, cash_delta}. */
 int lobsim_debug_process_orders(lobsim_t* h, int32_t env, const int64_t* orders, int32_t n, int64_t* fills_out);
+/* The memory-safety net of the diagnostic build (liblobsim_bounds.so = -DLOBSIM_BOUNDS -DLOBSIM_REDZONE; the pool this was built on has no GPU
+ * AddressSanitizer): 4 KiB sentinel zones in front of and behind every per-env device array and, for the arrays whose per-env stride is a
+ * run-time value (queue pages, feature rings, normalisation histories), behind every env's part.  *n_zones = zones looked at, *n_damaged = zones
+ * that no longer hold the sentinel (lobsim_last_error names the first).  The product library has no zones: 0 / 0.  The reference is Python: an
+ * index out of range raises there (IndexError / KeyError), it cannot write into a neighbouring object. */
+int lobsim_debug_check_redzones(lobsim_t* h, int32_t* n_zones, int32_t* n_damaged);
 
 /* --- simulator-level entry (rl4mm/simulation/OrderbookSimulator.py:55-88 on its own: no env, no features, no warm-up) -------- */
 /* OrderbookSimulator.reset_episode(start) (:55-68) for n envs: central book <- the last snapshot at or before start_us
@@ -386,7 +404,8 @@ enum lobsim_forward_flags {
  * orders - rows orders[i][0 .. n_orders[i]) of [max_orders][6], the row format of lobsim_debug_process_orders - then the
  * messages of (now, until_us[i]], sets its clock to until_us[i] and, on a whole second and near the edge of its initial price
  * range, runs update_outer_levels (:99-135).  until <= now is the reference's assert (:71-73), an exception that leaves the simulator as it
- * was: the call returns LOBSIM_ERR_ARG, that env is untouched (the other envs of the call have stepped).  Every fill of the call
+ * was: the clocks of all envs of the call are checked first and the call returns LOBSIM_ERR_ARG with NO env stepped (lobsim_last_error lists the
+ * envs; until ABI 5 the other envs of the call had already moved).  Every fill of the call
  * goes to the env's fill log (lobsim_get_fills).  orders / n_orders may be NULL (no internal orders); obs (host, [n][obs_dim])
  * may be NULL. */
 int lobsim_forward(lobsim_t* h, const int32_t* env_ids, int32_t n, const int64_t* until_us, const int64_t* orders,

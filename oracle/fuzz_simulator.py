@@ -46,6 +46,7 @@ def book_rows(book, id_of=None):
 
 def run(seed):
     r = np.random.Generator(np.random.PCG64(77_000 + seed))
+    r2 = np.random.Generator(np.random.PCG64(177_000 + seed))  # (dimensions added later draw from a generator of their own)
     kind = str(r.choice(["syn10", "syn10", "syn5", "drift", "thin", "thinx", "syn50"]))
     db, ps, tick, L, t0, t1 = fr.day(kind)
     outer = int(r.choice([5, 20, 40]))
@@ -77,7 +78,10 @@ def run(seed):
                 vol = None if whole and r.random() < 0.5 else int(v0 if whole else max(1, int(r.integers(1, v0 + 1))))
                 cls_r, cls_m = (RM.Deletion, S.Deletion) if vol is None else (RM.Cancellation, S.Cancellation)
                 kw = dict(timestamp=ts, direction=direction, ticker=tick, external_id=None, is_external=False, price=price, volume=vol)
-                ro.insert(0, cls_r(internal_id=id_r, **kw)); mo.insert(0, cls_m(internal_id=id_m, **kw))
+                # anywhere in the call's list - also BEHIND own limit / market orders of the same call that cross the book or the agent's own
+                # quotes (round 6: the device finds the target by its internal id; until then the mirror refused such calls)
+                at = 0 if r2.random() < 0.4 else int(r2.integers(0, len(ro) + 1))
+                ro.insert(at, cls_r(internal_id=id_r, **kw)); mo.insert(at, cls_m(internal_id=id_m, **kw))
             elif what < 0.85:
                 side = "buy" if r.random() < 0.5 else "sell"
                 ref_p = bb if side == "buy" else bs

@@ -39,6 +39,8 @@ typedef struct {
     int64_t ext_id; /* external_id (unused for agent / snapshot orders) */
     int64_t vol;
     int is_ext;
+    int64_t tag; /* agent orders: the submission tag - the id a caller of oracle_forward gave the order (row id > 0: rl4mm_amd/simulator.py names its
+                    orders by it), else the next value of the env's own counter; lobsim_order_view.reserved */
 } Resting;
 
 typedef struct {
@@ -49,6 +51,7 @@ typedef struct {
     int64_t iid; /* IID_NONE = None */
     int64_t ext_id;
     int is_ext;
+    int64_t tag; /* agent limit orders: the caller's id for it (0: none) */
 } Order;
 
 typedef struct {
@@ -135,6 +138,7 @@ typedef struct {
     Feature feat[LOBSIM_MAX_FEATURES];
     int status;
     int n_resyncs;
+    int64_t agent_seq; /* next submission tag of an agent order that names none (the HIP layout's AgentOrd.seq) */
     double prev_action[LOBSIM_MAX_ACTION_DIM];
     int64_t cash_delta_dbg;
     /* RollingSharpe state (RewardFunctions.py:50-59), [0] per-step instance, [1] terminal instance; never reset */
@@ -378,7 +382,7 @@ static void execute_order(Ctx* c, Order* o) {
         Resting best = bl->q[0];
         int64_t bprice = bl->price;
         if (!o->is_ext && !best.is_ext) { /* cannot fill our own order: delete it (:91-94) */
-            Order d = {LOBSIM_DELETION, opp, bprice, best.vol, best.iid, best.ext_id, 0};
+            Order d = {LOBSIM_DELETION, opp, bprice, best.vol, best.iid, best.ext_id, 0, 0};
             process_order(c, &d);
             if (e->status) return;
             continue;
@@ -404,7 +408,13 @@ static void submit_order(Ctx* c, Order* o) {
     Exchange* ex = &c->env->ex;
     if (crosses(ex, o)) { execute_order(c, o); return; }
     ex->ids.counter += 1; /* OrderIDConvertor.py:12-19 */
-    Resting r = {ex->ids.counter, o->ext_id, o->vol, o->is_ext};
+    Resting r = {ex->ids.counter, o->ext_id, o->vol, o->is_ext, 0};
+    if (!o->is_ext) { /* (the tag is bookkeeping of the test interface, not of the reference: it orders nothing) */
+        Env* en = c->env;
+        const int64_t sq = o->tag > 0 ? o->tag : en->agent_seq;
+        r.tag = sq & 0x7fffffff;
+        en->agent_seq = (sq > en->agent_seq ? sq : en->agent_seq) + 1;
+    }
     if (o->is_ext) idmap_put(&ex->ids, o->ext_id, r.iid);
     Book* books[2] = {&ex->central, &ex->internal};
     int nb = o->is_ext ? 1 : 2;
@@ -484,7 +494,7 @@ static void set_level_to_snapshot(Book* b, int side, int64_t price, int64_t vol)
     Level* l = side_find(&b->s[side], price);
     if (!l) l = side_insert(&b->s[side], price);
     l->n = 0;
-    Resting r = {-1, 0, vol, 1};
+    Resting r = {-1, 0, vol, 1, 0};
     level_append(l, r);
 }
 
@@ -521,7 +531,7 @@ static void update_outer_levels(oracle_t* h, Env* e, Ctx* c) {
             int m = il->n;
             Order* canc = (Order*)malloc(sizeof(Order) * (size_t)m);
             for (int k = 0; k < m; k++) {
-                Order o = {LOBSIM_CANCELLATION, sides[i], prices[i], il->q[k].vol, il->q[k].iid, il->q[k].ext_id, 0};
+                Order o = {LOBSIM_CANCELLATION, sides[i], prices[i], il->q[k].vol, il->q[k].iid, il->q[k].ext_id, 0, 0};  /* (re-added under a fresh tag) */
                 canc[k] = o;
                 if (n_rep == cap_rep) { cap_rep = cap_rep ? 2 * cap_rep : 16; replace = (Order*)realloc(replace, sizeof(Order) * (size_t)cap_rep); }
                 o.type = LOBSIM_LIMIT;
@@ -585,6 +595,7 @@ static void reset_episode(oracle_t* h, Env* e, int64_t start_us, const int64_t* 
     int L = h->cfg.n_levels;
     book_clear(&e->ex.central);
     book_clear(&e->ex.internal);
+    e->agent_seq = 0;
     const int64_t* row = explicit_row;
     if (!row && e->stream_id >= 0) {
         const Stream* st = &h->streams[e->stream_id];
@@ -944,7 +955,7 @@ static void convert_action_to_orders(const oracle_t* h, Env* e, const double* ac
             int64_t price = prices[side][k];
             int64_t diff = desired[side][k] - internal_volume_at(ib, side, price);
             if (diff > 0) {
-                Order o = {LOBSIM_LIMIT, side, price, diff, IID_NONE, 0, 0};
+                Order o = {LOBSIM_LIMIT, side, price, diff, IID_NONE, 0, 0, 0};
                 olist_push(out, o);
             }
             if (diff < 0) { /* cancel from the newest order backwards, :240-249 */
@@ -952,7 +963,7 @@ static void convert_action_to_orders(const oracle_t* h, Env* e, const double* ac
                 int j = l->n - 1;
                 while (diff < 0) {
                     int64_t v = l->q[j].vol < -diff ? l->q[j].vol : -diff;
-                    Order o = {LOBSIM_CANCELLATION, side, price, v, l->q[j].iid, 0, 0};
+                    Order o = {LOBSIM_CANCELLATION, side, price, v, l->q[j].iid, 0, 0, 0};
                     olist_push(out, o);
                     diff += v;
                     j--;
@@ -966,14 +977,14 @@ static void convert_action_to_orders(const oracle_t* h, Env* e, const double* ac
             for (int k = 0; k < Q; k++) if (prices[side][k] == l->price) quoted = 1;
             if (quoted) continue;
             for (int j = 0; j < l->n; j++) {
-                Order o = {LOBSIM_CANCELLATION, side, l->price, l->q[j].vol, l->q[j].iid, 0, 0};
+                Order o = {LOBSIM_CANCELLATION, side, l->price, l->q[j].vol, l->q[j].iid, 0, 0, 0};
                 olist_push(out, o);
             }
         }
     }
     if (clearing) { /* _get_inventory_clearing_market_order, :260-266 */
         double v = rint((double)abs_inv * cfg->market_order_fraction_of_inventory);
-        Order o = {LOBSIM_MARKET, e->inventory < 0 ? LOBSIM_BUY : LOBSIM_SELL, 0, (int64_t)v, IID_NONE, 0, 0};
+        Order o = {LOBSIM_MARKET, e->inventory < 0 ? LOBSIM_BUY : LOBSIM_SELL, 0, (int64_t)v, IID_NONE, 0, 0, 0};
         olist_push(out, o);
     }
 }
@@ -1327,7 +1338,7 @@ int oracle_get_level_orders(oracle_t* h, int32_t env, int32_t side, int64_t pric
             out[n].volume = l->q[i].vol; out[n].reserved = 0;
             if (l->q[i].iid == -1) { out[n].kind = 2; out[n].id = -1; }
             else if (l->q[i].is_ext) { out[n].kind = 0; out[n].id = l->q[i].ext_id; }
-            else { out[n].kind = 1; out[n].id = agent_rank++; }
+            else { out[n].kind = 1; out[n].id = agent_rank++; out[n].reserved = (int32_t)l->q[i].tag; }
             n++;
         }
     }
@@ -1338,6 +1349,23 @@ int oracle_get_level_orders(oracle_t* h, int32_t env, int32_t side, int64_t pric
 int oracle_debug_set_book(oracle_t* h, int32_t env, const int64_t* snapshot_row, int64_t now_us) {
     if (env < 0 || env >= h->cfg.n_envs) return LOBSIM_ERR_ARG;
     Env* e = &h->env[env];
+    if (now_us < 0) { /* -1: replace the book of a simulator that has been reset (reset_episode(start_date, start_book), :55-68); -2: only the
+                         initial price ranges again, from the book as it is (include/lobsim.h) */
+        e->n_resyncs = 0;
+        e->min_buy_price = INFINITY; e->max_sell_price = 0; e->initial_buy_range = INFINITY; e->initial_sell_range = INFINITY;
+        if (now_us == -1) {
+            const int sid = e->stream_id;
+            const int64_t now = e->now_us;
+            e->stream_id = -1;  /* (reset_episode: the explicit row, not the stream's snapshot) */
+            if (snapshot_row) reset_episode(h, e, now, snapshot_row);
+            else { book_clear(&e->ex.central); book_clear(&e->ex.internal); e->agent_seq = 0; reset_price_ranges(e); }
+            e->stream_id = sid;
+        } else reset_price_ranges(e);
+        e->price = 0.0;
+        if (!e->status && !book_microprice(&e->ex.central, &e->price)) e->price = 0.0;
+        e->fin.n = e->fex.n = 0;
+        return LOBSIM_OK;
+    }
     e->status = 0; e->stream_id = -1; e->n_resyncs = 0;
     e->min_buy_price = INFINITY; e->max_sell_price = 0; e->initial_buy_range = INFINITY; e->initial_sell_range = INFINITY;
     reset_episode(h, e, now_us, snapshot_row);
@@ -1345,6 +1373,26 @@ int oracle_debug_set_book(oracle_t* h, int32_t env, const int64_t* snapshot_row,
     e->terminal_us = INT64_MAX / 4;
     e->fin.n = e->fex.n = 0;
     return LOBSIM_OK;
+}
+
+/* One order row {type, side, price, volume (-1 none), id, who} of oracle_debug_process_orders / oracle_forward (include/lobsim.h).
+ * who = 1: an external order, id = its external id.  who = 0: the agent's; a limit order's id > 0 is the tag the caller names it by, a
+ * cancellation / deletion addresses its target by FIFO rank among the agent's orders at that price (see get_level_orders).  who = 2: the
+ * agent's cancellation / deletion naming its target by TAG - the internal id of rl4mm_amd/simulator.py's orders: what the reference's
+ * Cancellation carries (Exchange.py:196-217 looks the internal id up in the level's deque). */
+static Order row_order(Env* e, const int64_t* r) {
+    const int who = (int)r[5];
+    Order o = {(int)r[0], (int)r[1], r[2], r[3], IID_NONE, r[4], who == 1, 0};
+    if (who == 1) return o;
+    o.ext_id = 0;
+    if (o.type == LOBSIM_LIMIT) { o.tag = r[4] > 0 ? r[4] : 0; return o; }
+    if (o.type == LOBSIM_CANCELLATION || o.type == LOBSIM_DELETION) {
+        Level* l = side_find(&e->ex.internal.s[o.side], o.price);
+        o.iid = INT64_MAX / 2; /* (addresses no order) */
+        if (l && who == 0 && r[4] >= 0 && r[4] < l->n) o.iid = l->q[r[4]].iid;
+        if (l && who == 2) for (int k = 0; k < l->n; k++) if (l->q[k].tag == r[4]) { o.iid = l->q[k].iid; break; }
+    }
+    return o;
 }
 
 int oracle_debug_process_orders(oracle_t* h, int32_t env, const int64_t* orders, int32_t n, int64_t* fills_out) {
@@ -1355,12 +1403,7 @@ int oracle_debug_process_orders(oracle_t* h, int32_t env, const int64_t* orders,
     int64_t cash0 = e->cash;
     for (int i = 0; i < n && !e->status; i++) {
         const int64_t* r = orders + 6 * (size_t)i;
-        Order o = {(int)r[0], (int)r[1], r[2], r[3], IID_NONE, r[4], (int)r[5]};
-        if (!o.is_ext && (o.type == LOBSIM_CANCELLATION || o.type == LOBSIM_DELETION)) {
-            /* agent orders are addressed by their FIFO rank within the internal book level (see get_level_orders) */
-            Level* l = side_find(&e->ex.internal.s[o.side], o.price);
-            if (l && r[4] >= 0 && r[4] < l->n) o.iid = l->q[r[4]].iid; else o.iid = INT64_MAX / 2;
-        }
+        Order o = row_order(e, r);
         process_order(&c, &o);
     }
     update_portfolio(e);
@@ -1467,11 +1510,7 @@ int oracle_forward(oracle_t* h, const int32_t* env_ids, int32_t n, const int64_t
         e->fin.n = e->fex.n = 0;
         for (int k = 0; k < ni && !e->status; k++) {
             const int64_t* r = orders + ((size_t)i * max_orders + k) * 6;
-            Order o = {(int)r[0], (int)r[1], r[2], r[3], IID_NONE, r[4], (int)r[5]};
-            if (!o.is_ext && (o.type == LOBSIM_CANCELLATION || o.type == LOBSIM_DELETION)) {
-                Level* l = side_find(&e->ex.internal.s[o.side], o.price);
-                if (l && r[4] >= 0 && r[4] < l->n) o.iid = l->q[r[4]].iid; else o.iid = INT64_MAX / 2;
-            }
+            Order o = row_order(e, r);
             process_order(&c, &o);
         }
         if (!e->status) forward_step_keep_fills(h, e, until_us[i]);

@@ -14,12 +14,13 @@ import numpy as np
 
 MAX_FEATURES = 16
 MAX_ACTION_DIM = 5
-ABI_VERSION = 5  # LOBSIM_ABI_VERSION of the include/lobsim.h this file mirrors
+ABI_VERSION = 6  # LOBSIM_ABI_VERSION of the include/lobsim.h this file mirrors
 FWD_UPDATE_FEATURES = 1  # enum lobsim_forward_flags
 
 # status bits (include/lobsim.h: enum lobsim_status)
 ST_EMPTY_BOOK, ST_BAD_MESSAGE, ST_LEVEL_OVERFLOW, ST_QUEUE_OVERFLOW = 1, 2, 4, 8
 ST_AGENT_OVERFLOW, ST_STREAM_END, ST_ASSERT, ST_NOT_RESET = 16, 32, 64, 128
+ST_INTERNAL = 256  # (the diagnostic build only: bits 16 - 30 = the line of lobsim_kernels.hip whose bounds check failed)
 
 F_SPREAD, F_PRICE_MOVE, F_VOLATILITY, F_INVENTORY, F_EPISODE_PROPORTION, F_TIME_OF_DAY = 1, 2, 3, 4, 5, 6
 F_TRADE_DIRECTION_IMBALANCE, F_TRADE_VOLUME_IMBALANCE, F_BOOK_IMBALANCE, F_PRICE_RANGE, F_PRICE, F_AMIHUD_LAMBDA = 7, 8, 9, 10, 11, 12
@@ -171,10 +172,11 @@ PROTOTYPES = {
     "features_reset": (C.c_int, [C.c_void_p, _P32, C.c_int32]),
     "debug_set_book": (C.c_int, [C.c_void_p, C.c_int32, _P64, C.c_int64]),
     "debug_process_orders": (C.c_int, [C.c_void_p, C.c_int32, _P64, C.c_int32, _P64]),
+    "debug_check_redzones": (C.c_int, [C.c_void_p, _P32, _P32]),
 }
 # the oracle has no device entry points
 ORACLE_SKIP = {"drop_stream", "set_stream", "step_device", "sync", "rollout_device", "set_info_buffer", "set_trace_buffer", "host_io_buffers", "step_host_io",
-               "step_device_skip", "reset_device"}
+               "step_device_skip", "reset_device", "debug_check_redzones"}
 
 
 def _ptr(a: Optional[np.ndarray], typ):
@@ -374,6 +376,12 @@ class Sim:
         lim = Limits()
         self._check(self.b.fn["get_limits"](self.h, C.byref(lim)), "get_limits")
         return lim.as_dict()
+
+    def check_redzones(self):
+        """(zones looked at, zones damaged) - 0 / 0 on the product library, which has none (lobsim_debug_check_redzones)."""
+        n, bad = C.c_int32(0), C.c_int32(0)
+        self._check(self.b.fn["debug_check_redzones"](self.h, C.byref(n), C.byref(bad)), "debug_check_redzones")
+        return int(n.value), int(bad.value)
 
     def status(self) -> np.ndarray:
         out = np.zeros(self.n_envs, dtype=np.int32)

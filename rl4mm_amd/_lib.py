@@ -86,6 +86,41 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     return LIB_PATH
 
 
+BOUNDS_LIB_PATH = CSRC / "liblobsim_bounds.so"
+BOUNDS_FLAGS = ["-DLOBSIM_BOUNDS", "-DLOBSIM_REDZONE"]
+
+
+def build_bounds_library(force: bool = False) -> Path:
+    """The diagnostic build of the same sources: every computed index held against its array (LOBSIM_ST_INTERNAL + the line of the check),
+    sentinel zones around the per-env arrays (lobsim_debug_check_redzones).  GPU AddressSanitizer is not available on the pool this was
+    developed on; this is what stands in for it.  In-tree like the product library (it travels with the repo snapshot); only the tests
+    and the fuzzers load it - explicitly, by path."""
+    if not force and BOUNDS_LIB_PATH.exists() and all((not s.exists()) or s.stat().st_mtime <= BOUNDS_LIB_PATH.stat().st_mtime for s in SOURCES):
+        return BOUNDS_LIB_PATH
+    import fcntl
+    import tempfile
+
+    with open(CSRC / ".build.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            fd, tmp = tempfile.mkstemp(suffix=".so", dir=str(CSRC))
+            os.close(fd)
+            try:
+                compile_library(Path(tmp), BOUNDS_FLAGS)
+                os.replace(tmp, BOUNDS_LIB_PATH)
+            finally:
+                if os.path.exists(tmp):
+                    os.unlink(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return BOUNDS_LIB_PATH
+
+
+def bounds_binding() -> _capi.Binding:
+    _one_hip_runtime()
+    return _capi.Binding(build_bounds_library(), prefix="lobsim_")
+
+
 def _one_hip_runtime():
     """PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so (SONAME libamdhip64.so.7, the one liblobsim.so
     names).  With torch imported FIRST the loader resolves liblobsim's dependency to that copy: one HIP runtime in the process.

@@ -97,10 +97,41 @@ namespace lobk {
 #ifndef LOBSIM_FAR_EVICT
 #define LOBSIM_FAR_EVICT 1  // (ditto: eviction / refill / slabs beyond the first mask)
 #endif
+#ifndef LOBSIM_LPT
+#define LOBSIM_LPT 1  // 0 (diagnostic builds only): no sorter waves in the step kernel (lpt_sort_body)
+#endif
 #ifndef LOBSIM_TOMB
 #define LOBSIM_TOMB 128  // tombstones a level may hold before its slab is squeezed.  Measured 8 .. 384: with queue scans
                          // on every cancellation the optimum was 16-32; now that the position cache answers most of them, 128
 #endif
+// Diagnostic build -DLOBSIM_BOUNDS (rl4mm_amd/_lib.py: build_bounds_library -> liblobsim_bounds.so; GPU AddressSanitizer is not to be had
+// on this pool): every computed index into an env's arrays - queue slots by (slab, slot), the agent entries that stay in HBM, the buddy
+// pool's mask words, feature rings, normalisation histories, Sharpe windows, the on-chip agent table and op list - is held against its
+// extent.  A violation does not trap: the access goes to element 0 of the same array and the env's status gets LOBSIM_ST_INTERNAL with the
+// SOURCE LINE of the check in bits 16 - 31 (the first one of the launch wins), so that the class of bug that commit 1956fb9 found after
+// 15 846 fuzz cases - a read one word past an array, visible only with the preceding cases' allocation history - is caught where it
+// happens.  The violation mark lives in LDS (any lane of a diverged wave may set it; the wave-uniform status word is folded at the end
+// of the kernel body).  The product library is built without it: BIDX(i, n) is `i`.
+#ifdef LOBSIM_BOUNDS
+static __shared__ uint32_t g_bviol;  // line of the first violated check of this launch (0: none)
+static __shared__ int32_t g_bpages;  // 1 KiB pages of this env's slab pool
+static __shared__ int32_t g_bring[LOBSIM_MAX_FEATURES];  // 8-byte words of each feature's ring
+#define RIDX(i) lobk::bidx(__LINE__, (i), (long long)lobk::g_bring[threadIdx.x < LOBSIM_MAX_FEATURES ? threadIdx.x : 0])
+#define RING_WORDS(f) lobk::g_bring[f]
+__device__ __forceinline__ void bfail(int line) { if (g_bviol == 0) g_bviol = (uint32_t)line; }
+template <typename I> __device__ __forceinline__ I bidx(int line, I i, long long n) {
+    if ((long long)i < 0 || (long long)i >= n) { bfail(line); return (I)0; }
+    return i;
+}
+#define BIDX(i, n) lobk::bidx(__LINE__, (i), (long long)(n))
+#define BCHECK(cond) do { if (!(cond)) lobk::bfail(__LINE__); } while (0)
+#else
+#define BIDX(i, n) (i)
+#define RIDX(i) (i)
+#define RING_WORDS(f) 0
+#define BCHECK(cond) do { } while (0)
+#endif
+
 struct Op8 {  // one agent order waiting to be processed (built from the pre-step state, then replayed)
     int32_t vol;
     int32_t code;  // type (bits 0-3) | side << 4 | from_agent << 5 | idx << 8; idx = quote level (limit) or agent index
@@ -121,6 +152,11 @@ struct StepArgs {
     int32_t* steps_taken;   // or null: 1 per env that stepped, 0 for an env that was already done
     double* info;           // or null: [n_envs][LOBSIM_INFO_DIM] info arrays (lobsim_set_info_buffer)
     const int32_t* order;   // or null: workgroup b steps env order[b] (longest job first across a launch that does not fit the chip at once)
+    // longest job first INSIDE a launch (round 6, lpt_sort_body): when order_next is set the first LPT_CLASSES workgroups of the launch are
+    // sorter waves - they rank the envs by the weight of the window each will replay in the NEXT launch and write that launch's order -
+    // and workgroup LPT_CLASSES + b steps env order[b]
+    int32_t* order_next;
+    int32_t n_envs;
 };
 
 struct ResetArgs {
@@ -256,13 +292,33 @@ SDI int m_live(uint64_t m) { return (int)(m >> 48); }
 #define LOBSIM_FLAT_SLABS 0  // 1 (diagnostic builds only): round 4's layout - every level owns a fixed 16 KiB slab - under round 5's code, to tell what the layout costs from what the code costs
 #endif
 #if LOBSIM_FLAT_SLABS
-SDI int slab_cap(int slab) { return SLOTS; }
-SDI int m_cap(uint64_t m) { return SLOTS; }
-template <typename T> SDI T* slab_ptr(T* slots, int slab) { return slots + (size_t)slab * SLOTS; }
+SDI int slab_cap(int slab) { return FLAT_SLOTS; }
+SDI int m_cap(uint64_t m) { return FLAT_SLOTS; }
+template <typename T> SDI T* slab_ptr(T* slots, int slab) { return slots + (size_t)slab * FLAT_SLOTS; }
 #else
-SDI int slab_cap(int slab) { return PAGE_SLOTS << (2 * (slab >> SLAB_CLASS_SHIFT)); }  // 64 / 256 / 1024 slots
+SDI int slab_cap(int slab) { return PAGE_SLOTS << (2 * (slab >> SLAB_CLASS_SHIFT)); }  // 64 / 256 / 1024 / 4096 slots
 SDI int m_cap(uint64_t m) { return slab_cap(m_slab(m)); }
 template <typename T> SDI T* slab_ptr(T* slots, int slab) { return slots + (size_t)(slab & SLAB_PAGE_MASK) * PAGE_SLOTS; }
+#endif
+// SLAB_PTR(slots, slab)[i]: slot i of a slab.  The product build: a plain pointer.  -DLOBSIM_BOUNDS: the slab id is held against the env's
+// pool (class, alignment of its first page inside the buddy pool, last page) and every index against the slab's capacity.
+#ifdef LOBSIM_BOUNDS
+template <typename T>
+struct SlabRef {
+    T* p; int cap, line;
+    DI T& operator[](int i) const { return p[lobk::bidx(line, i, cap)]; }
+};
+template <typename T> SDI SlabRef<T> slab_ref(int line, T* slots, int slab) {
+    static_assert(!LOBSIM_FLAT_SLABS, "the bounds build checks the paged layout");
+    const int cls = slab >> SLAB_CLASS_SHIFT, page = slab & SLAB_PAGE_MASK, np = 1 << (2 * cls);
+    const bool ok = slab >= 0 && slab < 0xffff && cls <= SLAB_CLASS_MAX && page + np <= g_bpages && (cls == 0 || (page >= NSLAB && ((page - NSLAB) & (np - 1)) == 0));
+    if (!ok) { lobk::bfail(line); slab = 0; }
+    SlabRef<T> r = {slab_ptr(slots, slab), slab_cap(slab), line};
+    return r;
+}
+#define SLAB_PTR(slots, slab) slab_ref(__LINE__, (slots), (slab))
+#else
+#define SLAB_PTR(slots, slab) slab_ptr((slots), (slab))
 #endif
 
 // wave-uniform scalars of the env being advanced (kept in registers)
@@ -322,6 +378,37 @@ SDI void wsync() {
 }
 
 SDI int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+// -DLOBSIM_BOUNDS: the violation mark is cleared at the top of every kernel body (with the extents the checks need) and folded into the
+// env's status word where the body writes it (store_env); nothing in a product build
+SDI void bounds_begin(const DevCfg& C, const DevPtrs& P) {
+#ifdef LOBSIM_BOUNDS
+    const int f = lane(), F = C.c.n_features;
+    if (f == 0) { g_bviol = 0; g_bpages = NSLAB + 16 * P.n_big; }
+    if (f < LOBSIM_MAX_FEATURES) {  // (a feature without a ring reads "its" word 0 and drops it: feature_raw)
+        const int w = f < F ? (f + 1 < F ? C.ring_off[f + 1] : C.ring_words) - C.ring_off[f] : 0;
+        g_bring[f] = w > 1 ? w : 1;
+    }
+    wsync();
+#endif
+}
+// (bounds build) a violation redirected an access: the state the wave works on may no longer be consistent - a sweep that finds no volume where the
+// level's count says there is some would turn for ever - so the loops that depend on such consistency poll the mark and stop the env
+template <typename SC> SDI void bounds_poll(SC& S) {
+#ifdef LOBSIM_BOUNDS
+    if (uni((int32_t)g_bviol)) S.status |= LOBSIM_ST_INTERNAL;
+#else
+    (void)S;
+#endif
+}
+SDI int bounds_status() {
+#ifdef LOBSIM_BOUNDS
+    wsync();
+    const uint32_t v = (uint32_t)uni((int32_t)g_bviol);
+    return v ? (int)(LOBSIM_ST_INTERNAL | ((v & 0x7fffu) << 16)) : 0;
+#else
+    return 0;
+#endif
+}
 SDI int32_t rl32(int32_t v, int src) { return __builtin_amdgcn_readlane(v, src); }
 SDI int64_t rl64(int64_t v, int src) {
     int32_t lo = __builtin_amdgcn_readlane((int32_t)(v & 0xffffffffll), src);
@@ -383,32 +470,32 @@ SDI AgentOrd* agent_hi(Slot* slots) { return reinterpret_cast<AgentOrd*>(reinter
 SDI uint16_t* apos_hi(Slot* slots) { return reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(slots) - HI_BYTES - AGHI_BYTES + (NA_MAX - NAL) * sizeof(AgentOrd)); }
 SDI bool ag_is_hi(int idx) { return NA > NAL && UNLIKELY(idx >= NAL); }
 SDI AgentOrd ag_get(const Lds& L, const Scal& S, int idx) {
-    if (ag_is_hi(idx)) return agent_hi(S.slots)[idx - NAL];
-    return L.agent[idx];
+    if (ag_is_hi(idx)) return agent_hi(S.slots)[BIDX(idx - NAL, NA - NAL)];
+    return L.agent[BIDX(idx, NAL)];
 }
 SDI int32_t ag_vol(const Lds& L, const Scal& S, int idx) {
-    if (ag_is_hi(idx)) return agent_hi(S.slots)[idx - NAL].vol;
-    return L.agent[idx].vol;
+    if (ag_is_hi(idx)) return agent_hi(S.slots)[BIDX(idx - NAL, NA - NAL)].vol;
+    return L.agent[BIDX(idx, NAL)].vol;
 }
 SDI int64_t ag_price(const Lds& L, const Scal& S, int idx) {
-    if (ag_is_hi(idx)) return agent_hi(S.slots)[idx - NAL].price;
-    return L.agent[idx].price;
+    if (ag_is_hi(idx)) return agent_hi(S.slots)[BIDX(idx - NAL, NA - NAL)].price;
+    return L.agent[BIDX(idx, NAL)].price;
 }
 SDI void ag_put(Lds& L, const Scal& S, int idx, const AgentOrd& o) {
-    if (ag_is_hi(idx)) agent_hi(S.slots)[idx - NAL] = o;
-    else L.agent[idx] = o;
+    if (ag_is_hi(idx)) agent_hi(S.slots)[BIDX(idx - NAL, NA - NAL)] = o;
+    else L.agent[BIDX(idx, NAL)] = o;
 }
 SDI void ag_set_vol(Lds& L, const Scal& S, int idx, int32_t v) {
-    if (ag_is_hi(idx)) agent_hi(S.slots)[idx - NAL].vol = v;
-    else L.agent[idx].vol = v;
+    if (ag_is_hi(idx)) agent_hi(S.slots)[BIDX(idx - NAL, NA - NAL)].vol = v;
+    else L.agent[BIDX(idx, NAL)].vol = v;
 }
 SDI int ap_get(const Lds& L, const Scal& S, int idx) {
-    if (ag_is_hi(idx)) return (int)apos_hi(S.slots)[idx - NAL];
-    return (int)L.apos[idx];
+    if (ag_is_hi(idx)) return (int)apos_hi(S.slots)[BIDX(idx - NAL, NA - NAL)];
+    return (int)L.apos[BIDX(idx, NAL)];
 }
 SDI void ap_put(Lds& L, const Scal& S, int idx, int pos) {
-    if (ag_is_hi(idx)) apos_hi(S.slots)[idx - NAL] = (uint16_t)pos;
-    else L.apos[idx] = (uint16_t)pos;
+    if (ag_is_hi(idx)) apos_hi(S.slots)[BIDX(idx - NAL, NA - NAL)] = (uint16_t)pos;
+    else L.apos[BIDX(idx, NAL)] = (uint16_t)pos;
 }
 // does the half of the table that stays in HBM hold anything?  (bits of its free-mask words: set = free; an entry freed in this
 // step keeps its bit clear until the step ends: conservative)
@@ -518,6 +605,7 @@ SDI void far_st(FarLevel* e, int64_t price, uint64_t meta, int64_t vol) {
 // same pages.  -1: nothing left.
 SDI int buddy_take(uint64_t* w, int w0, int nw) {  // the first set bit of the mask words [w0, w0 + nw); -1: none
     const int ln = lane();
+    BCHECK(w0 >= 0 && w0 + nw <= (int)(HI_BYTES / 8));
     const uint64_t v = ln < nw ? w[w0 + ln] : 0;
     const uint64_t b = ballot(v != 0);
     if (!b) return -1;
@@ -528,52 +616,28 @@ SDI int buddy_take(uint64_t* w, int w0, int nw) {  // the first set bit of the m
     return wl * 64 + bit;
 }
 SDI void buddy_put3(uint64_t* w, int w0, int b) {  // blocks b + 1 .. b + 3 (b a multiple of 4) become free
-    if (lane() == 0) w[w0 + (b >> 6)] |= 0xEull << (b & 63);
+    if (lane() == 0) w[BIDX(w0 + (b >> 6), HI_BYTES / 8)] |= 0xEull << (b & 63);
     wsync();
 }
-constexpr int hi_w0(int cls) { return cls == 0 ? HI_W0 : cls == 1 ? HI_W1 : HI_W2; }
-constexpr int hi_nw(int cls) { return cls == 0 ? 64 : cls == 1 ? NMID_MAX / 64 : NBIG_MAX / 64; }
+SDI int hi_w0(int cls) { return cls == 0 ? HI_W0 : cls == 1 ? HI_W1 : cls == 2 ? HI_W2 : HI_W3; }
+SDI int hi_nw(int cls) { return cls == 0 ? 64 : cls == 1 ? NMID_MAX / 64 : cls == 2 ? NBIG_MAX / 64 : NHUGE_MAX / 64; }
+// a free slab of class `cls`: a block of that size, or the first free block of a larger size split down to it (three quarters of every
+// split go to the next smaller size's mask).  -1: no block of this size or larger is free.
 SDI int slab_alloc_cls(Slot* slots, int cls) {
     uint64_t* w = hi_free_words(slots);
     cls = uni(cls);
-    int b = -1;
 #if LOBSIM_FLAT_SLABS
-    b = buddy_take(w, HI_W0, 64);
-    return b < 0 ? -1 : NSLAB + b;
+    { const int f = buddy_take(w, HI_W0, 64); return f < 0 ? -1 : NSLAB + f; }
 #endif
-    if (cls == 0) {
-        b = buddy_take(w, HI_W0, 64);
-        if (b < 0) {
-            int p = buddy_take(w, HI_W1, NMID_MAX / 64);
-            if (p < 0) {
-                const int g = buddy_take(w, HI_W2, NBIG_MAX / 64);
-                if (g < 0) return -1;
-                p = 4 * g; buddy_put3(w, HI_W1, p);
-            }
-            b = 4 * p; buddy_put3(w, HI_W0, b);
-        }
-        return NSLAB + b;
-    }
-    if (cls == 1) {
-        b = buddy_take(w, HI_W1, NMID_MAX / 64);
-        if (b < 0) {
-            const int g = buddy_take(w, HI_W2, NBIG_MAX / 64);
-            if (g < 0) return -1;
-            b = 4 * g; buddy_put3(w, HI_W1, b);
-        }
-        return (1 << SLAB_CLASS_SHIFT) | (NSLAB + 4 * b);
-    }
-    b = buddy_take(w, HI_W2, NBIG_MAX / 64);
-    return b < 0 ? -1 : (2 << SLAB_CLASS_SHIFT) | (NSLAB + 16 * b);
+    int c = cls, b = -1;
+    for (; c <= SLAB_CLASS_MAX; c++) { b = buddy_take(w, hi_w0(c), hi_nw(c)); if (b >= 0) break; }
+    if (b < 0) return -1;
+    for (; c > cls; c--) { b *= 4; buddy_put3(w, hi_w0(c - 1), b); }
+    return (cls << SLAB_CLASS_SHIFT) | (NSLAB + (b << (2 * cls)));
 }
 SDI int slab_alloc_hi(Slot* slots) { return slab_alloc_cls(slots, 0); }
-// the smallest free slab of a class above `cls` (a level that has outgrown its slab); -1: none
-SDI int slab_alloc_larger(Slot* slots, int cls) {
-    int s = -1;
-    if (cls < 1) s = slab_alloc_cls(slots, 1);
-    if (s < 0) s = slab_alloc_cls(slots, 2);
-    return s;
-}
+// the next size up for a level that has outgrown its slab (allocation splits larger blocks, so when this fails nothing larger is free either); -1: none
+SDI int slab_alloc_larger(Slot* slots, int cls) { return cls < SLAB_CLASS_MAX ? slab_alloc_cls(slots, cls + 1) : -1; }
 SDI void slab_release(Lds& L, Slot* slots, int slab) {  // (inside the cold routines)
     if (slab < NSLAB) { mask_set(L.slab_free, slab); return; }
     uint64_t* w = hi_free_words(slots);
@@ -584,10 +648,11 @@ SDI void slab_release(Lds& L, Slot* slots, int slab) {  // (inside the cold rout
 #endif
     int cls = uni(slab >> SLAB_CLASS_SHIFT);
     int b = ((slab & SLAB_PAGE_MASK) - NSLAB) >> (2 * cls);
+    BCHECK(cls <= SLAB_CLASS_MAX && (slab & SLAB_PAGE_MASK) >= NSLAB && b >= 0 && b < 64 * hi_nw(cls));
     for (;;) {  // free block b of size class cls; four free siblings merge into their parent
-        const int wi = (cls == 0 ? HI_W0 : cls == 1 ? HI_W1 : HI_W2) + (b >> 6), sh = b & 60;  // (a group of four never straddles a word)
+        const int wi = BIDX(hi_w0(cls) + (b >> 6), HI_BYTES / 8), sh = b & 60;  // (a group of four never straddles a word)
         const uint64_t v = (uint64_t)uni64((int64_t)w[wi]) | (1ull << (b & 63));
-        const bool merge = cls < 2 && ((v >> sh) & 0xF) == 0xF;
+        const bool merge = cls < SLAB_CLASS_MAX && ((v >> sh) & 0xF) == 0xF;
         if (lane() == 0) w[wi] = merge ? v & ~(0xFull << sh) : v;
         wsync();
         if (!merge) break;
@@ -864,7 +929,7 @@ SDI Slot slot_load(const Slot* p) {
         return s;
     } else return *p;
 }
-SDI Slot load_slot(const Slot* sl, int i, int head, int tail) {
+template <typename SL> SDI Slot load_slot(const SL& sl, int i, int head, int tail) {
     if (i >= head && i < tail) return sl[i];
     return dead_slot();
 }
@@ -905,8 +970,8 @@ SDI uint64_t compact_level(Lds& L, Scal& S, int side, int idx, uint64_t m, int d
     EVENT(ev_compact);
     int slab = m_slab(m), head = m_head(m), tail = m_tail(m);
     if (dst < 0) dst = slab;  // in place; else: into another (larger) slab, the level moves
-    Slot* sl = slab_ptr(S.slots, slab);
-    Slot* dl = slab_ptr(S.slots, dst);
+    const auto sl = SLAB_PTR(S.slots, slab);
+    const auto dl = SLAB_PTR(S.slots, dst);
     uint64_t below = (1ull << ln) - 1;
     int out = 0;
 #ifndef LOBSIM_COMPACT_WIDTH
@@ -948,11 +1013,16 @@ SDI uint64_t compact_level(Lds& L, Scal& S, int side, int idx, uint64_t m, int d
 #define LOBSIM_ROOM 24
 #endif
 SDI bool nearly_full(uint64_t m) { return m_tail(m) + LOBSIM_ROOM > m_cap(m); }
+// has the level outgrown its slab?  (a one-page level that is nearly full; a larger one of which three quarters are live orders)
+SDI bool wants_larger(uint64_t m) {
+    const int cls = m_slab(m) >> SLAB_CLASS_SHIFT, cap = m_cap(m);
+    return cls < SLAB_CLASS_MAX && (cls == 0 ? m_tail(m) + LOBSIM_ROOM > cap : m_live(m) * 4 > cap * 3);
+}
 SDI uint64_t make_room(Lds& L, Scal& S, int side, int idx, uint64_t m) {
-    const int slab = m_slab(m), cap = slab_cap(slab), cls = slab >> SLAB_CLASS_SHIFT;
+    const int slab = m_slab(m), cls = slab >> SLAB_CLASS_SHIFT;
     int dst = -1;
-    const bool grow = cls == 0 ? m_tail(m) + LOBSIM_ROOM > cap : m_live(m) * 4 > cap * 3;
-    if (UNLIKELY(!LOBSIM_FLAT_SLABS && cls < 2 && grow)) dst = slab_alloc_larger(S.slots, cls);
+    if (UNLIKELY(!LOBSIM_FLAT_SLABS && wants_larger(m))) dst = slab_alloc_larger(S.slots, cls);
+    if (UNLIKELY(dst < 0 && m_tail(m) - m_head(m) == m_live(m))) return m;  // no larger slab to be had and no tombstone to squeeze out: nothing to move (an exhausted pool)
     const uint64_t nm = compact_level(L, S, side, idx, m, dst);
     if (UNLIKELY(dst >= 0)) slab_release(L, S.slots, slab);
     return nm;
@@ -962,7 +1032,9 @@ SDI void level_append(Lds& L, Scal& S, int side, int idx, int64_t id, int32_t vo
     {
         const int tombs = m_tail(m) - m_head(m) - m_live(m);
         // two chunks' worth of tombstones, or (nearly) full with something to gain: tombstones to squeeze out, or a larger slab to move to
-        if (tombs >= LOBSIM_TOMB || (nearly_full(m) && (tombs > 0 || m_cap(m) < SLOTS))) {
+        // (a nearly full slab without tombstones that has NOT outgrown its size - a 256-slot level with fewer than 192 live orders cannot be
+        // nearly full without tombstones, but a level whose move found the pool exhausted can - is left alone: squeezing it moves nothing)
+        if (tombs >= LOBSIM_TOMB || (nearly_full(m) && (tombs > 0 || wants_larger(m)))) {
             m = make_room(L, S, side, idx, m);
             if (m_tail(m) == m_cap(m)) { S.status |= LOBSIM_ST_QUEUE_OVERFLOW; return; }
         } else if (m_tail(m) == m_cap(m)) { S.status |= LOBSIM_ST_QUEUE_OVERFLOW; return; }
@@ -970,7 +1042,7 @@ SDI void level_append(Lds& L, Scal& S, int side, int idx, int64_t id, int32_t vo
     int tail = m_tail(m), live = m_live(m);
     if (lane() == 0) {
         Slot s; s.id = id; s.vol = vol; s.kind = kind;
-        slab_ptr(S.slots, m_slab(m))[tail] = s;
+        SLAB_PTR(S.slots, m_slab(m))[tail] = s;
         if (kind == K_AGENT) ap_put(L, S, (int)id, tail);
         if (kind == K_EXT) idc_put(S, id, m_slab(m), tail);
         L.meta[side][idx] = mk_meta(m_slab(m), live == 0 ? tail : m_head(m), tail + 1, live + 1);
@@ -1026,7 +1098,7 @@ SDI int alloc_agent(Lds& L, Scal& S) {
 SDI void reduce_slot(Lds& L, Scal& S, int side, int idx, uint64_t m, int pos, int32_t rv, int32_t pv, int32_t pk, int64_t pid) {
     int ln = lane();
     int head = m_head(m), tail = m_tail(m);
-    Slot* sl = slab_ptr(S.slots, m_slab(m));
+    const auto sl = SLAB_PTR(S.slots, m_slab(m));
     int32_t nv = pv - rv;
     bool gone = nv == 0;
     if (ln == 0) {
@@ -1057,7 +1129,7 @@ SDI void remove_order(Lds& L, Scal& S, int side, int64_t price, int32_t kind, in
     }
     int ln = lane();
     int head = m_head(m), tail = m_tail(m);
-    const Slot* sl = slab_ptr(S.slots, m_slab(m));
+    const auto sl = SLAB_PTR(S.slots, m_slab(m));
     int pos = -1;
     int32_t pv = 0;
 #ifdef LOBSIM_PROFILE
@@ -1200,6 +1272,8 @@ SDI int32_t execute(Lds& L, Scal& S, int side, bool is_agent, bool is_market, in
     const int32_t total = rem;
     const int32_t* cuts = &L.cur[0][0];
     while (rem > 0) {
+        bounds_poll(S);
+        if (S.status & LOBSIM_ST_INTERNAL) break;
         if (S.n_lv[opp] == 0) {
             if (is_market) S.status |= LOBSIM_ST_EMPTY_BOOK;  // EmptyOrderbookError (:180-186); a limit just stops crossing
             break;
@@ -1208,7 +1282,7 @@ SDI int32_t execute(Lds& L, Scal& S, int side, bool is_agent, bool is_market, in
         if (!is_market && !(side == LOBSIM_BUY ? le64(bp, price) : le64(price, bp))) break;
         uint64_t m = (uint64_t)uni64((int64_t)L.meta[opp][0]);
         int head = m_head(m), tail = m_tail(m);
-        Slot* sl = slab_ptr(S.slots, m_slab(m));
+        const auto sl = SLAB_PTR(S.slots, m_slab(m));
         int32_t carry = 0, exec_agent = 0, deleted_agent_vol = 0, n_ext = 0, n_agent = 0, n_removed = 0;
         int first_survivor = tail;
         EVENT(ev_exec_levels);
@@ -1315,7 +1389,11 @@ SDI void submit_limit(Lds& L, Scal& S, int side, int64_t price, int32_t vol, boo
     if (is_agent) {
         int a = alloc_agent(L, S);
         if (a >= 0) {
-            if (lane() == 0) { AgentOrd o; o.price = price; o.vol = vol; o.seq_side = (L.agent_seq & 0x7fffffffu) | ((uint32_t)side << 31); ag_put(L, S, a, o); L.agent_seq++; }
+            if (lane() == 0) {  // (an agent order that names its own tag - ext_id > 0: lobsim_forward's rows - is filed under it; the env's counter stays ahead of every tag)
+                const uint32_t cur = L.agent_seq, sq = ext_id > 0 ? (uint32_t)ext_id : cur;
+                AgentOrd o; o.price = price; o.vol = vol; o.seq_side = (sq & 0x7fffffffu) | ((uint32_t)side << 31); ag_put(L, S, a, o);
+                L.agent_seq = (sq > cur ? sq : cur) + 1;
+            }
             id = a;
         }
     }
@@ -1762,7 +1840,7 @@ SDI uint64_t apply_agent_ops_parallel(Lds& L, Scal& S, const DevCfg& C) {
     const int nlv = S.n_lv[side];
     const int li = (is_limit || (is_cancel && in_lds)) ? lane_find_level(L, side, nlv, price) : -1;
     const uint64_t m = li >= 0 ? L.meta[side][li] : 0;
-    Slot* sl = slab_ptr(S.slots, m_slab(m));
+    const auto sl = SLAB_PTR(S.slots, m_slab(m));
     // ---- new orders: append at the tail of an existing level that has room
     bool lim_ok = is_limit && li >= 0 && m_tail(m) < m_cap(m) && m_tail(m) - m_head(m) - m_live(m) < LOBSIM_TOMB;
     uint64_t lim_mask = ballot(lim_ok);
@@ -1851,9 +1929,12 @@ SDI void ladder_clear(Lds& L, Scal& S, const DevPtrs& P) {
     S.ladder_ver = 0;
     if (lane() < 2) { L.far_n[lane()] = 0; L.far_front[lane()] = 0; }
     uint64_t* hw = hi_free_words(S.slots);
-    hw[HI_W0 + lane()] = LOBSIM_FLAT_SLABS ? mask_word(P.n_slab - NSLAB, lane()) : 0;  // the buddy pool (slab_alloc_cls): all of it free as 16-page blocks, none split yet
+    // the buddy pool (slab_alloc_cls): all of it free as 64-page blocks, none split yet; the 16-page blocks behind the last whole 64-page
+    // block (a pool that is not a multiple of 64 pages) are free 16-page blocks that never merge
+    hw[HI_W0 + lane()] = LOBSIM_FLAT_SLABS ? mask_word(P.n_slab - NSLAB, lane()) : 0;
     if (lane() < NMID_MAX / 64) hw[HI_W1 + lane()] = 0;
-    if (lane() < NBIG_MAX / 64) hw[HI_W2 + lane()] = LOBSIM_FLAT_SLABS ? 0 : mask_word(P.n_big, lane());
+    if (lane() < NBIG_MAX / 64) hw[HI_W2 + lane()] = LOBSIM_FLAT_SLABS ? 0 : mask_word(P.n_big, lane()) & ~mask_word(P.n_big & ~3, lane());
+    if (lane() < NHUGE_MAX / 64) hw[HI_W3 + lane()] = LOBSIM_FLAT_SLABS ? 0 : mask_word(P.n_big >> 2, lane());
     if (lane() == 0) hw[HI_COUNTS] = (uint64_t)P.n_slab | ((uint64_t)P.n_big << 32);  // (n_slab: the env's budget of price levels, ladder_insert_cold)
     if (lane() < NSLAB / 64) L.slab_free[lane()] = ~0ull;
     if (lane() < NA / 64) { L.agent_free[lane()] = ~0ull; L.agent_pending[lane()] = 0; }
@@ -1882,7 +1963,7 @@ SDI void set_level_to_snapshot(Lds& L, Scal& S, int side, int64_t price, int32_t
     if (lane() == 0) {
         int slab = m_slab(L.meta[side][idx]);
         Slot s; s.id = -1; s.vol = vol; s.kind = K_SNAP;
-        slab_ptr(S.slots, slab)[0] = s;
+        SLAB_PTR(S.slots, slab)[0] = s;
         L.meta[side][idx] = mk_meta(slab, 0, 1, 1); L.vol[side][idx] = vol;
     }
     wsync();
@@ -1988,7 +2069,12 @@ SDI void resync_outer_levels(Lds& L, Scal& S, const DevCfg& C, const StreamDev& 
     }
     if (n_readd > OPS_MAX) S.status |= LOBSIM_ST_AGENT_OVERFLOW;
     wsync();
-    for (int k = 0; k < n_readd && !S.status; k++) process_op(L, S, C, L.ops[k]);
+    for (int k = 0; k < n_readd && !S.status; k++) {  // (re-adds: limit orders at the price of the agent entry they name - never a quote level, so this loop keeps
+        Op8 op = L.ops[k];                               // the step's quote prices S.q_buy / S.q_sell out of the live set of the whole message replay)
+        op.code = uni(op.code); op.vol = uni(op.vol);
+        if (!(op.vol > 0)) { S.status |= LOBSIM_ST_ASSERT; break; }
+        submit_limit(L, S, (op.code >> 4) & 1, uni64(ag_price(L, S, op.code >> 8)), op.vol, true, 0);
+    }
     if (S.status) return;
     int64_t wb, ws;
     if (!price_range(L, S, wb, ws)) { S.status |= LOBSIM_ST_EMPTY_BOOK; return; }
@@ -2070,7 +2156,7 @@ SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt,
         if (app) {
             Slot w; w.id = b.eid; w.vol = (int32_t)vol64; w.kind = K_EXT;
             const int pos = m_tail(m) + rank;
-            slot_store<2>(&slab_ptr(S.slots, m_slab(m))[pos], w);
+            slot_store<2>(&SLAB_PTR(S.slots, m_slab(m))[pos], w);
             idc_put(S, b.eid, m_slab(m), pos);
             atomicAdd(reinterpret_cast<unsigned long long*>(&L.meta[side][li]), (1ull << 32) + (1ull << 48));  // tail += 1, live += 1
             atomicAdd(&L.vol[side][li], (int32_t)vol64);
@@ -2084,7 +2170,7 @@ SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt,
 #if LOBSIM_SLOT_EARLY
     // (no branch around the load: the compiler would wait for it at the end of the branch, i.e. before the appends instead
     // of behind them; a lane without a removal reads slot 0 of slab 0 and ignores it)
-    const Slot cs = slot_load<8>(&slab_ptr(S.slots, rem ? cslab : 0)[rem ? cpos : 0]);
+    const Slot cs = slot_load<8>(&SLAB_PTR(S.slots, rem ? cslab : 0)[rem ? cpos : 0]);
 #endif
     book_appends();
     // ---- cancellations / deletions whose order the position cache still knows: straight to the slot, no queue scan.
@@ -2097,7 +2183,7 @@ SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt,
     const uint64_t m2 = rem ? L.meta[side][li] : 0;  // after the appends of this segment
     rem = rem && cslab == m_slab(m2) && cpos >= m_head(m2) && cpos < m_tail(m2);
     Slot cs = dead_slot();
-    if (rem) cs = slab_ptr(S.slots, cslab)[cpos];
+    if (rem) cs = SLAB_PTR(S.slots, cslab)[cpos];
 #endif
     rem = rem && cs.kind == K_EXT && cs.id == b.eid;
     const int rkey = (cslab << 16) | cpos;
@@ -2131,7 +2217,7 @@ SDI uint64_t append_segment(Lds& L, Scal& S, const MsgBatch& b, int j0, int cnt,
         const int32_t rv = v > cs.vol ? cs.vol : v, nv = cs.vol - rv;  // CancellationVolumeExceededError -> whole remainder
         gone = nv == 0;
         Slot w = cs; w.vol = nv; if (gone) w.kind = K_DEAD;
-        slot_store<4>(&slab_ptr(S.slots, cslab)[cpos], w);
+        slot_store<4>(&SLAB_PTR(S.slots, cslab)[cpos], w);
         atomicAdd(&L.vol[side][li], -rv);
         if (gone) atomicAdd(reinterpret_cast<unsigned long long*>(&L.meta[side][li]), (unsigned long long)(-(1ll << 48)));  // live -= 1
     }
@@ -2207,6 +2293,7 @@ SDI void replay_messages(Lds& L, Scal& S, const StreamDev& st, int64_t& cursor, 
         uint64_t applied = 0;  // lanes whose limit order the lane-parallel pass has already booked
         int classified = 0;    // lanes below this have been through append_segment
         for (int j = 0; j < cnt && !S.status; j++) {
+            bounds_poll(S);
             if (j >= classified) {
                 int seg_end;
                 EVENT(ev_x[6]);
@@ -2337,7 +2424,7 @@ SDI bool feature_raw(const lobsim_feature& d, FeatState& f, int64_t* ring, const
     // one feature kind after the other (each lane group waiting for its own loads), this way the HBM latency is paid
     // once (or not at all: the step kernel asks for them at the top of the step).
     int64_t w0 = pre0, w1 = pre1;
-    if (!have_pre) { int i0, i1; ring_idx(d.kind, lb, f.count, f.pos, i0, i1); w0 = ring[i0]; w1 = ring[i1]; }
+    if (!have_pre) { int i0, i1; ring_idx(d.kind, lb, f.count, f.pos, i0, i1); w0 = ring[RIDX(i0)]; w1 = ring[RIDX(i1)]; }
     switch (d.kind) {
     case LOBSIM_F_SPREAD: f.current_value = v.spread; return true;
     case LOBSIM_F_BOOK_IMBALANCE:
@@ -2357,7 +2444,7 @@ SDI bool feature_raw(const lobsim_feature& d, FeatState& f, int64_t* ring, const
     case LOBSIM_F_PRICE_MOVE:
     case LOBSIM_F_PRICE_RANGE: {  // deque(maxlen=lookback+1).appendleft(price)
         const int cap = lb + 1;
-        pr[f.pos] = v.price;
+        pr[RIDX(f.pos)] = v.price;
         if (f.count < cap) f.count++;
         f.pos = f.pos + 1 == cap ? 0 : f.pos + 1;
         if (d.kind == LOBSIM_F_PRICE_MOVE) {
@@ -2368,7 +2455,7 @@ SDI bool feature_raw(const lobsim_feature& d, FeatState& f, int64_t* ring, const
             f.current_value = v.price - oldest;
         } else {
             double mx = v.price, mn = v.price;
-            for (int i = 0; i < f.count; i++) { double x = pr[i]; mx = x > mx ? x : mx; mn = x < mn ? x : mn; }
+            for (int i = 0; i < f.count; i++) { double x = pr[RIDX(i)]; mx = x > mx ? x : mx; mn = x < mn ? x : mn; }
             f.current_value = mx - mn;
         }
         return true;
@@ -2377,7 +2464,7 @@ SDI bool feature_raw(const lobsim_feature& d, FeatState& f, int64_t* ring, const
         const int cap = lb + 1;
         if (f.count < lb || f.count == lb) {
             bool closing = f.count == lb;
-            pr[f.pos] = v.price;
+            pr[RIDX(f.pos)] = v.price;
             if (f.count == 0) { f.p_first = v.price; f.acc = 0.0; }
             else { double r = (v.price - f.p_last) / f.p_first; f.acc = f.acc + r * r; }  // sum(pct_returns**2), left to right
             f.p_last = v.price;
@@ -2389,7 +2476,7 @@ SDI bool feature_raw(const lobsim_feature& d, FeatState& f, int64_t* ring, const
             double next_oldest = __longlong_as_double(w1);
             double old_ret = (next_oldest - oldest) / oldest;
             double new_ret = (v.price - f.p_last) / f.p_last;
-            pr[f.pos] = v.price;
+            pr[RIDX(f.pos)] = v.price;
             f.pos = f.pos + 1 == cap ? 0 : f.pos + 1;
             f.p_last = v.price;
             double ss = f.current_value * lb - old_ret * old_ret + new_ret * new_ret;
@@ -2412,10 +2499,10 @@ SDI bool feature_raw(const lobsim_feature& d, FeatState& f, int64_t* ring, const
         const int64_t new_dv = f.total;
         const int n = f.count;  // appends so far; the deques hold min(n, cap) prices and min(n, tlb) volumes
         if (n < tlb) {
-            pr[n] = new_price; dv[n % tlb] = new_dv;
+            pr[RIDX(n)] = new_price; dv[RIDX(cap + n % tlb) - cap] = new_dv;
             f.current_value = 0.0;
         } else if (n == tlb) {
-            pr[n] = new_price; dv[n % tlb] = new_dv;  // the volume deque (maxlen tlb) just dropped its oldest entry
+            pr[RIDX(n)] = new_price; dv[RIDX(cap + n % tlb) - cap] = new_dv;  // the volume deque (maxlen tlb) just dropped its oldest entry
             const double p0 = pr[0];
             double sum = 0.0;
             for (int i = 0; i < tlb; i++) {
@@ -2426,7 +2513,7 @@ SDI bool feature_raw(const lobsim_feature& d, FeatState& f, int64_t* ring, const
             f.current_value = sum / tlb;
         } else {
             const int po = n % cap;  // oldest price (the slot the new one overwrites)
-            const double oldest = pr[po], next_oldest = pr[(po + 1) % cap], newest = pr[(po + cap - 1) % cap];
+            const double oldest = pr[RIDX(po)], next_oldest = pr[(po + 1) % cap], newest = pr[(po + cap - 1) % cap];
             // Python floats: a division by 0.0 raises ZeroDivisionError (:306, :309).  The averaged price is 0.0 exactly when slowing_factor
             // is 1 (the partial sum is only added to BETWEEN slow updates, :287-290): such a feature raises at its (lookback + 2)-th update
             if (oldest == 0.0 || newest == 0.0) return false;
@@ -2449,14 +2536,14 @@ SDI bool feature_raw(const lobsim_feature& d, FeatState& f, int64_t* ring, const
         int64_t nb = dirn ? v.ext_cnt[0] : v.ext_vol[0], ns = dirn ? v.ext_cnt[1] : v.ext_vol[1];
         if (d.iparam) { nb += dirn ? v.int_cnt[0] : v.int_vol[0]; ns += dirn ? v.int_cnt[1] : v.int_vol[1]; }  // track_internal (:379-381, :438-440)
         if (f.count < lb) {
-            ring[f.pos] = nb; ring[lb + f.pos] = ns;
+            ring[RIDX(f.pos)] = nb; ring[RIDX(lb + f.pos)] = ns;
             f.total += nb + ns; f.diff += nb - ns;
             f.count++;
             f.pos = f.pos + 1 == lb ? 0 : f.pos + 1;
             f.current_value = 0.0;
         } else {
             int64_t ob = w0, os = w1;
-            ring[f.pos] = nb; ring[lb + f.pos] = ns;
+            ring[RIDX(f.pos)] = nb; ring[RIDX(lb + f.pos)] = ns;
             f.total += (nb + ns) - (ob + os); f.diff += (nb - ns) - (ob - os);
             f.pos = f.pos + 1 == lb ? 0 : f.pos + 1;
             f.current_value = f.total != 0 ? (double)f.diff / (double)f.total : 0.5;
@@ -2473,64 +2560,112 @@ SDI double* norm_history(const DevCfg& C, const DevPtrs& P, int env, int f) {
     return P.norm + (size_t)env * C.norm_words + C.norm_off[f];
 }
 
-// ---- normalisation_on (Features.py:60-74): z-score of the newest value against the feature's whole history.
-// numpy's add.reduce over n contiguous f64 values, optionally of (x - mean)^2: pairwise summation (8 accumulators up to
-// 128 elements, halves rounded down to a multiple of 8 above) inside chunks of the ufunc buffer size (8192 elements)
-// that are added left to right.  The history is a ring (deque(maxlen)): element i is a[(start + i) mod cap].  One lane
-// per feature walks it serially, as everywhere in the feature phase; the explicit stacks make this the part of the
-// EXTRAS kernel variants that uses private memory.
-SDI double np_leaf_ring(const double* a, int cap, int first, int n, bool centered, double mean) {
-    auto at = [&](int i) { int k = first + i; k = k >= cap ? k - cap : k; const double x = a[k]; return centered ? (x - mean) * (x - mean) : x; };
-    if (n < 8) { double r = 0.; for (int i = 0; i < n; i++) r += at(i); return r; }
-    double r0 = at(0), r1 = at(1), r2 = at(2), r3 = at(3), r4 = at(4), r5 = at(5), r6 = at(6), r7 = at(7);
-    int i;
-    for (i = 8; i < n - (n % 8); i += 8) { r0 += at(i); r1 += at(i + 1); r2 += at(i + 2); r3 += at(i + 3); r4 += at(i + 4); r5 += at(i + 5); r6 += at(i + 6); r7 += at(i + 7); }
-    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-    for (; i < n; i++) res += at(i);
-    return res;
-}
-SDI double np_sum_ring(const double* a, int cap, int start, int n, bool centered, double mean) {
+// ---- normalisation_on (Features.py:60-74): z-score of the newest value against the feature's whole history - the one part of the path
+// that is bound by HBM bandwidth: every update reads the history twice (mean, then the squared deviations), 16 B per element.
+// numpy's add.reduce over n contiguous f64 values, optionally of (x - mean)^2: pairwise summation inside chunks of the ufunc buffer size
+// (8192 elements) that are added left to right.  Inside a chunk: a block of more than 128 elements is split - the left half rounded down
+// to a multiple of 8 - and the halves' sums added; a block of 8 .. 128 elements is summed by 8 accumulators (accumulator j takes elements
+// j, j + 8, j + 16 ..., combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the < 8 elements left over one by one); fewer than 8: one by one.
+// The history is a ring (deque(maxlen)): element i is a[(start + i) mod cap].
+//
+// Round 6: the WAVE sums a history, not one lane (until then lane f walked feature f's history serially, twice: 5 M env-steps/s at 1024
+// envs).  The chunk's tree is embedded in a complete binary tree of 2^D leaf slots (D <= 7: the depth of the chunk's deepest block, found
+// along its right spine - the right half is never the smaller one): slot s = the path from the root, one bit per split, a block that stops
+// splitting early owns the slots below it and puts its sum into the first of them, the others hold -0.0, the one value x + (-0.0) == x
+// holds for bit for bit.  Eight lanes sum one block - lane j IS accumulator j, the eight loads of a turn are 64 contiguous bytes - so a wave
+// takes eight blocks (up to 8 KiB of history) per pass, all of a pass's loads in flight before the first add; the slots are then combined
+// by a butterfly (lanes i and i + 2^k: the tree's own order, and a + b == b + a).  Bit for bit numpy's result: tests/test_gpu_parity.py
+// (the three normalised trajectories recorded from the reference, the 256-env batch), tests/test_gpu_fuzz.py.
+SDI double shfl_xor_f64(double v, int m) { return __shfl_xor(v, m); }
+SDI double shfl_down_f64(double v, int d) { return __shfl_down(v, d); }
+SDI double wave_np_sum(Lds& L, const double* a, int cap, int start, int n, bool centered, double mean) {
+    const int ln = lane(), grp = ln >> 3, j = ln & 7;
+    auto at = [&](int first, int i) {  // element i of the block whose first element sits at ring position `first`
+        int k = first + i; k = k >= cap ? k - cap : k;
+        const double x = a[BIDX(k, cap)];
+        return centered ? (x - mean) * (x - mean) : x;
+    };
     double total = 0.;
+    double* slotv = reinterpret_cast<double*>(L.ops);  // 128 slots (the op list is long consumed when the features are updated)
+    static_assert(sizeof(L.ops) >= 128 * sizeof(double), "");
     for (int coff = 0; coff < n; coff += 8192) {
-        // depth-first over the pairwise tree of this chunk; `red` = additions owed once the subtree's sum is known
-        int off[8], len[8], red[8], sp = 1, vp = 0;
-        double val[9];
-        off[0] = coff; len[0] = n - coff < 8192 ? n - coff : 8192; red[0] = 0;
-        while (sp) {
-            sp--;
-            const int o = off[sp], l = len[sp];
-            int r = red[sp];
-            if (l > 128) {
-                int n2 = l / 2;
-                n2 -= n2 % 8;
-                off[sp] = o + n2; len[sp] = l - n2; red[sp] = r + 1; sp++;  // right half: completes this node
-                off[sp] = o; len[sp] = n2; red[sp] = 0; sp++;               // left half first
-                continue;
+        const int l = n - coff < 8192 ? n - coff : 8192;
+        int cfirst = start + coff; cfirst = cfirst >= cap ? cfirst - cap : cfirst;  // (start < cap, coff < n <= cap)
+        int D = 0;
+        for (int t = l; t > 128; D++) { int n2 = t / 2; n2 -= n2 % 8; t -= n2; }
+        const int nslots = 1 << D;
+        slotv[ln] = -0.0; slotv[ln + 64] = -0.0;
+        wsync();
+        for (int s0 = 0; s0 < nslots; s0 += 8) {
+            const int s = s0 + grp;
+            int o = 0, len = l;
+            bool real = s < nslots;
+            for (int d = D - 1; d >= 0; d--) {  // the block of slot s: one bit of s per split, from the root
+                const int bit = (s >> d) & 1;
+                if (len > 128) { int n2 = len / 2; n2 -= n2 % 8; if (bit) { o += n2; len -= n2; } else len = n2; }
+                else if (bit) real = false;
             }
-            int first = start + o;
-            first = first >= cap ? first - cap : first;
-            val[vp++] = np_leaf_ring(a, cap, first, l, centered, mean);
-            for (; r > 0; r--) { vp--; val[vp - 1] = val[vp - 1] + val[vp]; }
+            int first = cfirst + o; first = first >= cap ? first - cap : first;
+            double res = 0.;
+            if (real) {
+                if (len < 8) { for (int i = 0; i < len; i++) res += at(first, i); }  // (a chunk of fewer than 8 elements: the group's lanes all do the same)
+                else {
+                    const int nb = len >> 3;  // whole turns of the 8 accumulators (<= 16)
+                    double x[16];
+#pragma unroll
+                    for (int b = 0; b < 16; b++) x[b] = b < nb ? at(first, 8 * b + j) : 0.;  // every load of the block before the first add
+                    double r = x[0];
+#pragma unroll
+                    for (int b = 1; b < 16; b++) r = b < nb ? r + x[b] : r;
+                    res = r;
+                }
+            }
+            // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) inside every group of eight lanes (all lanes take part in the exchange; a block of fewer
+            // than 8 elements keeps the sum its lanes worked out one by one)
+            double t = res + shfl_xor_f64(res, 1);
+            t = t + shfl_xor_f64(t, 2);
+            t = t + shfl_xor_f64(t, 4);
+            if (real && len >= 8) {
+                res = t;
+                for (int i = len & ~7; i < len; i++) res += at(first, i);  // the elements left over, one by one
+            }
+            if (real && j == 0) slotv[s] = res;
         }
-        total = total + val[0];
+        wsync();
+        double v = slotv[2 * ln] + slotv[2 * ln + 1];
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) v = v + shfl_down_f64(v, sh);
+        total = total + rld(v, 0);
+        wsync();
     }
     return total;
 }
-// Feature.normalise: history.append(value) [preceded by value + 1e-06 when the history is empty], then
-// scipy.stats.zscore(history)[-1] = (value - mean) / std, numpy mean and std(ddof=0).  hist[0] = count | start << 32.
-SDI double feature_normalise(double* hist, int cap, double value) {
-    int64_t* hw = reinterpret_cast<int64_t*>(hist);
-    int n = (int)(hw[0] & 0xffffffff), start = (int)(hw[0] >> 32);
-    double* a = hist + 1;
-    for (int k = n == 0 ? 0 : 1; k < 2; k++) {
-        const double x = k == 0 ? value + 1e-06 : value;
-        if (n == cap) { a[start] = x; start = start + 1 == cap ? 0 : start + 1; }  // the oldest value falls out
-        else { int idx = start + n; idx = idx >= cap ? idx - cap : idx; a[idx] = x; n++; }
+// Feature.normalise for the lanes in `need` (uniform mask), one feature after the other, the wave summing: history.append(value) [preceded by
+// value + 1e-06 when the history is empty], then scipy.stats.zscore(history)[-1] = (value - mean) / std, numpy mean and std(ddof=0).
+// hist[0] = count | start << 32.
+SDI void normalise_wave(Lds& L, const DevCfg& C, const DevPtrs& P, int env, FeatState& fs, uint64_t need) {
+    const int ln = lane();
+    for (; need; need &= need - 1) {
+        const int f = ffs64(need);
+        double* hist = P.norm + (size_t)env * C.norm_words + C.norm_off[f];
+        const int cap = (int)C.c.features[f].norm_len;
+        const double value = rld(fs.current_value, f);
+        int64_t* hw = reinterpret_cast<int64_t*>(hist);
+        const int64_t w0 = uni64(hw[0]);
+        int n = (int)(w0 & 0xffffffff), start = (int)(w0 >> 32);
+        double* a = hist + 1;
+        for (int k = n == 0 ? 0 : 1; k < 2; k++) {
+            const double x = k == 0 ? value + 1e-06 : value;
+            if (n == cap) { if (ln == 0) a[BIDX(start, cap)] = x; start = start + 1 == cap ? 0 : start + 1; }  // the oldest value falls out
+            else { int idx = start + n; idx = idx >= cap ? idx - cap : idx; if (ln == 0) a[BIDX(idx, cap)] = x; n++; }
+        }
+        if (ln == 0) hw[0] = (int64_t)n | ((int64_t)start << 32);
+        wsync();  // (the wave's own stores are visible to its later loads: vector-memory instructions execute in program order)
+        const double mean = wave_np_sum(L, a, cap, start, n, false, 0.) / (double)n;
+        const double var = wave_np_sum(L, a, cap, start, n, true, mean) / (double)n;
+        const double z = (value - mean) / sqrt(var);
+        if (ln == f) fs.current_value = z;
     }
-    hw[0] = (int64_t)n | ((int64_t)start << 32);
-    const double mean = np_sum_ring(a, cap, start, n, false, 0.) / (double)n;
-    const double var = np_sum_ring(a, cap, start, n, true, mean) / (double)n;
-    return (value - mean) / sqrt(var);
 }
 
 // `carried`: the feature's current_value from before the reset.  Feature objects outlive the episode and neither reset() nor _reset()
@@ -2550,15 +2685,16 @@ SDI bool feature_reset(const lobsim_feature& d, FeatState& f, int64_t* ring, con
 
 template <bool EXTRAS>
 SDI bool feature_update(const lobsim_feature& d, FeatState& f, int64_t* ring, const StepView& v, double* hist, bool have_pre = false, int64_t pre0 = 0, int64_t pre1 = 0,
-                        bool* touched = nullptr) {  // update, :80-86.  *touched: the feature's state changed (else it need not be written back)
+                        bool* touched = nullptr, bool* need_norm = nullptr) {  // update, :80-86.  *touched: the feature's state changed (else it need not be written back)
     if (touched) *touched = false;
+    if (need_norm) *need_norm = false;
     if (v.now_us < f.first_usage_us) return true;
     if (d.update_us <= 0xffffffffll ? (v.now_mod_min % (uint32_t)d.update_us != 0) : ((int64_t)v.now_mod_min % d.update_us != 0)) return true;  // _now_is_multiple_of_update_freq
     if (touched) *touched = true;
     if (!feature_raw(d, f, ring, v, have_pre, pre0, pre1)) return false;
     f.current_value = clampd(f.current_value, d.min_value, d.max_value);
     if constexpr (EXTRAS)
-        if (hist) f.current_value = feature_normalise(hist, (int)d.norm_len, f.current_value);  // :86
+        if (hist && need_norm) *need_norm = true;  // :86 - the WAVE normalises, once every lane has its value (normalise_wave)
     return true;
 }
 
@@ -2586,7 +2722,8 @@ SDI double rolling_sharpe(Lds& L, Scal& S, const lobsim_reward& r, double* st, i
     int filled = (int)(word & 0xffffffff), next = (int)(word >> 32);
     double* ring = st + 1;
     const double new_aum = (double)cash + price * (double)inv;  // calculate_aum(next_state)
-    if (ln == 0) ring[next] = new_aum;
+    BCHECK(W >= 1 && W <= LOBSIM_SHARPE_MAX_WINDOW && next >= 0 && next < W && filled >= 0 && filled <= W);
+    if (ln == 0) ring[BIDX(next, W)] = new_aum;
     next = next + 1 == W ? 0 : next + 1;
     filled = filled + 1 < W ? filled + 1 : W;
     if (ln == 0) ((int64_t*)st)[0] = (int64_t)filled | ((int64_t)next << 32);
@@ -2597,7 +2734,7 @@ SDI double rolling_sharpe(Lds& L, Scal& S, const lobsim_reward& r, double* st, i
     for (int k = ln; k < filled; k += WAVE) {
         int idx = next - filled + k;
         idx = idx < 0 ? idx + W : idx;
-        const double a = k == filled - 1 ? new_aum : ring[idx];  // the newest value was written by lane 0 just now
+        const double a = k == filled - 1 ? new_aum : ring[BIDX(idx, W)];  // the newest value was written by lane 0 just now
         bad = bad || a <= 0;
         scr[k] = log(a);
     }
@@ -2699,6 +2836,7 @@ SDI EnvRegs load_env_issue(Scal& S, const DevPtrs& P, int env, const HdrRegs& H)
     int ln = lane();
     const Ladder& G = P.ladder[env];
     S.n_lv.v = (uint32_t)H.n_lv0 | ((uint32_t)H.n_lv1 << 16);
+    BCHECK(H.n_lv0 >= 0 && H.n_lv0 <= LV && H.n_lv1 >= 0 && H.n_lv1 <= LV);
     // every global load of the common case (<= 64 levels per side) is issued before the first LDS store: one HBM
     // round trip for the whole env state instead of one per loop
     // (ladder and agent loads sit in branches - lanes beyond the live levels / free agent entries load nothing - but no
@@ -2782,8 +2920,9 @@ SDI void store_env(const Lds& L, const Scal& S, const DevPtrs& P, int env, EnvHd
     if (ln < 2) { H.far_n[ln] = L.far_n[ln]; H.far_front[ln] = L.far_front[ln]; }
     }
     if (!rest) return;
+    const int bst = bounds_status();
     if (ln == 0) {
-        H.status = S.status; H.inventory = L.inv; H.cash = L.cash;
+        H.status = S.status | bst; H.inventory = L.inv; H.cash = L.cash;
         H.agent_fill_count = L.ag_cnt[0] + L.ag_cnt[1]; H.agent_vol[0] = L.ag_vol[0]; H.agent_vol[1] = L.ag_vol[1];
         H.ext_count[0] = L.ext_cnt[0]; H.ext_count[1] = L.ext_cnt[1]; H.ext_vol[0] = L.ext_vol[0]; H.ext_vol[1] = L.ext_vol[1];
     }
@@ -2820,6 +2959,7 @@ SDI void run_agent_ops(Lds& L, Scal& S, const DevCfg& C) {
     if (S.n_ops <= 64 && !has_market && resting_only) todo = apply_agent_ops_parallel(L, S, C);
     if (S.n_ops <= 64) {
         while (todo && !S.status) {
+            bounds_poll(S);
             int k = ffs64(todo); todo &= todo - 1; EVENT(ev_serial_ops);
 #ifdef LOBSIM_PROFILE
             const uint64_t t0 = __builtin_amdgcn_s_memtime();
@@ -2921,12 +3061,76 @@ SDI void load_snapshot_book(Lds& L, Scal& S, const int64_t* row, int Lv, bool sk
 // ---------------------------------------------------------------------------------------------------------------
 
 
+// Longest job first inside a launch (round 6).  A launch lasts as long as its slowest wave, and a wave is slow because its window is long
+// AND because it shares its SIMD with three others: measured with orders worked out on the host from the stream (tools/order_probe.py,
+// profiles/r6/order_probe.txt) the same 4096 envs take 26.6 us per launch when the envs are dispatched heaviest first - the dispatcher
+// deals consecutive workgroups round the XCDs, CUs and SIMDs, so every SIMD gets one env of each weight quartile and the heavy ones start
+// first - against 30.1 us in env order and 33.4 us with the heavy ones packed together.  What a window will cost is known before anybody
+// replays it: lobsim_add_stream tabulates, per stream and per window of one step, messages + 8 x runs of executions (window_weight).  So
+// the first LPT_CLASSES workgroups of every step launch are SORTER waves: wave j ranks the envs of residue class j (mod LPT_CLASSES) by
+// the weight of the window each will replay in the NEXT launch - a counting sort in LDS over the class's N / 16 members, ~3 k cycles, done
+// long before the first env wave finishes - and writes them, heaviest first, into the places j, j + 16, j + 32 ... of the next launch's
+// order.  An env keeps its residue class, hence its XCD (workgroup b runs on XCD b mod 8): its state stays in that XCD's L2.
+// The sorters read the env clocks while the env waves of the same launch are still running; the order they write is a permutation
+// whatever they read (the keys are read once, into LDS), so a stale or torn clock costs quality only, never an env stepped twice.
+// (Out of line, plain values in, called from the kernel's entry behind a never-taken branch, its scratch the workgroup's LDS block from
+// offset 0 - which a sorter wave does not use otherwise: inlined into the step body, or called from inside it, the sorter cost the env
+// waves' register allocation 10 - 12 spilled vector registers, and those cost the step 2.8 us - more than the order gains.)
+typedef int32_t __attribute__((address_space(3))) * LdsI32;
+typedef uint8_t __attribute__((address_space(3))) * LdsU8;
+static __device__ __attribute__((noinline)) void lpt_sort(LdsI32 hist, const EnvHdr* hdr, const StreamDev* streams, int64_t step, int32_t* order_next, int N) {
+    __builtin_amdgcn_s_setprio(3);
+    const int j = (int)blockIdx.x, ln = lane();
+    const int size = (N - j + LPT_CLASSES - 1) / LPT_CLASSES;  // envs j, j + 16, ...
+    LdsU8 keys = (LdsU8)(hist + 256);                          // 256 counters, then one key byte per member (the host refuses N beyond what fits)
+    const double inv_step = 1.0 / (double)step;
+#pragma unroll
+    for (int k = 0; k < 4; k++) hist[ln + 64 * k] = 0;
+    wsync();
+    for (int base = 0; base < size; base += WAVE) {
+        const int r = base + ln;
+        if (r < size) {
+            const EnvHdr& H = hdr[j + LPT_CLASSES * r];
+            const int sid = H.stream_id;
+            int w = 0;
+            if (H.status == 0 && sid >= 0) {
+                const StreamDev& st = streams[sid];
+                const int64_t x = H.now_us + step - st.first_sec * 1000000;  // where the window AFTER this launch's begins, on the table's grid
+                const int g = (int)((double)x * inv_step + 0.5);             // (clocks sit on the grid: rounding, not a 64-bit division - a weight is a hint)
+                if (g >= 0 && g < st.n_win) w = st.wtab[g];
+            }
+            const int key = 255 - w;  // ascending key = descending weight
+            keys[r] = (uint8_t)key;
+            __hip_atomic_fetch_add(hist + key, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    wsync();
+    {   // exclusive prefix sum over the 256 counters, four per lane
+        const int c0 = hist[4 * ln], c1 = hist[4 * ln + 1], c2 = hist[4 * ln + 2], c3 = hist[4 * ln + 3];
+        const int s = c0 + c1 + c2 + c3;
+        const int b0 = wave_incl_scan(s) - s;
+        wsync();
+        hist[4 * ln] = b0; hist[4 * ln + 1] = b0 + c0; hist[4 * ln + 2] = b0 + c0 + c1; hist[4 * ln + 3] = b0 + c0 + c1 + c2;
+    }
+    wsync();
+    for (int base = 0; base < size; base += WAVE) {
+        const int r = base + ln;
+        if (r < size) {
+            const int pos = __hip_atomic_fetch_add(hist + (int)keys[r], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (a place of its own for every member, whatever the keys are)
+            order_next[j + LPT_CLASSES * BIDX(pos, size)] = j + LPT_CLASSES * r;
+        }
+    }
+}
+
 template <bool EXTRAS>
 SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
     __shared__ Lds L;
+    bounds_begin(C, P);
     // (A launch of more envs than the chip holds at once runs in rounds: the envs of the busiest streams go first - the host sorts
     // them by their stream's message rate - so that the last round is made of short windows.  Null when all envs are resident.)
-    const int env = A.order ? A.order[blockIdx.x] : (int)blockIdx.x, ln = lane();
+    // (a launch with sorter waves - longest job first, lpt_sort: the kernel's entry sends the first LPT_CLASSES workgroups there - runs env order[b] in workgroup LPT_CLASSES + b)
+    const int blk = (int)blockIdx.x - ((LOBSIM_LPT && A.order_next) ? LPT_CLASSES : 0);
+    const int env = A.order ? A.order[blk] : blk, ln = lane();
     if (A.active && (A.active[env] != 0) == (A.skip_mode != 0)) return;
     EnvHdr& H = P.hdr[env];
     const int F = C.c.n_features, AD = CFG_ADIM(C), D = C.obs_dim;
@@ -2998,7 +3202,7 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
         int i0, i1;
         ring_idx(fkind, flb, fcount, fpos, i0, i1);
         const int64_t* ring = P.rings + (size_t)env * C.ring_words + froff;
-        rw0 = ring[i0]; rw1 = ring[i1];  // in flight while the agent's orders are built
+        rw0 = ring[BIDX(i0, RING_WORDS(lf))]; rw1 = ring[BIDX(i1, RING_WORDS(lf))];  // in flight while the agent's orders are built
     }
     STAMP(1);
     {   // longest-job-first from the start of the step (replay_messages sets the same level again)
@@ -3051,13 +3255,14 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
         if (!S.status) {
             StepView v = make_view(L, S, price, now);
             SUBSTAMP(9);
-            bool ok = true;
+            bool ok = true, need_norm = false;
 #if LOBSIM_FEAT_PF
-            if (ln < F) ok = feature_update<EXTRAS>(dsc, fs, P.rings + (size_t)env * C.ring_words + froff, v, norm_history(C, P, env, ln), true, L.rstash[ln][0], L.rstash[ln][1], &fs_touched);
+            if (ln < F) ok = feature_update<EXTRAS>(dsc, fs, P.rings + (size_t)env * C.ring_words + froff, v, norm_history(C, P, env, ln), true, L.rstash[ln][0], L.rstash[ln][1], &fs_touched, &need_norm);
 #else
-            if (ln < F) ok = feature_update<EXTRAS>(C.c.features[ln], fs, P.rings + (size_t)env * C.ring_words + C.ring_off[ln], v, norm_history(C, P, env, ln), false, 0, 0, &fs_touched);
+            if (ln < F) ok = feature_update<EXTRAS>(C.c.features[ln], fs, P.rings + (size_t)env * C.ring_words + C.ring_off[ln], v, norm_history(C, P, env, ln), false, 0, 0, &fs_touched, &need_norm);
 #endif
             if (ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
+            if constexpr (EXTRAS) if (!S.status) normalise_wave(L, C, P, env, fs, ballot(need_norm));
         }
         if (!S.status) {
             reward = step_reward<EXTRAS>(L, S, C, P, env, false, inv0, cash0, p0, price);
@@ -3108,13 +3313,13 @@ SDI void step_body(const DevCfg& C, const DevPtrs& P, const StepArgs& A) {
         for (int k = 0; k < 6; k++) P.prof[(size_t)env * 8 + k] += prof_t[k + 1] - prof_t[k];
         P.prof[(size_t)env * 8 + 6] += S.n_ops;
         P.prof[(size_t)env * 8 + 7] += 1;
-        uint64_t* ev = P.prof + (size_t)gridDim.x * 8 + (size_t)env * 16;  // event counts share the message-class block
+        uint64_t* ev = P.prof + (size_t)A.n_envs * 8 + (size_t)env * 16;  // event counts share the message-class block
 #ifndef LOBSIM_PROFILE_MSG
         ev[0] += S.ev_chunks; ev[1] += S.ev_compact; ev[2] += S.ev_ladder; ev[3] += S.ev_exec_levels; ev[4] += S.ev_rare; ev[5] += S.ev_serial_ops;
         for (int k = 0; k < 9; k++) ev[6 + k] += S.ev_x[k];
         ev[15] += S.t_after;
 #else
-        uint64_t* pm = P.prof + (size_t)gridDim.x * 8 + (size_t)env * 16;
+        uint64_t* pm = P.prof + (size_t)A.n_envs * 8 + (size_t)env * 16;
         for (int k = 0; k < 8; k++) { pm[k] += S.pm_cycles[k]; pm[8 + k] += S.pm_count[k]; }  // (in the place of the event counts)
 #endif
     }
@@ -3153,6 +3358,7 @@ SDI Act5 teradactyl_action(const double* p, double inventory) {
 template <bool EXTRAS>
 SDI void rollout_body(const DevCfg& C, const DevPtrs& P, const RolloutArgs& A) {
     __shared__ Lds L;
+    bounds_begin(C, P);
     const int env = A.order ? A.order[blockIdx.x] : (int)blockIdx.x, ln = lane();
     if (A.active && !A.active[env]) return;
     EnvHdr& H = P.hdr[env];
@@ -3204,14 +3410,18 @@ SDI void rollout_body(const DevCfg& C, const DevPtrs& P, const RolloutArgs& A) {
         if (UNLIKELY(S.status && !forward_returned)) portfolio_rollback(L, inv0, cash0);
         if (!S.status) {
             StepView v = make_view(L, S, price, now);
-            bool ok = true;
+            bool ok = true, need_norm = false;
+            FeatState fs = FeatState();
             if (ln < F) {
-                FeatState fs = P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln];
-                ok = feature_update<EXTRAS>(C.c.features[ln], fs, P.rings + (size_t)env * C.ring_words + C.ring_off[ln], v, norm_history(C, P, env, ln));
+                fs = P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln];
+                ok = feature_update<EXTRAS>(C.c.features[ln], fs, P.rings + (size_t)env * C.ring_words + C.ring_off[ln], v, norm_history(C, P, env, ln), false, 0, 0, nullptr, &need_norm);
+            }
+            if (ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
+            if constexpr (EXTRAS) if (!S.status) normalise_wave(L, C, P, env, fs, ballot(need_norm));
+            if (ln < F) {
                 P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln] = fs;
                 fval = fs.current_value;
             }
-            if (ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
         }
         if (!S.status) {
             reward = step_reward<EXTRAS>(L, S, C, P, env, false, inv0, cash0, p0, price);
@@ -3262,6 +3472,7 @@ SDI void rollout_body(const DevCfg& C, const DevPtrs& P, const RolloutArgs& A) {
 template <bool EXTRAS>
 SDI void reset_body(const DevCfg& C, const DevPtrs& P, const ResetArgs& A) {
     __shared__ Lds L;
+    bounds_begin(C, P);
     const int k = blockIdx.x, ln = lane();
     const int env = A.env_ids[k];
     EnvHdr& H = P.hdr[env];
@@ -3316,9 +3527,10 @@ SDI void reset_body(const DevCfg& C, const DevPtrs& P, const ResetArgs& A) {
         advance_one_step(L, S, C, P, stream_id, cursor, now, R, n_resyncs, price, false, fetch_messages(st, cursor), n_msgs_all);
         if (S.status) break;
         StepView v = make_view(L, S, price, now);
-        bool ok = true;
-        if (ln < F) ok = feature_update<EXTRAS>(C.c.features[ln], fs, ring, v, norm_history(C, P, env, ln));
+        bool ok = true, need_norm = false;
+        if (ln < F) ok = feature_update<EXTRAS>(C.c.features[ln], fs, ring, v, norm_history(C, P, env, ln), false, 0, 0, nullptr, &need_norm);
         if (ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
+        if constexpr (EXTRAS) if (!S.status) normalise_wave(L, C, P, env, fs, ballot(need_norm));
     }
     const size_t orow = A.rows_by_env ? (size_t)env : (size_t)k;
     if (ln < D && A.obs) A.obs[orow * D + ln] = ln < F ? fs.current_value : 0.0;  // zeros for the previous action (:158-159)
@@ -3338,37 +3550,61 @@ SDI void reset_body(const DevCfg& C, const DevPtrs& P, const ResetArgs& A) {
 // engine-level entry points (unit parity of Exchange.process_order)
 SDI void set_book_body(const DevCfg& C, const DevPtrs& P, int env, const int64_t* row, int64_t now_us) {
     __shared__ Lds L;
+    bounds_begin(C, P);
     EnvHdr& H = P.hdr[env];
     Scal S;
-    S.slots = env_slabs(P, env);
-    S.idc = P.idc + (size_t)env * IDC_N;
-    S.status = 0; S.n_ops = 0;
-    if (lane() == 0) { L.inv = H.inventory; L.cash = H.cash; }
-    ladder_clear(L, S, P);
-    clear_step_fills(L);
-    if (row) load_snapshot_book(L, S, row, C.c.n_levels, true);
+    // now_us >= 0: a fresh env without a stream (engine-level tests).  now_us == -1: the book of a simulator that HAS been reset is replaced
+    // (OrderbookSimulator.reset_episode(start_date, start_book), OrderbookSimulator.py:55-68: clock, stream and cursor stay what the reset
+    // made them, the initial price ranges are those of the new book).  now_us == -2: the book stays too - the ranges are worked out again
+    // (the orders a start book holds beyond its snapshot levels went in through lobsim_debug_process_orders in between).
+    const bool keep = now_us < 0;
+    if (now_us == -2) load_env(L, S, P, env, H);
+    else {
+        S.slots = env_slabs(P, env);
+        S.idc = P.idc + (size_t)env * IDC_N;
+        S.status = 0; S.n_ops = 0;
+        if (lane() == 0) { L.inv = H.inventory; L.cash = H.cash; }
+        ladder_clear(L, S, P);
+        clear_step_fills(L);
+        if (row) load_snapshot_book(L, S, row, C.c.n_levels, true);
+    }
+    Ranges R = {(double)INFINITY, 0.0, (double)INFINITY, (double)INFINITY};
+    double price = 0.0;
+    if (keep && !S.status) {  // _reset_initial_price_ranges (:185-188)
+        int64_t wb, ws;
+        if (price_range(L, S, wb, ws)) {
+            R.min_buy = (double)wb; R.max_sell = (double)ws;
+            R.init_buy = best_buy_d(L, S) - R.min_buy; R.init_sell = R.max_sell - best_sell_d(L, S);
+        } else S.status |= LOBSIM_ST_EMPTY_BOOK;
+        if (!S.status && !microprice(L, S, price)) price = 0.0;
+    }
     store_env(L, S, P, env, H);
     if (lane() == 0) {
-        H.now_us = now_us; H.terminal_us = INT64_MAX / 4; H.episode_start_us = now_us; H.msg_cursor = 0; H.stream_id = -1;
-        H.price = 0.0; H.n_resyncs = 0; H.min_buy = (double)INFINITY; H.max_sell = 0.0;
-        H.init_buy_range = (double)INFINITY; H.init_sell_range = (double)INFINITY; H.status = S.status & ~LOBSIM_ST_EMPTY_BOOK;
-        H.msgs = P.streams[0].msgs; H.n_msgs = 0;  // (no stream: the batch the step kernel reads unconditionally comes from a valid address and is masked)
+        if (!keep) {
+            H.now_us = now_us; H.terminal_us = INT64_MAX / 4; H.episode_start_us = now_us; H.msg_cursor = 0; H.stream_id = -1;
+            H.status = S.status & ~LOBSIM_ST_EMPTY_BOOK;
+            H.msgs = P.streams[0].msgs; H.n_msgs = 0;  // (no stream: the batch the step kernel reads unconditionally comes from a valid address and is masked)
+        }
+        H.price = price; H.n_resyncs = 0; H.min_buy = R.min_buy; H.max_sell = R.max_sell;
+        H.init_buy_range = R.init_buy; H.init_sell_range = R.init_sell;
     }
 }
 
-// one order row {type, side, price, volume (-1 none), id, is_external}; agent cancels address their target by FIFO rank
-// among the agent's orders at that price
+// one order row {type, side, price, volume (-1 none), id, who} (include/lobsim.h).  who = 1: an external order (id = external id).  who = 0:
+// the agent's - a limit order's id > 0 is the TAG the caller names it by (stored as the entry's submission sequence), a cancellation /
+// deletion addresses its target by FIFO rank among the agent's orders at that price.  who = 2: the agent's cancellation / deletion
+// naming its target by tag - the internal id the reference's Cancellation carries (Exchange.py:196-217) - found by a ballot over the table
 SDI void process_raw_order(Lds& L, Scal& S, const int64_t* r) {
     const int ln = lane();
     int type = (int)r[0], side = (int)r[1];
     int64_t price = r[2], vol = r[3], id = r[4];
-    bool is_ext = r[5] != 0;
+    const bool is_ext = r[5] == 1, by_tag = r[5] == 2;
     if (vol != -1 && !(vol > 0)) { S.status |= LOBSIM_ST_ASSERT; return; }
     if (is_ext) {
         if (type == LOBSIM_LIMIT) submit_limit(L, S, side, price, (int32_t)vol, false, id);
         else if (type == LOBSIM_MARKET) execute(L, S, side, false, true, 0, (int32_t)vol);
         else remove_order(L, S, side, price, K_EXT, id, (int32_t)vol);
-    } else if (type == LOBSIM_LIMIT) submit_limit(L, S, side, price, (int32_t)vol, true, 0);
+    } else if (type == LOBSIM_LIMIT) submit_limit(L, S, side, price, (int32_t)vol, true, id > 0 && id < 0x7fffffff ? id : 0);
     else if (type == LOBSIM_MARKET) execute(L, S, side, true, true, 0, (int32_t)vol);
     else {
         // rank -> agent index: the id-th oldest live agent order at (side, price)
@@ -3395,13 +3631,14 @@ SDI void process_raw_order(Lds& L, Scal& S, const int64_t* r) {
         }
         int aidx = NA + 1000;
 #pragma unroll
-        for (int k = AE - 1; k >= 0; k--) { const uint64_t hk = ballot(mt[k] && older[k] == id); if (hk) aidx = 64 * k + ffs64(hk); }
+        for (int k = AE - 1; k >= 0; k--) { const uint64_t hk = ballot(mt[k] && (by_tag ? (int64_t)q[k] == id : older[k] == id)); if (hk) aidx = 64 * k + ffs64(hk); }
         remove_order(L, S, side, price, K_AGENT, aidx, (int32_t)vol);
     }
 }
 
 SDI void process_orders_body(const DevCfg& C, const DevPtrs& P, int env, const int64_t* orders, int n, int64_t* fills_out) {
     __shared__ Lds L;
+    bounds_begin(C, P);
     EnvHdr& H = P.hdr[env];
     const int ln = lane();
     Scal S;
@@ -3426,6 +3663,7 @@ SDI void process_orders_body(const DevCfg& C, const DevPtrs& P, int env, const i
 // ranges reset, clock = start.  No features, no warm-up, no terminal time.
 SDI void sim_reset_body(const DevCfg& C, const DevPtrs& P, const ResetArgs& A) {
     __shared__ Lds L;
+    bounds_begin(C, P);
     const int k = blockIdx.x, ln = lane();
     const int env = A.env_ids[k];
     EnvHdr& H = P.hdr[env];
@@ -3471,6 +3709,7 @@ SDI void sim_reset_body(const DevCfg& C, const DevPtrs& P, const ResetArgs& A) {
 // written to obs: Feature.update as the reference's feature tests call it.
 SDI void forward_body(const DevCfg& C, const DevPtrs& P, const ForwardArgs& A) {
     __shared__ Lds L;
+    bounds_begin(C, P);
     const int k = blockIdx.x, ln = lane();
     const int env = A.env_ids[k];
     EnvHdr& H = P.hdr[env];
@@ -3508,14 +3747,18 @@ SDI void forward_body(const DevCfg& C, const DevPtrs& P, const ForwardArgs& A) {
         if (!microprice(L, S, price)) S.status |= LOBSIM_ST_EMPTY_BOOK;
         if (!S.status) {
             StepView v = make_view(L, S, price, now);
-            bool ok = true;
+            bool ok = true, need_norm = false;
+            FeatState fs = FeatState();
             if (ln < F) {
-                FeatState fs = P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln];
-                ok = feature_update<true>(C.c.features[ln], fs, P.rings + (size_t)env * C.ring_words + C.ring_off[ln], v, norm_history(C, P, env, ln));
+                fs = P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln];
+                ok = feature_update<true>(C.c.features[ln], fs, P.rings + (size_t)env * C.ring_words + C.ring_off[ln], v, norm_history(C, P, env, ln), false, 0, 0, nullptr, &need_norm);
+            }
+            if (ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
+            if (!S.status && P.norm) normalise_wave(L, C, P, env, fs, ballot(need_norm));
+            if (ln < F) {
                 P.feat[(size_t)env * LOBSIM_MAX_FEATURES + ln] = fs;
                 val = fs.current_value;
             }
-            if (ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
         }
     }
     if (A.obs && ln < D) A.obs[(size_t)k * D + ln] = ln < F ? val : 0.0;
@@ -3528,6 +3771,7 @@ SDI void forward_body(const DevCfg& C, const DevPtrs& P, const ForwardArgs& A) {
 // are live from the next forward step on, no warm-up (rl4mm/features/tests/testFeatures.py resets its features like this)
 SDI void features_reset_body(const DevCfg& C, const DevPtrs& P, const int32_t* env_ids) {
     __shared__ Lds L;
+    bounds_begin(C, P);
     const int env = env_ids[blockIdx.x], ln = lane();
     EnvHdr& H = P.hdr[env];
     const int F = C.c.n_features;
@@ -3547,7 +3791,8 @@ SDI void features_reset_body(const DevCfg& C, const DevPtrs& P, const int32_t* e
         }
         if (ballot(!ok)) S.status |= LOBSIM_ST_EMPTY_BOOK;
     }
-    if (ln == 0) { H.price = price; H.status = S.status; }
+    const int bst = bounds_status();
+    if (ln == 0) { H.price = price; H.status = S.status | bst; }
 }
 
 };  // struct Eng
@@ -3570,7 +3815,12 @@ SDI void features_reset_body(const DevCfg& C, const DevPtrs& P, const int32_t* e
 constexpr int step_waves(int lvt, int na, bool extras) { return lvt == 64 ? (extras ? 4 : LOBSIM_STEP_WAVES) : (na == 128 ? LOBSIM_STEP_WAVES_DEEP : 3); }
 constexpr int other_waves(int lvt, int na) { return lvt == 64 ? 4 : (na == 128 ? LOBSIM_STEP_WAVES_DEEP : 3); }
 template <bool EXTRAS, int LVT, int NAT, bool SPEC = false>
-__global__ __launch_bounds__(64, step_waves(LVT, NAT, EXTRAS)) void lob_step_kernel(DevCfg C, DevPtrs P, StepArgs A) { Eng<LVT, SPEC, false, NAT>::template step_body<EXTRAS>(C, P, A); }
+__global__ __launch_bounds__(64, step_waves(LVT, NAT, EXTRAS)) void lob_step_kernel(DevCfg C, DevPtrs P, StepArgs A) {
+    typedef Eng<LVT, SPEC, false, NAT> E;
+    static_assert(sizeof(typename E::Lds) >= 1024 + 6000, "sorter scratch: 256 counters + a key byte per env of a class (lobsim_create: lpt)");
+    if (UNLIKELY(LOBSIM_LPT && A.order_next && blockIdx.x < (unsigned)LPT_CLASSES)) { E::lpt_sort((typename E::LdsI32)0, P.hdr, P.streams, C.c.step_us, A.order_next, A.n_envs); return; }  // (LDS offset 0: the kernel's own block, unused by a sorter wave)
+    E::template step_body<EXTRAS>(C, P, A);
+}
 template <bool EXTRAS, int LVT, int NAT, bool SPEC = false>
 __global__ __launch_bounds__(64, LVT == 64 ? LOBSIM_ROLLOUT_WAVES : other_waves(LVT, NAT)) void lob_rollout_kernel(DevCfg C, DevPtrs P, RolloutArgs A) { Eng<LVT, SPEC, false, NAT>::template rollout_body<EXTRAS>(C, P, A); }
 template <bool EXTRAS, int LVT, int NAT>
@@ -3592,7 +3842,7 @@ __global__ __launch_bounds__(64) void lob_features_reset_kernel(DevCfg C, DevPtr
 // What the host side needs to launch the kernels of one (ladder width, agent table) combination.  The library is built from several
 // translation units in parallel (rl4mm_amd/_lib.py: -DLOBSIM_PART=k), one per combination plus the host part; each defines the
 // launch table of its combination, the host part only sees the declarations.  Compiled without LOBSIM_PART this file is the
-// whole library in one unit (tools/build_variant.sh and the diagnostic builds do that).
+// whole library in one unit (tools/isa_census.py's listings; tools/build_variant.sh and the diagnostic builds go through the same five-part build as the product).
 struct LaunchCtx {
     const DevCfg* cfg; const DevPtrs* ptrs; hipStream_t stream;
     bool spec;          // the cfg is the reference's default configuration: kernels with its constants folded (Eng<LVT, true>)
@@ -3683,6 +3933,13 @@ __global__ void lob_gather_best_prices_kernel(DevPtrs P, int n, int64_t* best_bu
     if (i >= n) return;
     best_buy[i] = P.hdr[i].n_lv[0] > 0 ? P.ladder[i].price[0][0] : 0;
     best_sell[i] = P.hdr[i].n_lv[1] > 0 ? P.ladder[i].price[1][0] : INT64_MAX;
+}
+
+// the clocks of the listed envs (lobsim_forward checks `until` against them before it launches); INT64_MIN for an env that has stopped - its
+// clock no longer matters, the forward kernel leaves it alone
+__global__ void lob_gather_now_kernel(DevPtrs P, const int32_t* ids, int n, int64_t* now) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) now[i] = P.hdr[ids[i]].status ? INT64_MIN : P.hdr[ids[i]].now_us;
 }
 
 __global__ void lob_init_hdr_kernel(DevPtrs P, int n) {

@@ -10,7 +10,7 @@
 //                               every level that left LOBSTER's visible range): a ring per side, best-first from its front
 //   hi_free[..]                 free masks of the slabs whose mask is not in the header (lobsim_layout.h: HiWords)
 //   Slot pages[n_pages][64]     the slab pool in 1 KiB pages.  One slab per price level = that level's FIFO queue, CONTIGUOUS, in one
-//                               of three sizes - 1, 4 or 16 pages = 64 / 256 / 1024 slots; a level starts in the smallest and moves
+//                               of four sizes - 1, 4, 16 or 64 pages = 64 / 256 / 1024 / 4096 slots; a level starts in the smallest and moves
 //                               to a larger one when it outgrows its slab (rare: make_room).  Slot index = time priority; removed
 //                               orders leave tombstones, squeezed out once LOBSIM_TOMB of them have piled up (or the slab is
 //                               full), so a scan touches ceil((live+tombstones)/64) chunks
@@ -28,15 +28,17 @@ namespace lobk {
 
 constexpr int WAVE = 64;
 constexpr int LV = 128;          // price levels per side of the NEAR ladder (the part of a side an env keeps in LDS; 2 per lane)
-// The slab of a level: a contiguous run of 1 KiB pages (64 slots of 16 B: one wave-load) in the env's pool, in one of three size
-// classes.  Slab id (the 16-bit field of a level's meta word, of a position-cache entry) = class << 14 | first page: a slot's address
+// The slab of a level: a contiguous run of 1 KiB pages (64 slots of 16 B: one wave-load) in the env's pool, in one of four size
+// classes (round 6 added the 64-page class: all four values of the 2-bit field are in use).  Slab id (the 16-bit field of a level's meta word, of a position-cache entry) = class << 14 | first page: a slot's address
 // is a function of the meta word alone - no table in between - and the class says how many slots the level may use.  Until round 5
 // every level owned a fixed 16 KiB slab (16.5 MB of device memory per env at the default level budget, ~400 x what a day's live orders
 // take); now a level takes 1 KiB while it is thin - the hundreds of stale levels a drifting day leaves behind hold an order or two -
 // and only the levels that really hold hundreds of orders take 16 KiB.
 constexpr int PAGE_SLOTS = 64;
 constexpr int SLAB_CLASS_SHIFT = 14, SLAB_PAGE_MASK = (1 << SLAB_CLASS_SHIFT) - 1;
-constexpr int SLOTS = PAGE_SLOTS << 4;  // order slots of the largest class = the most live orders + tombstones one price can hold (1024)
+constexpr int SLAB_CLASS_MAX = 3;  // 64 << 2 * class slots: 64 / 256 / 1024 / 4096
+constexpr int SLOTS = PAGE_SLOTS << (2 * SLAB_CLASS_MAX);  // order slots of the largest class = the most live orders + tombstones one price can hold (4096; 1024 until round 6)
+constexpr int FLAT_SLOTS = PAGE_SLOTS << 4;  // (-DLOBSIM_FLAT_SLABS diagnostic builds: round 4's fixed 16 KiB slab per level)
 constexpr int NSLAB = 2 * LV;    // class-0 slabs whose free mask lives in the header / in LDS (the first ones handed out): slab id = page < NSLAB
 // Levels beyond the near ladder ("far" levels: the worse end of a side) live in HBM, one ring per side that is ordered
 // best-first from its front: the level next to the near ladder's worst is at `front`, the k-th best far level at
@@ -46,14 +48,15 @@ constexpr int NSLAB = 2 * LV;    // class-0 slabs whose free mask lives in the h
 constexpr int FAR_CAP = 2048;
 constexpr int NSLAB_MAX = NSLAB + 64 * 64;  // the free mask of the class-0 slabs beyond NSLAB is one 64-bit word per lane
 // free masks in HBM (u64 words of the env's aux block) of the buddy pool behind the first NSLAB pages: blocks of 1 page (class 0), 4
-// pages (class 1), 16 pages (class 2), bit b of a size's mask = block b of that size; and the env's counts (level budget | 16-page
-// blocks << 32: the cold routines read them here instead of carrying them in registers)
-constexpr int HI_W0 = 0, HI_W1 = 64, HI_W2 = 80, HI_COUNTS = 84;
-constexpr int NMID_MAX = 16 * 64, NBIG_MAX = 4 * 64;
+// pages (class 1), 16 pages (class 2), 64 pages (class 3), bit b of a size's mask = block b of that size (block b of class c = pages
+// NSLAB + b * 4^c ...); and the env's counts (level budget | 16-page blocks << 32: the cold routines read them here instead of carrying
+// them in registers)
+constexpr int HI_W0 = 0, HI_W1 = 64, HI_W2 = 80, HI_W3 = 84, HI_COUNTS = 85;
+constexpr int NMID_MAX = 16 * 64, NBIG_MAX = 4 * 64, NHUGE_MAX = 64;
 struct alignas(16) FarLevel { int64_t price; uint64_t meta; int64_t vol; int64_t pad; };  // meta as in Ladder
 static_assert(sizeof(FarLevel) == 32, "");
 constexpr size_t FAR_BYTES = 2 * (size_t)FAR_CAP * sizeof(FarLevel);
-constexpr size_t HI_BYTES = 1024;                  // hi_free[128] u64 (85 used; pages stay 1 KiB-aligned)
+constexpr size_t HI_BYTES = 1024;                  // hi_free[128] u64 (86 used; pages stay 1 KiB-aligned)
 constexpr size_t AGHI_BYTES = 3072;                // the agent-order entries beyond the 128 that are staged on chip: AgentOrd[128] (2048 B), then their slot indices u16[128]
 constexpr size_t AUX_BYTES = FAR_BYTES + AGHI_BYTES + HI_BYTES;  // per env, in front of its pages: far rings, upper agent entries, hi_free
 // Agent orders per env (live ones + those freed in the current step): a property of the HANDLE since round 5 (cfg.agent_orders), the
@@ -74,6 +77,8 @@ constexpr int QMAX = 32;         // quote levels per side (2 * QMAX <= 64 lanes)
 // <= 2 x (100 + Q/2) cancellations of one-share orders + 2Q limits + the clearing order for up to 28 quote levels (the default has 10; the
 // table itself is provably large enough for up to 18).  Beyond: LOBSIM_ST_AGENT_OVERFLOW
 constexpr int na_ops_max(int na) { return na == 128 ? 2 * QMAX + 128 + 8 : 286; }
+
+constexpr int LPT_CLASSES = 16;  // sorter waves at the head of a step launch = residue classes of the envs (lobsim_kernels.hip: lpt_sort_body)
 
 constexpr int64_t DUMMY_PRICE = 9999999999ll;
 
@@ -146,7 +151,10 @@ struct StreamDev {
     int64_t n_msgs, n_snaps;
     int64_t first_sec;
     int32_t n_secs;
-    int32_t pad;
+    int32_t n_win;               // entries of wtab
+    // weight of every window of one step of this stream: window g = (first_sec s + g step, first_sec s + (g + 1) step], messages in it +
+    // 8 x runs of executions, capped at 255 (built by lobsim_add_stream; read by the step launch's sorter waves: longest job first)
+    const uint8_t* wtab;
 };
 
 struct DevCfg {

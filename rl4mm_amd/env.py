@@ -495,7 +495,11 @@ class _StreamResidency:
                 break
             if key in in_use:
                 continue
-            self.sim.drop_stream(self.sid.pop(key))
+            try:  # (the bookkeeping follows the device: a stream the library refuses to drop - an env's last reset still names it - stays tracked)
+                self.sim.drop_stream(self.sid[key])
+            except _capi.LobsimError:
+                continue
+            del self.sid[key]
             total -= self.bytes.pop(key)
             del self.last_use[key]
             self.drops += 1
@@ -791,13 +795,15 @@ class HistoricalOrderbookVectorEnv(_RayVectorEnv):
         if missing:
             raise KeyError(f"no packed stream loaded for {missing[0]}")
         sid = self._residency.ensure(sorted(set(keys)))
-        for e, k in zip(ids, keys):
-            self._env_key[int(e)] = k
         self.last_draw = (ids.copy(), keys, start_us.copy())
         return np.array([sid[k] for k in keys], dtype=np.int32), start_us
 
     def _after_reset(self):
-        """the device has moved the envs onto their new streams: days nobody replays any more may leave it (stream_budget_mb)"""
+        """the device has moved the envs onto their new streams - only now does the bookkeeping follow (a reset that raised leaves every
+        env on the stream the library still has it on) - and days nobody replays any more may leave the device (stream_budget_mb)"""
+        if self.last_draw is not None:
+            for e, k in zip(self.last_draw[0], self.last_draw[1]):
+                self._env_key[int(e)] = k
         self._residency.trim({k for k in self._env_key if k is not None})
 
     # ---- errors --------------------------------------------------------------------------------------------------
@@ -817,7 +823,7 @@ class HistoricalOrderbookVectorEnv(_RayVectorEnv):
             parts.append("LOBSIM_ST_LEVEL_OVERFLOW: more price levels than the env's budget (max_levels; the reference never drops a level that left "
                          "LOBSTER's visible range: one stale level per tick of price drift) - pass a larger max_levels (up to 2048) or shorten the episode")
         if status & _capi.ST_QUEUE_OVERFLOW:
-            parts.append("LOBSIM_ST_QUEUE_OVERFLOW: more live orders at one price than a level's queue holds (lobsim_limits.queue_slots: 1024 - or 64 / 256 with the env's queue_pages used up)")
+            parts.append("LOBSIM_ST_QUEUE_OVERFLOW: more live orders at one price than a level's queue holds (lobsim_limits.queue_slots: 4096 - or 64 / 256 / 1024 with the env's queue_pages used up)")
         if status & _capi.ST_AGENT_OVERFLOW:
             parts.append("LOBSIM_ST_AGENT_OVERFLOW: more live agent orders than the env's table holds (agent_orders=128 was asked for - the default of 256 cannot overflow for up to 18 quote levels; entries freed in a step are reusable from the next one)")
         if status & _capi.ST_STREAM_END:
@@ -1115,7 +1121,7 @@ def env_creator(env_config: dict, catalog: StreamCatalog = None, num_envs: Optio
         terminal_reward_function=get_reward_function(env_config["terminal_reward_function"]),
         market_order_clearing=env_config["market_order_clearing"], market_order_fraction_of_inventory=env_config["market_order_fraction_of_inventory"],
         concentration=env_config["concentration"], min_quote_level=env_config["min_quote_level"], max_quote_level=env_config["max_quote_level"],
-        enter_spread=env_config["enter_spread"], info_calculator=env_config.get("info_calculator"), n_levels=env_config["n_levels"],
+        enter_spread=env_config["enter_spread"], info_calculator=env_config["info_calculator"], n_levels=env_config["n_levels"],  # (a required key, as in rl4mm/gym/utils.py:81)
     )  # fmt: skip
     dev = env_config.get("device_id")
     kw["device_id"] = default_device_id(env_config) if dev is None else int(dev)

@@ -14,10 +14,11 @@ snapshots decoded from device state when asked for.  There is no CPU path: witho
 What differs from the reference, by construction:
 * the data source is a ``StreamCatalog`` / ``PackedStream`` (rl4mm_amd/stream.py) where the reference takes a ``HistoricalDatabase``;
   ``order_generators`` is accepted and ignored (the packed stream IS the historical order generator's output);
-* the agent's orders are identified by ``internal_id`` as in the reference (``forward_step`` assigns one to every LimitOrder it
-  books and the agent cancels by it); the library addresses an agent order by its FIFO rank at its price, this class keeps the
-  map.  A cancellation in the same ``forward_step`` call as an own order that could sweep the agent's other orders (a
-  self-crossing order) is refused: the rank of the target is then not knowable on the host - submit them in separate calls;
+* the agent's orders are identified by ``internal_id`` as in the reference: ``forward_step`` gives every LimitOrder it submits the next
+  id (ascending in submission order, like OrderIDConvertor.py:12-19), the library files the order under it (``lobsim_order_view.reserved``)
+  and finds the target of a Cancellation / Deletion by it on the device (round 6; until then the host turned ids into FIFO ranks and had to
+  refuse the calls in which it could not know them).  The outer-level resync re-adds the agent's orders of a level under FRESH ids, as the
+  reference does (OrderbookSimulator.py:114-129 re-submits them): read them from ``exchange.internal_orderbook`` like the reference's env does;
 * ``FilledOrders.internal`` entries are ``LimitOrder`` records (direction, price, volume) for resting fills and aggressing fills
   alike - the reference makes the latter ``MarketOrder`` copies with a price; every consumer reads direction / price / volume.
 """
@@ -214,7 +215,7 @@ class OrderbookSimulator:
         self._stream_ids: Dict[str, int] = {}
         self._day0: Optional[datetime] = None
         self._next_internal_id = 0
-        self._agent: Dict[Tuple[int, int], List[List[int]]] = {}  # (side, price) -> [[internal_id, volume], ...] in queue order
+        self._n_resyncs = 0
 
     # ---- data ---------------------------------------------------------------------------------------------------
     def _stream_for(self, day: datetime) -> int:
@@ -232,18 +233,46 @@ class OrderbookSimulator:
 
     # ---- OrderbookSimulator.py:55-68 ------------------------------------------------------------------------------
     def reset_episode(self, start_date: datetime, start_book: Optional[Orderbook] = None) -> Orderbook:
-        if start_book is not None:
-            raise NotImplementedError("start_book: the book of an episode is the stream's snapshot (lobsim_debug_set_book takes an explicit one)")
         assert start_date.microsecond == 0, "Episodes must be started on the second."
         self._day0 = datetime(start_date.year, start_date.month, start_date.day)
         sid = self._stream_for(self._day0)
         self.sim.reset_episode(self._us(start_date), sid)
         st = self._state()
         assert not (st["status"] & _capi.ST_STREAM_END), f"There is no data before the episode start time: {start_date}"
+        if start_book is not None:
+            self._install_book(start_book)
+            st = self._state()
         self._raise_on_status(st["status"])
         self.now_is = start_date
-        self._agent = {}
+        self._next_internal_id = 0
+        self._n_resyncs = 0
         return self.exchange.central_orderbook
+
+    def _install_book(self, book: Orderbook):
+        """``self.exchange.central_orderbook = start_book`` (:58) + ``_reset_initial_price_ranges`` (:185-188): a level whose first order is a
+        snapshot order (``internal_id == -1``: what get_historical_start_book builds, :156-175) goes to the device as that; every other order
+        of the book follows in queue order as an external limit order under an id no later message can name (the reference's id map knows
+        nothing of a start book's orders either: OrderIDConvertor.py:7-37) - or as the agent's own when ``is_external`` is false."""
+        L = self.n_levels
+        row = np.zeros(4 * L, dtype=np.int64)  # sell_p, sell_v, buy_p, buy_v per level; price 0 = absent
+        extra = []
+        fake_id = -(1 << 40)
+        for side, levels, col in ((1, book.sell, 0), (0, book.buy, 2)):
+            prices = sorted(levels, reverse=(side == 0))
+            if len(prices) > L:
+                raise ValueError(f"start_book holds {len(prices)} {SIDE_NAME[side]} levels, the simulator was made for n_levels={L}")
+            for i, p in enumerate(prices):
+                q = list(levels[p])
+                if q and q[0].internal_id == -1:
+                    row[4 * i + col], row[4 * i + col + 1] = int(p), int(q[0].volume)
+                    q = q[1:]
+                for o in q:
+                    fake_id -= 1
+                    extra.append((1, side, int(p), int(o.volume), fake_id if o.is_external else 0, 1 if o.is_external else 0))
+        self.sim.debug_set_book(0, row, -1)
+        if extra:
+            self.sim.debug_process_orders(0, np.array(extra, dtype=np.int64))
+            self.sim.debug_set_book(0, None, -2)
 
     # ---- OrderbookSimulator.py:70-88 ------------------------------------------------------------------------------
     def forward_step(self, until: datetime, internal_orders: Optional[List[Order]] = None) -> FilledOrders:
@@ -253,7 +282,10 @@ class OrderbookSimulator:
         st = self._state()
         self._raise_on_status(st["status"])
         self.now_is = until
-        self._reconcile_agent_orders()
+        if st["n_resyncs"] != self._n_resyncs:  # the resync re-added the agent's orders of the levels it replaced under fresh ids, taken from the
+            self._n_resyncs = st["n_resyncs"]   # device's counter: the ids this class hands out next must lie beyond them
+            tags = [int(o["reserved"]) for side in (0, 1) for p in self.sim.book(0, side, 4096)[0] for o in self.sim.level_orders(0, side, int(p), 4096) if o["kind"] == 1]
+            self._next_internal_id = max([self._next_internal_id] + tags)
         filled = FilledOrders()
         for lst, side, price, vol in self.sim.fills(0):
             o = LimitOrder(timestamp=until, direction=SIDE_NAME[side], ticker=self.ticker, internal_id=None, external_id=None, is_external=bool(lst),
@@ -299,80 +331,45 @@ class OrderbookSimulator:
             raise RuntimeError(f"simulator stopped with status {status} (include/lobsim.h: enum lobsim_status)")
 
     def _rows_of(self, orders: List[Order]) -> np.ndarray:
-        """Internal orders -> rows of lobsim_forward; assigns internal ids to new limit orders and turns the internal id a
-        cancellation names into the FIFO rank of its target among the agent's orders at that price."""
+        """Internal orders -> rows of lobsim_forward {type, side, price, volume, id, who} (include/lobsim.h).  A new limit order gets the next
+        internal id and is filed under it on the device; a Cancellation / Deletion carries the internal id it names (who = 2: the device
+        looks the order up) - also one that names an order of this very call, one the call's own orders may have swept, or one that never
+        rested: the list is processed in order on the device, as Exchange.process_order does (Exchange.py:58-69)."""
         rows = []
-        may_have_swept_own = False
-        marketable = set()  # (side, price) of this call's own limit orders that cross the touch: the device may fill them (in part) on arrival
-        st = self._state() if any(isinstance(o, Deletion) for o in orders) else None
         for o in orders:
             assert not o.is_external, "internal_orders are the agent's own orders (historical messages come from the packed stream)"
             side = SIDE[o.direction]
             if isinstance(o, LimitOrder):
-                opp_live = any(s == 1 - side and (p <= o.price if side == 0 else p >= o.price) for (s, p), q in self._agent.items() if q)
-                may_have_swept_own = may_have_swept_own or opp_live
-                if st is not None and ((side == 0 and o.price >= st["best_sell"]) or (side == 1 and o.price <= st["best_buy"])):
-                    marketable.add((side, int(o.price)))
                 self._next_internal_id += 1
                 o.internal_id = self._next_internal_id
-                self._agent.setdefault((side, int(o.price)), []).append([o.internal_id, int(o.volume)])
-                rows.append((_capi_type("limit"), side, int(o.price), int(o.volume), 0, 0))
+                rows.append((_capi_type("limit"), side, int(o.price), int(o.volume), o.internal_id, 0))
             elif isinstance(o, MarketOrder):
-                may_have_swept_own = may_have_swept_own or any(s == 1 - side and q for (s, _), q in self._agent.items())
                 rows.append((_capi_type("market"), side, 0, int(o.volume), 0, 0))
             elif isinstance(o, Deletion):  # Cancellation is a Deletion
-                if may_have_swept_own:
-                    raise NotImplementedError("a cancellation after a self-crossing own order in one forward_step call: submit them in separate calls")
-                if (side, int(o.price)) in marketable:
-                    # (the marketable order may never rest, or rest with less volume: the FIFO rank the host would name is not the device's)
-                    raise NotImplementedError("a cancellation at the price of a marketable own limit order of the same forward_step call: submit them in separate calls")
-                q = self._agent.get((side, int(o.price)), [])
-                rank = next((i for i, e in enumerate(q) if e[0] == o.internal_id), None)
                 typ = _capi_type("cancellation" if isinstance(o, Cancellation) else "deletion")
-                if rank is None:  # not one of the agent's live orders: the reference warns and moves on (Exchange.py:128-139)
-                    rows.append((typ, side, int(o.price), -1 if o.volume is None else int(o.volume), 1 << 30, 0))
-                    continue
-                vol = q[rank][1] if o.volume is None else min(int(o.volume), q[rank][1])
-                q[rank][1] -= vol
-                if q[rank][1] == 0:
-                    q.pop(rank)
-                rows.append((typ, side, int(o.price), -1 if o.volume is None else int(o.volume), rank, 0))
+                iid = o.internal_id if (o.internal_id is not None and 0 < o.internal_id < (1 << 31) - 1) else (1 << 31) - 1  # (None / -1: names no order)
+                rows.append((typ, side, int(o.price), -1 if o.volume is None else int(o.volume), int(iid), 2))
             else:
                 raise TypeError(f"unsupported internal order {type(o).__name__}")
         return np.array(rows, dtype=np.int64).reshape(-1, 6)
 
-    def _reconcile_agent_orders(self):
-        """After a step: fills (and sweeps of own orders) consume the agent's orders at a price from the front, the resync
-        re-queues them in order - so what is left at a price are the LAST entries of the host's list, with the device's volumes."""
-        q = self.sim.queues(0)
-        live: Dict[Tuple[int, int], List[int]] = {}
-        for side, price, kind, _rank, vol in q:
-            if kind == 1:
-                live.setdefault((int(side), int(price)), []).append(int(vol))
-        new = {}
-        for key, vols in live.items():
-            mine = self._agent.get(key, [])
-            assert len(mine) >= len(vols), "agent order bookkeeping out of step with the device"
-            keep = mine[len(mine) - len(vols) :]
-            new[key] = [[iid, v] for (iid, _), v in zip(keep, vols)]
-        self._agent = new
-
     def _read_book(self, internal: bool) -> Orderbook:
-        q = self.sim.queues(0)
         day0 = self._day0 or datetime(2000, 1, 1)
         sides = ({}, {})
-        for side, price, kind, oid, vol in q:
-            side, price, kind = int(side), int(price), int(kind)
-            if internal and kind != 1:
-                continue
-            if kind == 1:
-                iid = self._agent.get((side, price), [])
-                iid = iid[int(oid)][0] if int(oid) < len(iid) else None
-                o = LimitOrder(timestamp=self.now_is, direction=SIDE_NAME[side], ticker=self.ticker, internal_id=iid, external_id=None, is_external=False, price=price, volume=int(vol))
-            else:  # tracked external order (kind 0) or snapshot aggregate (kind 2: internal_id == -1, external)
-                o = LimitOrder(timestamp=day0, direction=SIDE_NAME[side], ticker=self.ticker, internal_id=-1 if kind == 2 else None,
-                               external_id=None if kind == 2 else int(oid), is_external=True, price=price, volume=int(vol))  # fmt: skip
-            sides[side].setdefault(price, []).append(o)
+        for side in (0, 1):
+            for price in self.sim.book(0, side, 4096)[0]:
+                price = int(price)
+                for ov in self.sim.level_orders(0, side, price, 4096):
+                    kind, vol = int(ov["kind"]), int(ov["volume"])
+                    if internal and kind != 1:
+                        continue
+                    if kind == 1:  # (the order's tag on the device IS its internal id)
+                        o = LimitOrder(timestamp=self.now_is, direction=SIDE_NAME[side], ticker=self.ticker, internal_id=int(ov["reserved"]), external_id=None,
+                                       is_external=False, price=price, volume=vol)  # fmt: skip
+                    else:  # tracked external order (kind 0) or snapshot aggregate (kind 2: internal_id == -1, external)
+                        o = LimitOrder(timestamp=day0, direction=SIDE_NAME[side], ticker=self.ticker, internal_id=-1 if kind == 2 else None,
+                                       external_id=None if kind == 2 else int(ov["id"]), is_external=True, price=price, volume=vol)  # fmt: skip
+                    sides[side].setdefault(price, []).append(o)
         return Orderbook(buy=_sorted(sides[0]), sell=_sorted(sides[1]), ticker=self.ticker, tick_size=100)
 
 

@@ -129,9 +129,18 @@ def draw_case(seed: int, n: int):
     # SimpleInfoCalculator's arrays written by the step kernel's epilogue (lobsim_set_info_buffer) against the package's host mirror of
     # the calculator working on the ORACLE's state (InfoCalculators.py:17-89); the kernel takes the env's own quote range, so level 0 up
     with_info = (not chunk) and (not masked) and minq == 0 and r2.random() < 0.35
-    desc = dict(kw, n_levels=n_levels, rate=rate, feats=[(f.kind, f.lookback, f.update_us, f.norm_len) for f in feats], amax=amax, ep_steps=ep_steps, chunk=chunk, bad_msgs=bad_msgs,
+    # round 6 dimensions (a generator of their own again): how the step is CALLED - the host-pointer entry (lobsim_step), the pinned
+    # host-io entry with f32 observations (lobsim_step_host_io), or the device entry a torch learner uses (lobsim_step_device: device
+    # buffers, f32 observations) - resets through lobsim_reset_device (first observations into the caller's device buffers, done flags
+    # cleared on the device), and a day that leaves the device and comes back while no env replays it (lobsim_drop_stream: the stream
+    # budget of the Python env evicts like that)
+    r3 = np.random.Generator(np.random.PCG64(290_000 + seed))
+    call = "host" if (chunk or masked or with_info) else str(r3.choice(["host", "host_io_f32", "device_f32"]))
+    reset_dev = (not chunk) and bool(r3.random() < 0.4)
+    evict = len(streams) > 1 and bool(r3.random() < 0.5)
+    desc = dict(kw, call=call, reset_dev=reset_dev, evict=evict, n_levels=n_levels, rate=rate, feats=[(f.kind, f.lookback, f.update_us, f.norm_len) for f in feats], amax=amax, ep_steps=ep_steps, chunk=chunk, bad_msgs=bad_msgs,
                 sharpe=sharpe, normalised=int(sum(f.norm_len > 0 for f in feats)), days=len(streams), policy=policy[0], masked=masked, drift=drift, with_info=with_info)
-    extra = dict(streams=streams, policy=policy, masked=masked, r2=r2, with_info=with_info)
+    extra = dict(streams=streams, policy=policy, masked=masked, r2=r2, with_info=with_info, call=call, reset_dev=reset_dev, evict=evict, r3=r3)
     return cfg, extra, starts, amax, ep_steps, desc, r, (first, total_s - warm_s - episode_us // 1_000_000 - 6), chunk
 
 
@@ -152,7 +161,52 @@ def _rollout(sim, acts, policy=(_capi.POLICY_GIVEN, [])):
     return obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy(), (steps.cpu().numpy(), ret.cpu().numpy())
 
 
-def run_case(seed: int, n: int):
+class _DeviceIO:
+    """The step / reset entries a caller with device or pinned memory uses, for run_case: `device_f32` = lobsim_step_device with torch tensors
+    (f32 observations), `host_io_f32` = lobsim_step_host_io on the handle's pinned buffers (f32 observations), `host` = lobsim_step (only
+    the resets go through lobsim_reset_device then)."""
+
+    def __init__(self, sim, n, A, call):
+        import torch
+
+        self.torch, self.call, self.n, self.A = torch, call, n, A
+        self.f32 = call != "host"
+        dev = torch.device("cuda", 0)
+        D = sim.obs_dim
+        self.act = torch.zeros((n, A), dtype=torch.float64, device=dev)
+        self.obs = torch.zeros((n, D), dtype=torch.float64, device=dev)
+        self.obs32 = torch.zeros((n, D), dtype=torch.float32, device=dev)
+        self.rew = torch.zeros(n, dtype=torch.float64, device=dev)
+        self.done = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self.io = sim.host_io() if call == "host_io_f32" else None
+
+    def step(self, sim, act, active=None):
+        if self.call == "host":
+            return sim.step(act, active)
+        if self.call == "host_io_f32":
+            self.io["actions"][:, : self.A] = act
+            sim.step_host_io(False, 2)
+            return self.io["obs_f32"].astype(np.float64), self.io["reward"].copy(), self.io["done"].copy()
+        self.act.copy_(self.torch.from_numpy(np.ascontiguousarray(act)))
+        self.torch.cuda.synchronize()
+        sim.step_device(self.act.data_ptr(), 0, 0, self.obs32.data_ptr(), self.rew.data_ptr(), self.done.data_ptr(), 0)
+        sim.sync()
+        return self.obs32.cpu().numpy().astype(np.float64), self.rew.cpu().numpy(), self.done.cpu().numpy()
+
+    def reset(self, sim, starts, sids, ids):
+        """lobsim_reset_device: the observations land in the rows of the reset envs, their done flags are cleared on the device."""
+        self.done.fill_(1)
+        self.torch.cuda.synchronize()
+        sim.reset_device(starts, sids, ids, 0 if self.f32 else self.obs.data_ptr(), self.obs32.data_ptr() if self.f32 else 0, self.done.data_ptr())
+        sim.sync()
+        d = self.done.cpu().numpy()
+        assert not d[ids].any() and d[np.setdiff1d(np.arange(self.n), ids)].all(), "reset_device must clear the done flags of exactly the envs it reset"
+        o = (self.obs32 if self.f32 else self.obs).cpu().numpy().astype(np.float64)
+        return o[ids]
+
+
+def run_case(seed: int, n: int, new_gpu=None):
+    """`new_gpu(cfg)`: the handle under test (default: the product library; tests/test_gpu_bounds.py passes the bounds build)."""
     cfg, extra, starts, amax, ep_steps, desc, r, (first, span), chunk = draw_case(seed, n)
     streams, policy, masked, r2 = extra["streams"], extra["policy"], extra["masked"], extra["r2"]
     sids = r2.integers(0, len(streams), size=n).astype(np.int32)
@@ -161,7 +215,7 @@ def run_case(seed: int, n: int):
     # both from the reference's numpy: 4.4e-8 on the recorded trajectory, tests/test_gpu_parity.py) show at 1e-6 in the ratio.  That is
     # the formula's conditioning, not a difference of the paths: every other reward is compared to 1e-9 absolute
     r_rtol, r_atol = (1e-5, 1e-6) if desc["sharpe"] else (0.0, ATOL)
-    gpu, cpu = (ol.oracle_sim(cfg) if os.environ.get("FUZZ_SELF") else _lib.new_sim(cfg)), ol.oracle_sim(cfg)  # (FUZZ_SELF=1: the harness against itself, no GPU)
+    gpu, cpu = (ol.oracle_sim(cfg) if os.environ.get("FUZZ_SELF") else (new_gpu or _lib.new_sim)(cfg)), ol.oracle_sim(cfg)  # (FUZZ_SELF=1: the harness against itself, no GPU)
     try:
         inv0 = int(r.integers(-20, 20))
         for s in (gpu, cpu):
@@ -191,7 +245,10 @@ def run_case(seed: int, n: int):
             high[-1] = float(r.choice([5.0, 60.0, 400.0]))
         steps = 2 * ep_steps + 8
         if chunk: steps = -(-steps // chunk)
-        resets = flagged_steps = 0
+        resets = flagged_steps = evictions = 0
+        dev_io = None
+        if not os.environ.get("FUZZ_SELF") and (extra["call"] != "host" or extra["reset_dev"]):
+            dev_io = _DeviceIO(gpu, n, cfg.action_dim, extra["call"])
         capacity_stops = int(lost.sum())
         for t in range(steps):
             T = chunk or 1
@@ -204,8 +261,11 @@ def run_case(seed: int, n: int):
                 (og, rg, dg, xg), (oc, rc, dc, xc) = _rollout(gpu, act, policy), _rollout(cpu, act, policy)
             else:
                 if masked: active = (r2.random(n) >= 0.1).astype(np.uint8)
-                og, rg, dg = gpu.step(act[0], active)
                 oc, rc, dc = cpu.step(act[0], active)
+                if dev_io is None: og, rg, dg = gpu.step(act[0], active)
+                else:
+                    og, rg, dg = dev_io.step(gpu, act[0], active)
+                    if dev_io.f32: oc = oc.astype(np.float32).astype(np.float64)  # (the kernel writes the observation_space's dtype: the f64 value rounded once)
                 if masked:  # (an env that sits the step out has no row in it)
                     for a in (og, oc, rg, rc, dg, dc): a[active == 0] = 0
             sg, sc = gpu.status(), cpu.status()
@@ -251,7 +311,19 @@ def run_case(seed: int, n: int):
                     li = np.nonzero(lost)[0].astype(np.int32)
                     gpu.set_portfolio(ic[li], cc[li], li)
                 sids[ids] = r2.integers(0, len(streams), size=len(ids))
-                o1, o2 = gpu.reset(starts[ids], sids[ids], ids), cpu.reset(starts[ids], sids[ids], ids)
+                if extra["evict"] and not os.environ.get("FUZZ_SELF"):  # a day no env replays any more leaves the device and comes back (into the slot it had: the lowest free one)
+                    sids_after = sids.copy()
+                    for k in range(len(streams)):
+                        if not (sids_after == k).any():
+                            gpu.drop_stream(k)
+                            back = gpu.add_stream(streams[k])
+                            if back != k: return f"step {t}: stream {k} came back as {back}", desc
+                            evictions += 1
+                            break
+                o2 = cpu.reset(starts[ids], sids[ids], ids)
+                if dev_io is not None and extra["reset_dev"]: o1 = dev_io.reset(gpu, starts[ids], sids[ids], ids)
+                else: o1 = gpu.reset(starts[ids], sids[ids], ids)
+                if dev_io is not None and extra["reset_dev"] and dev_io.f32: o2 = o2.astype(np.float32).astype(np.float64)
                 s1, s2 = gpu.status()[ids], cpu.status()[ids]
                 cap = (s1 & 28) != 0  # (a warm-up that outgrew a capacity)
                 capacity_stops += int(cap.sum())
@@ -272,12 +344,22 @@ def run_case(seed: int, n: int):
             if not lost[e] and not np.array_equal(gpu.queues(e), cpu.queues(e)):
                 return f"end: env {e}: per-order book contents differ", desc
         st = np.array([gpu.env_state(e)["status"] for e in range(n)])
-        desc = dict(desc, resets=resets, flagged=flagged_steps, capacity_stops=capacity_stops, max_agent_orders=max(gpu.env_state(e)["n_agent_orders"] for e in range(n)), inv_max=int(np.abs(ig).max()))
+        if gpu.b.prefix == "lobsim_":  # (the diagnostic build's sentinel zones; the product library has none: 0 of 0)
+            zones, damaged = gpu.check_redzones()
+            if damaged:
+                return f"end: {damaged} of {zones} red zones damaged: {gpu.b.fn['last_error'](gpu.h).decode()}", desc
+            desc = dict(desc, red_zones=zones)
+        desc = dict(desc, evictions=evictions, resets=resets, flagged=flagged_steps, capacity_stops=capacity_stops, max_agent_orders=max(gpu.env_state(e)["n_agent_orders"] for e in range(n)), inv_max=int(np.abs(ig).max()))
         return None, desc
     finally:
         gpu.close()
         cpu.close()
 
+
+BOUNDS_SIM = None
+if os.environ.get("FUZZ_BOUNDS"):  # FUZZ_BOUNDS=1: the handle under test is the diagnostic build (liblobsim_bounds.so: bounds checks + red zones)
+    _bb = _lib.bounds_binding()
+    BOUNDS_SIM = lambda cfg: _capi.Sim(_bb, cfg)
 
 if __name__ == "__main__":
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
@@ -287,11 +369,11 @@ if __name__ == "__main__":
     for seed in range(first, end):
         t = time.time()
         try:
-            err, desc = run_case(seed, n)
+            err, desc = run_case(seed, n, new_gpu=BOUNDS_SIM)
         except Exception as ex:  # a configuration one side refuses: both must refuse it (reported, not counted as a difference)
             err, desc = f"EXCEPTION {type(ex).__name__}: {ex}", {}
         short = {k: desc[k] for k in ("step_us", "n_levels", "rate", "min_quote_level", "max_quote_level", "concentration", "market_order_clearing", "enter_spread", "ladder_levels",
-                                        "agent_orders", "max_levels", "outer_levels", "chunk", "bad_msgs", "sharpe", "normalised", "days", "policy", "masked", "with_info", "resets", "flagged", "capacity_stops", "max_agent_orders", "inv_max") if k in desc}  # fmt: skip
+                                        "agent_orders", "max_levels", "outer_levels", "chunk", "bad_msgs", "sharpe", "normalised", "days", "policy", "masked", "with_info", "call", "reset_dev", "evictions", "resets", "flagged", "capacity_stops", "max_agent_orders", "inv_max") if k in desc}  # fmt: skip
         print(f"seed {seed:4d} {'OK  ' if err is None else 'DIFF'} {time.time() - t:5.1f}s {short}" + (f"\n    -> {err}\n    {desc}" if err else ""), flush=True)
         bad += err is not None
     print(f"{end - first} cases, {bad} with a difference or an exception")

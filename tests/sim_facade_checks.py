@@ -107,3 +107,66 @@ def check_internal_orders_by_id(new_sim):
     assert [(o.direction, o.price, o.volume) for o in filled.internal][:1] == [("sell", bb, v)]
     assert [(o.direction, o.price, o.volume) for o in filled.external][:1] == [("buy", bb, v)]
     sim.close()
+
+
+def check_cancellations_the_host_could_not_rank(new_sim):
+    """The calls rl4mm_amd.simulator refused until round 6 (it turned internal ids into FIFO ranks on the host): a cancellation BEHIND a
+    marketable own limit order at the same price, and one behind an own order that sweeps the agent's quotes, in ONE forward_step -
+    the list is processed in order, as Exchange.process_order does (Exchange.py:58-69), and the target is found by its id on the device."""
+    ps = ol.golden_stream("msft")
+    sim = _simulator(new_sim)
+    start, _ = _episode_start(ps)
+    book = sim.reset_episode(start)
+    bb, bs = book.best_buy_price, book.best_sell_price
+    mk = lambda cls, direction, **kw: cls(timestamp=start, direction=direction, ticker=TICKER, internal_id=None, external_id=None, is_external=False, **kw)  # noqa: E731
+    cancel = lambda o, v, t: Cancellation(timestamp=t, direction=o.direction, ticker=TICKER, internal_id=o.internal_id, external_id=None, is_external=False, price=o.price, volume=v)  # noqa: E731
+    t = start + timedelta(milliseconds=1)
+    a = mk(LimitOrder, "sell", price=bs, volume=40)  # rests at the best ask, behind the external orders there
+    sim.forward_step(t, internal_orders=[a])
+    ask_vol = sum(o.volume for o in sim.exchange.central_orderbook.sell[bs] if o.is_external)
+    # (1) a buy limit AT the best ask for more than the externals hold - it executes, deletes the agent's own resting sell on its way
+    # (Exchange.py:91-94) and its remainder rests at bs as the new best bid - and, in the same call, a cancellation of that remainder's
+    # price level naming `a`: a is gone, the level's head is now the agent's own buy order (not a snapshot order): nothing happens
+    t += timedelta(milliseconds=1)
+    m = mk(LimitOrder, "buy", price=bs, volume=ask_vol + 25)
+    filled = sim.forward_step(t, internal_orders=[m, cancel(a, 40, t)])
+    assert sum(o.volume for o in filled.internal) == ask_vol  # the own sell was deleted, not filled
+    ib = sim.exchange.internal_orderbook
+    assert bs not in ib.sell and [(o.internal_id, o.volume) for o in ib.buy[bs]] == [(m.internal_id, 25)]
+    # (2) behind a marketable own order at the SAME price as its target: 10 of the remainder are cancelled by id
+    t += timedelta(milliseconds=1)
+    book = sim.exchange.central_orderbook
+    bs2 = book.best_sell_price
+    m2 = mk(LimitOrder, "buy", price=bs, volume=5)  # joins the agent's own level behind m
+    sim.forward_step(t, internal_orders=[m2, cancel(m, 10, t)])
+    ib = sim.exchange.internal_orderbook
+    assert [(o.internal_id, o.volume) for o in ib.buy[bs]] == [(m.internal_id, 15), (m2.internal_id, 5)] and bs2 == sim.exchange.central_orderbook.best_sell_price
+    # (3) an own sell that sweeps the agent's whole bid level (it deletes its own resting orders, Exchange.py:91-94) and, behind it in the
+    # same call, a cancellation of one of them: the order is gone, the cancellation finds nothing
+    t += timedelta(milliseconds=1)
+    bids = sum(o.volume for p, q in sim.exchange.central_orderbook.buy.items() if p >= bs - 100 for o in q if o.is_external)
+    sweep = mk(MarketOrder, "sell", volume=bids + 1 if bids else 1)
+    sim.forward_step(t, internal_orders=[sweep, cancel(m, 15, t)])
+    assert bs not in sim.exchange.internal_orderbook.buy
+    sim.close()
+
+
+def check_reset_episode_with_a_start_book(new_sim):
+    """OrderbookSimulator.reset_episode(start_date, start_book) (OrderbookSimulator.py:55-68): the episode starts from the caller's book -
+    here the historical one with its best bid thickened by two more orders and its worst ask taken out - the price ranges are that
+    book's, and the messages of the stream are replayed against it."""
+    ps = ol.golden_stream("msft")
+    sim = _simulator(new_sim)
+    start, _ = _episode_start(ps)
+    hist = sim.reset_episode(start)
+    bb, worst_ask = hist.best_buy_price, max(hist.sell)
+    extra = [LimitOrder(timestamp=start, direction="buy", ticker=TICKER, internal_id=7, external_id=9001 + k, is_external=True, price=bb, volume=30 + k) for k in range(2)]
+    hist.buy[bb] = list(hist.buy[bb]) + extra
+    del hist.sell[worst_ask]
+    book = sim.reset_episode(start, start_book=hist)
+    assert [o.volume for o in book.buy[bb]][-2:] == [30, 31] and book.buy[bb][0].internal_id == -1 and worst_ask not in book.sell
+    assert sim.max_sell_price == max(book.sell) and sim.min_buy_price == min(book.buy)
+    assert sim.initial_buy_price_range == bb - min(book.buy) and sim.initial_sell_price_range == max(book.sell) - book.best_sell_price
+    sim.forward_step(start + timedelta(seconds=1))
+    assert sim.now_is == start + timedelta(seconds=1)
+    sim.close()

@@ -200,7 +200,7 @@ def test_limits_and_default_level_budget():
     for max_levels, slabs in ((0, 1024), (64, 256), (200, 448), (2048, 4096)):
         s = _lib.new_sim(_capi.make_cfg(4, 10, feats, max_levels=max_levels))
         lim = s.limits()
-        assert lim["level_slabs"] == slabs and lim["ladder_levels"] == 64 and lim["queue_slots"] == 1024 and lim["agent_orders"] in (128, 256) and lim["far_levels"] == 2048
+        assert lim["level_slabs"] == slabs and lim["ladder_levels"] == 64 and lim["queue_slots"] == 4096 and lim["agent_orders"] in (128, 256) and lim["far_levels"] == 2048
         assert lim["queue_pages"] >= max(slabs, 1024 + 256)  # at least a page per level of the budget
         assert lim["bytes_per_env"] > lim["queue_pages"] * 1024  # a level's queue: 1, 4 or 16 KiB by the orders it holds
         if max_levels == 0:

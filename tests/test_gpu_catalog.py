@@ -233,3 +233,39 @@ def test_env_creator_forwards_device_and_sizing_keys():
     single = E.env_creator(dict(cfg, num_envs=1, device_id=0))
     assert isinstance(single, E.HistoricalOrderbookEnvironment) and single._venv.sim.cfg.device_id == 0
     single.close()
+
+
+def test_default_device_id_with_the_real_device_count():
+    """`default_device_id` against the device count of THIS box (the CPU test monkeypatches it): every rollout worker index, the local
+    worker and a torchrun rank map to a device that exists - on a one-GPU box all of them to device 0 - and a handle opens there.  The info
+    calculator is a required env_config key, as in the reference (rl4mm/gym/utils.py:81)."""
+    import os
+
+    import torch
+
+    n_dev = torch.cuda.device_count()
+    assert n_dev >= 1
+    for w in range(0, 17):
+        d = E.default_device_id({"worker_index": w})
+        assert 0 <= d < n_dev and (n_dev > 1 or d == 0), (w, d)
+        assert d == (0 if w == 0 else (w - 1) % n_dev)
+    old = os.environ.get("LOCAL_RANK")
+    try:
+        for r in range(0, 9):
+            os.environ["LOCAL_RANK"] = str(r)
+            assert E.default_device_id({}) == r % n_dev
+    finally:
+        if old is None:
+            os.environ.pop("LOCAL_RANK", None)
+        else:
+            os.environ["LOCAL_RANK"] = old
+    s = ol.golden_stream("synth_small")
+    cfg = dict(ticker=s.ticker, min_date=s.trading_date, max_date=s.trading_date, step_size=0.1, episode_length=1 / 30, n_levels=s.n_levels, features="agent_state",
+               max_inventory=1000, normalisation_on=False, initial_cash=10**9, initial_inventory=0, per_step_reward_function="PnL", terminal_reward_function="PnL",
+               market_order_clearing=False, market_order_fraction_of_inventory=0.0, min_quote_level=0, max_quote_level=10, enter_spread=False, concentration=None,
+               info_calculator=None, catalog=E.StreamCatalog().add(s), num_envs=8, worker_index=16)  # fmt: skip
+    v = E.env_creator(cfg)
+    assert v.sim.cfg.device_id == 15 % n_dev
+    v.close()
+    with pytest.raises(KeyError):
+        E.env_creator({k: x for k, x in cfg.items() if k != "info_calculator"})

@@ -230,10 +230,20 @@ def test_nan_volumes_raise_unless_the_step_clears_the_inventory():
 
 # seeds of tests/diag/config_fuzz.py.  The first eight stop envs in the middle of a sweep (they differed before the portfolio was put
 # back), 612 quotes into a crossed book, 204 and 624 carry a normalised AmihudLambda over a reset; the rest is a plain sample.
+# Round 6: about a hundred seeds (the drawn ones at 40 envs instead of 64: the sample trebles, the time does not), and the draw has
+# three more dimensions - how the step is called (lobsim_step / lobsim_step_host_io with f32 observations / lobsim_step_device with device
+# buffers and f32 observations), resets through lobsim_reset_device, a day that is dropped from the device and uploaded again mid-case.
 FUZZ_SEEDS = [0, 3, 5, 13, 32, 43, 44, 52, 612, 204, 624] + list(range(1000, 1024))
+MORE_FUZZ_SEEDS = list(range(2000, 2066))
 
 
 @pytest.mark.parametrize("seed", FUZZ_SEEDS)
 def test_drawn_configuration_against_oracle(seed):
     err, desc = config_fuzz.run_case(seed, 64)
+    assert err is None, f"{err}\n{desc}"
+
+
+@pytest.mark.parametrize("seed", MORE_FUZZ_SEEDS)
+def test_more_drawn_configurations_against_oracle(seed):
+    err, desc = config_fuzz.run_case(seed, 40)
     assert err is None, f"{err}\n{desc}"

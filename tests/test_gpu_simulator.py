@@ -42,6 +42,8 @@ def test_reference_simulator_tests_through_the_facade_class():
     fc.check_agreement_with_lobster(_lib.new_sim)
     fc.check_update_outer_levels_with_internal_orders(_lib.new_sim)
     fc.check_internal_orders_by_id(_lib.new_sim)
+    fc.check_cancellations_the_host_could_not_rank(_lib.new_sim)
+    fc.check_reset_episode_with_a_start_book(_lib.new_sim)
 
 
 def _random_internal_orders(rng, cpu, env, max_n):
@@ -141,7 +143,7 @@ def test_forward_argument_errors_and_fill_log_overflow():
     assert sim.env_state(0)["status"] == 0 and sim.env_state(0)["now_us"] == 36_000_050_000
     sim.reset_episode(36_000_000_000, sid)
     lim = sim.limits()
-    assert lim["fill_log_rows"] >= 256 and lim["level_slabs"] >= 256 and lim["queue_slots"] == 1024 and lim["agent_orders"] in (128, 256)
+    assert lim["fill_log_rows"] >= 256 and lim["level_slabs"] >= 256 and lim["queue_slots"] == 4096 and lim["agent_orders"] in (128, 256)
     # one agent market order per resting order: more fills than the log holds is reported, not silently truncated
     book = sim.queues(0)
     asks = book[book[:, 0] == 1]

@@ -417,7 +417,7 @@ def test_7z_archives_go_through_the_7z_executable(tmp_path, monkeypatch):
 
 
 def test_orderbook_simulator_class_host_logic_on_the_reference_simulator_tests():
-    """rl4mm_amd.simulator.OrderbookSimulator's own logic (datetime <-> stream time, internal ids <-> FIFO ranks, Orderbook /
+    """rl4mm_amd.simulator.OrderbookSimulator's own logic (datetime <-> stream time, internal ids = the device's order tags, Orderbook /
     FilledOrders decoding) through the reference's simulator tests (testOrderbookSimulator.py:46-108), with the class bound to
     the CPU restatement (same C-ABI).  The HIP library runs the same checks in tests/test_gpu_simulator.py."""
     import sim_facade_checks as fc
@@ -425,6 +425,8 @@ def test_orderbook_simulator_class_host_logic_on_the_reference_simulator_tests()
     fc.check_agreement_with_lobster(ol.oracle_sim)
     fc.check_update_outer_levels_with_internal_orders(ol.oracle_sim)
     fc.check_internal_orders_by_id(ol.oracle_sim)
+    fc.check_cancellations_the_host_could_not_rank(ol.oracle_sim)
+    fc.check_reset_episode_with_a_start_book(ol.oracle_sim)
 
 
 def test_reset_at_resets_all_finished_envs_in_one_launch_and_keeps_the_rng_sequence():
@@ -486,13 +488,18 @@ def test_mixed_ticker_draw_and_stream_residency_lru():
     assert np.array_equal(starts, start_ref)
     dates = env._day_lookup()
     ids, keys, st = env.last_draw
-    assert keys == [(tickers[i % 3], dates[int(d)]) for i, d in enumerate(day_ref)] and env._env_key == keys
+    assert keys == [(tickers[i % 3], dates[int(d)]) for i, d in enumerate(day_ref)]
+    assert env._env_key == [None] * 12  # (the bookkeeping moves once the device HAS reset the envs: a reset that raises leaves it alone)
+    env._after_reset()
+    assert env._env_key == keys
     assert [env._residency.sid[k] for k in keys] == sids.tolist()
     # a partial reset: only those envs' keys move, np.random advances by their draws only
     np.random.seed(9)
     d2, _ = env._draw_days(2)
     np.random.seed(9)
     env._draw(2, env_ids=[4, 7])
+    assert env._env_key[4] == keys[4]
+    env._after_reset()
     assert env._env_key[4] == ("BBB", dates[int(d2[0])]) and env._env_key[7] == ("BBB", dates[int(d2[1])]) and env._env_key[5] == keys[5]
 
     class Stream:  # what _StreamResidency touches of a PackedStream

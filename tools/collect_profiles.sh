@@ -9,7 +9,7 @@ cd $R
 python3 bench.py > $OUT/bench_random.json 2> $OUT/bench_random.err
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_random_20steps.json 2>/dev/null
 python3 bench.py --agent-orders 128 --no-cpu-baseline --no-facade > $OUT/bench_random_agent128.json 2>/dev/null
-for w in teradactyl ad deep50 rs; do python3 bench.py --workload $w --no-cpu-baseline --steps 200 > $OUT/bench_$w.json 2> $OUT/bench_$w.err; done
+for w in teradactyl ad deep50 rs norm; do python3 bench.py --workload $w --no-cpu-baseline --steps 200 > $OUT/bench_$w.json 2> $OUT/bench_$w.err; done
 python3 bench.py --workload deep50 --agent-orders 128 --no-cpu-baseline --no-facade --steps 200 > $OUT/bench_deep50_agent128.json 2>/dev/null
 python3 bench.py --generic-kernels --no-cpu-baseline --no-facade --steps 200 > $OUT/bench_generic.json 2>/dev/null
 for n in 8192 16384; do python3 bench.py --envs $n --no-cpu-baseline --no-facade --steps 200 > $OUT/bench_random_${n}envs.json 2>/dev/null; done
@@ -20,7 +20,7 @@ cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 cd $R
 # ---- PMC counters of the step kernel, per workload (one rocprofv3 run per counter group)
 PMC_ARGS="" bash tools/pmc_passes.sh $1/pmcdir_random > /dev/null 2>&1; python3 tools/pmc_csv.py $OUT/pmcdir_random $OUT/pmc_step_kernel.csv > /dev/null
-for w in teradactyl ad deep50 rs; do
+for w in teradactyl ad deep50 rs norm; do
   PMC_ONLY="sq1 sq2 fetch write" PMC_ARGS="--workload $w" bash tools/pmc_passes.sh $1/pmcdir_$w > /dev/null 2>&1
   python3 tools/pmc_csv.py $OUT/pmcdir_$w $OUT/pmc_step_kernel_$w.csv > /dev/null
 done
