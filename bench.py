@@ -214,7 +214,7 @@ def workload_starts(workload, n_envs, n_streams, seed):
     return starts, sids
 
 
-def pmc_traffic(workload, n_envs):
+def pmc_traffic(workload, n_envs, kernel=None):
     """HBM bytes per launch of the step kernel from the committed rocprofv3 --pmc passes of this same command
     (tools/pmc_passes.sh -> profiles/<round>/pmc_step_kernel.csv; counters cannot be collected from inside the timed
     run).  FETCH_SIZE / WRITE_SIZE are in KB per dispatch; on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes
@@ -224,7 +224,13 @@ def pmc_traffic(workload, n_envs):
         workload = "generic" if workload == "random" else workload + "_generic"
     f = ROOT / "profiles" / PROFILE_ROUND / ("pmc_step_kernel.csv" if workload == "random" else f"pmc_step_kernel_{workload}.csv")
     try:
-        rows = {r.split(",")[1]: float(r.split(",")[2]) for r in f.read_text().splitlines()[1:] if r.count(",") >= 3}
+        lines = f.read_text().splitlines()
+        # the file names the kernel its counters were taken on (tools/pmc_csv.py): a csv of another kernel - another agent table, another
+        # ladder, the generic instead of the specialised variant, a stale round - is refused, `traffic` is then null rather than wrong
+        named = [ln_[len("# kernel:"):].strip() for ln_ in lines if ln_.startswith("# kernel:")]
+        if kernel is not None and (not named or named[0] != kernel):
+            return None, None
+        rows = {r.split(",")[1]: float(r.split(",")[2]) for r in lines if r.count(",") >= 3 and not r.startswith(("#", "pass_"))}
         if int(rows["SQ_WAVES"]) not in (n_envs, n_envs + 16):  # (+ 16: the sorter waves at the head of a step launch, lpt_sort)
             return None, None
         return (2.0 * rows["FETCH_SIZE"] + rows["WRITE_SIZE"]) * 1024.0, str(f.relative_to(ROOT))
@@ -715,11 +721,11 @@ def main():
         achieved = N * b_step / (kernel_ms * 1e-3)
         sample = range(0, N, max(1, N // 64))
         st_bad = sum(sim.env_state(int(e))["status"] != 0 for e in sample)
-        traffic, traffic_src = pmc_traffic(wl, N)
         lim = sim.limits()
         extras = wl in ("rs", "norm")
         kernel = "lob_step_kernel<%s, %d, %d, %s>" % ("true" if extras else "false", lim["ladder_levels"], lim["agent_orders"],
                                                      "false" if (extras or os.environ.get("LOBSIM_GENERIC_KERNELS")) else "true")  # <EXTRAS, ladder, agent table, SPEC>
+        traffic, traffic_src = pmc_traffic(wl, N, kernel)
         # (Teradactyl: lobsim_rollout_device with T = 1 runs the step kernel, the policy in its prologue)
         out = {
             "metric": "env-steps/sec (batched LOB sims)", "value": world * N * K / elapsed, "unit": "env-steps/s",
@@ -735,6 +741,8 @@ def main():
                 "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                 "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src, "kernel": kernel, "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_env_step": round(b_step, 1),
+                **({"traffic_note": "normalisation histories grow with the episode: the PMC passes ran steps 5 - 85 after the reset (tools/pmc_passes.sh), whose algorithmic bytes are `algorithmic_bytes_at_pmc_steps` per launch, the timed regions steps %d - %d" % (W, W + K * R),
+                    "algorithmic_bytes_at_pmc_steps": round(N * (norm_history_bytes(cfg, int(starts[0]), 5, 80) + 32.0 * m_bar + 105.0))} if wl == "norm" else {}),
             },
         }  # fmt: skip
         if rollout:

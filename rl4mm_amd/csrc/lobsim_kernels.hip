@@ -1022,7 +1022,7 @@ SDI uint64_t make_room(Lds& L, Scal& S, int side, int idx, uint64_t m) {
     const int slab = m_slab(m), cls = slab >> SLAB_CLASS_SHIFT;
     int dst = -1;
     if (UNLIKELY(!LOBSIM_FLAT_SLABS && wants_larger(m))) dst = slab_alloc_larger(S.slots, cls);
-    if (UNLIKELY(dst < 0 && m_tail(m) - m_head(m) == m_live(m))) return m;  // no larger slab to be had and no tombstone to squeeze out: nothing to move (an exhausted pool)
+    if (UNLIKELY(dst < 0 && m_tail(m) == m_live(m))) return m;  // no larger slab to be had and no dead slot - neither a tombstone nor a slot below the head - to squeeze out: nothing to move (an exhausted pool)
     const uint64_t nm = compact_level(L, S, side, idx, m, dst);
     if (UNLIKELY(dst >= 0)) slab_release(L, S.slots, slab);
     return nm;
@@ -1032,9 +1032,9 @@ SDI void level_append(Lds& L, Scal& S, int side, int idx, int64_t id, int32_t vo
     {
         const int tombs = m_tail(m) - m_head(m) - m_live(m);
         // two chunks' worth of tombstones, or (nearly) full with something to gain: tombstones to squeeze out, or a larger slab to move to
-        // (a nearly full slab without tombstones that has NOT outgrown its size - a 256-slot level with fewer than 192 live orders cannot be
-        // nearly full without tombstones, but a level whose move found the pool exhausted can - is left alone: squeezing it moves nothing)
-        if (tombs >= LOBSIM_TOMB || (nearly_full(m) && (tombs > 0 || wants_larger(m)))) {
+        // (dead slots: tombstones AND the slots below a head that moved up - both come back in a squeeze; a nearly full slab that is all
+        // live orders and has not outgrown its size class - a level whose move found the pool exhausted - is left alone: squeezing it moves nothing)
+        if (tombs >= LOBSIM_TOMB || (nearly_full(m) && (m_tail(m) > m_live(m) || wants_larger(m)))) {
             m = make_room(L, S, side, idx, m);
             if (m_tail(m) == m_cap(m)) { S.status |= LOBSIM_ST_QUEUE_OVERFLOW; return; }
         } else if (m_tail(m) == m_cap(m)) { S.status |= LOBSIM_ST_QUEUE_OVERFLOW; return; }
@@ -3081,27 +3081,55 @@ typedef uint8_t __attribute__((address_space(3))) * LdsU8;
 static __device__ __attribute__((noinline)) void lpt_sort(LdsI32 hist, const EnvHdr* hdr, const StreamDev* streams, int64_t step, int32_t* order_next, int N) {
     __builtin_amdgcn_s_setprio(3);
     const int j = (int)blockIdx.x, ln = lane();
-    const int size = (N - j + LPT_CLASSES - 1) / LPT_CLASSES;  // envs j, j + 16, ...
+    const int size = (N - j + LPT_CLASSES - 1) / LPT_CLASSES;  // members of class j = the places j, j + 16, ... of an order
+    // member r of class j: env 16 r + ((j - r) mod 16) - every 16 consecutive envs are dealt to the 16 classes, ROTATED by their block number, so
+    // that a property that goes with the env index mod 2, 4, 8 or 16 (configs[4]: env i replays ticker i mod 4, and the tickers' rates differ
+    // twelvefold) does not put all heavy envs into the same classes, i.e. onto the same XCDs (a class keeps its XCD: first version, 113 M instead
+    // of 149 M env-steps/s on that shard).  The last, partial block of 16 is dealt unrotated, so that a class has as many members as places.
+    const int n_full = N / LPT_CLASSES;
+    auto member_env = [&](int r) { return LPT_CLASSES * r + (r < n_full ? ((j - r) & (LPT_CLASSES - 1)) : j); };
     LdsU8 keys = (LdsU8)(hist + 256);                          // 256 counters, then one key byte per member (the host refuses N beyond what fits)
     const double inv_step = 1.0 / (double)step;
 #pragma unroll
     for (int k = 0; k < 4; k++) hist[ln + 64 * k] = 0;
     wsync();
-    for (int base = 0; base < size; base += WAVE) {
-        const int r = base + ln;
-        if (r < size) {
-            const EnvHdr& H = hdr[j + LPT_CLASSES * r];
-            const int sid = H.stream_id;
-            int w = 0;
-            if (H.status == 0 && sid >= 0) {
-                const StreamDev& st = streams[sid];
-                const int64_t x = H.now_us + step - st.first_sec * 1000000;  // where the window AFTER this launch's begins, on the table's grid
-                const int g = (int)((double)x * inv_step + 0.5);             // (clocks sit on the grid: rounding, not a 64-bit division - a weight is a hint)
-                if (g >= 0 && g < st.n_win) w = st.wtab[g];
+    // four members per lane and turn, stage by stage, so that a turn is three round trips to memory whatever the class's size (header ->
+    // stream descriptor -> weight byte; one member at a time it was three per 64 members: ~20 us for the 256 members of a 4096-env launch,
+    // most of the launch - the sorter must be done long before the env waves are)
+    for (int base = 0; base < size; base += 4 * WAVE) {
+        int sid[4], st_ok[4], g[4], nw[4], w[4];
+        int64_t now[4], fsec[4];
+        const uint8_t* tab[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int r = base + 64 * u + ln;
+            const EnvHdr& H = hdr[member_env(r < size ? r : 0)];
+            sid[u] = H.stream_id; st_ok[u] = H.status == 0; now[u] = H.now_us;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const StreamDev& st = streams[sid[u] >= 0 ? sid[u] : 0];
+            fsec[u] = st.first_sec; nw[u] = st.n_win; tab[u] = st.wtab;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t x = now[u] + step - fsec[u] * 1000000;  // where the window AFTER this launch's begins, on the table's grid
+            g[u] = (int)((double)x * inv_step + 0.5);             // (clocks sit on the grid: rounding, not a 64-bit division - a weight is a hint)
+            st_ok[u] = st_ok[u] && sid[u] >= 0 && g[u] >= 0 && g[u] < nw[u] && tab[u] != nullptr;
+            tab[u] = st_ok[u] ? tab[u] + g[u] : reinterpret_cast<const uint8_t*>(hdr);  // (no branch around the load: a valid address, the byte dropped)
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) w[u] = (int)*tab[u];
+#pragma unroll
+        for (int u = 0; u < 4; u++) w[u] = st_ok[u] ? w[u] : 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int r = base + 64 * u + ln;
+            if (r < size) {
+                const int key = 255 - w[u];  // ascending key = descending weight
+                keys[r] = (uint8_t)key;
+                __hip_atomic_fetch_add(hist + key, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            const int key = 255 - w;  // ascending key = descending weight
-            keys[r] = (uint8_t)key;
-            __hip_atomic_fetch_add(hist + key, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     wsync();
@@ -3117,7 +3145,7 @@ static __device__ __attribute__((noinline)) void lpt_sort(LdsI32 hist, const Env
         const int r = base + ln;
         if (r < size) {
             const int pos = __hip_atomic_fetch_add(hist + (int)keys[r], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (a place of its own for every member, whatever the keys are)
-            order_next[j + LPT_CLASSES * BIDX(pos, size)] = j + LPT_CLASSES * r;
+            order_next[j + LPT_CLASSES * BIDX(pos, size)] = member_env(r);
         }
     }
 }

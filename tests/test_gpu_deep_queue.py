@@ -100,10 +100,10 @@ def test_a_price_with_3500_live_orders_equals_the_oracle():
     gpu.close()
 
 
-@pytest.mark.parametrize("queue_pages, most", [(256 + 16, 1024), (256 + 128, 4096)])
+@pytest.mark.parametrize("queue_pages, most", [(256 + 32, 1024), (256 + 128, 4096)])
 def test_a_pool_too_small_to_grow_says_so(queue_pages, most):
-    """The same appends on a handle whose buddy pool holds one 16-page block (the level cannot move beyond 1024 slots) or two 64-page
-    blocks (it grows to 16 pages inside the first and moves into the second - a buddy block cannot grow in place): equal to the oracle until the queue's pages are full of LIVE orders, then LOBSIM_ST_QUEUE_OVERFLOW - the status bit, the
+    """The same appends on a handle whose buddy pool holds two 16-page blocks (four pages cut from the first, then the second whole: 1024 slots) or two
+    64-page blocks (it grows to 16 pages inside the first and moves into the second - a buddy block cannot grow in place): equal to the oracle until the queue's pages are full of LIVE orders, then LOBSIM_ST_QUEUE_OVERFLOW - the status bit, the
     env stopped, no other level touched - and never before `most` orders."""
     gpu, cpu = _pair(queue_pages)
     assert gpu.limits()["queue_pages"] == queue_pages
