@@ -311,18 +311,17 @@ def run_case(seed: int, n: int, new_gpu=None):
                     li = np.nonzero(lost)[0].astype(np.int32)
                     gpu.set_portfolio(ic[li], cc[li], li)
                 sids[ids] = r2.integers(0, len(streams), size=len(ids))
-                if extra["evict"] and not os.environ.get("FUZZ_SELF"):  # a day no env replays any more leaves the device and comes back (into the slot it had: the lowest free one)
-                    sids_after = sids.copy()
+                o2 = cpu.reset(starts[ids], sids[ids], ids)
+                if dev_io is not None and extra["reset_dev"]: o1 = dev_io.reset(gpu, starts[ids], sids[ids], ids)
+                else: o1 = gpu.reset(starts[ids], sids[ids], ids)
+                if extra["evict"] and not os.environ.get("FUZZ_SELF"):  # a day no env replays any more (after this reset) leaves the device and comes back, into the slot it had: the lowest free one
                     for k in range(len(streams)):
-                        if not (sids_after == k).any():
+                        if not (sids == k).any():
                             gpu.drop_stream(k)
                             back = gpu.add_stream(streams[k])
                             if back != k: return f"step {t}: stream {k} came back as {back}", desc
                             evictions += 1
                             break
-                o2 = cpu.reset(starts[ids], sids[ids], ids)
-                if dev_io is not None and extra["reset_dev"]: o1 = dev_io.reset(gpu, starts[ids], sids[ids], ids)
-                else: o1 = gpu.reset(starts[ids], sids[ids], ids)
                 if dev_io is not None and extra["reset_dev"] and dev_io.f32: o2 = o2.astype(np.float32).astype(np.float64)
                 s1, s2 = gpu.status()[ids], cpu.status()[ids]
                 cap = (s1 & 28) != 0  # (a warm-up that outgrew a capacity)

@@ -82,6 +82,13 @@ def orders_for(w, simd_blocks):
         members = np.arange(j, N, 16)
         cl[j + 16 * np.arange(len(members))] = members[np.argsort(-w[members], kind="stable")]
     out["lpt16"] = cl
+    # what lpt_sort builds since the classes are rotated against the env index (member r of class j = env 16 r + ((j - r) mod 16))
+    rot = np.empty(N, dtype=np.int32)
+    for j in range(16):
+        r = np.arange((N - j + 15) // 16)
+        members = 16 * r + np.where(r < N // 16, (j - r) & 15, j)
+        rot[j + 16 * r] = members[np.argsort(-w[members], kind="stable")]
+    out["lpt16rot"] = rot
     return out
 
 
@@ -113,7 +120,7 @@ ids, counts = np.unique(place, return_counts=True)
 print(f"  SIMDs used {len(ids)}, blocks per SIMD min {counts.min()} max {counts.max()}")
 per = int(counts.min())
 simd_blocks = np.stack([np.flatnonzero(place == s)[:per] for s in ids])  # (a SIMD with more blocks than the rest: the extra ones keep their env)
-POLS = ["none", "identity", "packed", "lpt", "lpt16", "lpt16:count", "lpt16:runs16", "lpt16:runs4", "lpt16:mix", "identity"][:9]
+POLS = ["none", "identity", "packed", "lpt", "lpt16", "lpt16:count", "lpt16:runs16", "lpt16:runs4", "lpt16:mix", "lpt16rot"]
 res = {p: [] for p in POLS}
 dur_top = {p: [] for p in res}
 t = 12
