@@ -19,8 +19,13 @@ SOURCES = [CSRC / "lobsim_kernels.hip", CSRC / "lobsim_host.inc", CSRC / "lobsim
 # wave-reduction prologue (mbcnt / exec juggling, ~12 instructions per add) only costs scalar-unit time there.
 # -amdgpu-sched-strategy=max-ilp: the step kernel is a chain of dependent scalar / LDS / vector work per wave; the scheduler
 # tuned for instruction-level parallelism instead of occupancy measured +1.5 % per step (-1 % on the multi-step launch).
+# -disable-machine-licm (round 6): the machine-level loop-invariant code motion hoists per-lane address arithmetic out of the kernels' loops - out
+# of the multi-step launch's step loop above all - and the hoisted values then ride through the whole message replay in vector registers the
+# allocator spills there.  Without it: lob_rollout_kernel<false, 64, 256, true> 91 -> 0 spilled registers (224 -> 0 B of scratch), the multi-step
+# launch 21.1 -> 16.6 us per 4096-env step (194 -> 246 M env-steps/s); the reset kernels 57 -> 8, the forward kernel 127 -> 80 registers; the
+# per-step kernel 96 -> 86 registers at the same speed (28.0 us, tools/ab_libs.py, five interleaved rounds; profiles/r6/README.md).
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-               "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
+               "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-disable-machine-licm",
                "-Wno-pass-failed"]  # (the 128-level kernels are LDS-limited below their register budget's occupancy: expected)
 # The kernel file is compiled as N_PARTS translation units in parallel (-DLOBSIM_PART=k: 0 = the C-ABI host side, 1 .. 4 = the engine
 # kernels of one (on-chip ladder width, agent table) combination) and linked into one library; as one unit the 52 kernels take minutes.
