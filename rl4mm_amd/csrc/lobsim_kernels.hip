@@ -2606,14 +2606,16 @@ SDI double wave_np_sum(Lds& L, const double* a, int cap, int start, int n, bool 
                 else if (bit) real = false;
             }
             int first = cfirst + o; first = first >= cap ? first - cap : first;
-            double res = 0.;
+            double res = 0., xt = 0.;
+            const int tn = len >= 8 ? (len & 7) : 0;  // elements left over behind the whole turns: lane j < tn of the group fetches the j-th
             if (real) {
                 if (len < 8) { for (int i = 0; i < len; i++) res += at(first, i); }  // (a chunk of fewer than 8 elements: the group's lanes all do the same)
                 else {
                     const int nb = len >> 3;  // whole turns of the 8 accumulators (<= 16)
                     double x[16];
 #pragma unroll
-                    for (int b = 0; b < 16; b++) x[b] = b < nb ? at(first, 8 * b + j) : 0.;  // every load of the block before the first add
+                    for (int b = 0; b < 16; b++) x[b] = b < nb ? at(first, 8 * b + j) : 0.;  // every load of the block before the first add ...
+                    if (j < tn) xt = at(first, (len & ~7) + j);  // ... the left-over elements too (read one by one behind the sum they were a dependent trip to memory each: up to seven per block)
                     double r = x[0];
 #pragma unroll
                     for (int b = 1; b < 16; b++) r = b < nb ? r + x[b] : r;
@@ -2625,9 +2627,11 @@ SDI double wave_np_sum(Lds& L, const double* a, int cap, int start, int n, bool 
             double t = res + shfl_xor_f64(res, 1);
             t = t + shfl_xor_f64(t, 2);
             t = t + shfl_xor_f64(t, 4);
-            if (real && len >= 8) {
-                res = t;
-                for (int i = len & ~7; i < len; i++) res += at(first, i);  // the elements left over, one by one
+            if (real && len >= 8) res = t;
+#pragma unroll
+            for (int i = 0; i < 7; i++) {  // the elements left over, added one by one in their order (every lane takes part in the exchange)
+                const double v = __shfl(xt, (ln & ~7) + i);
+                if (real && i < tn) res += v;
             }
             if (real && j == 0) slotv[s] = res;
         }
