@@ -1,0 +1,322 @@
+"""Diagnostic (a sample of it runs in the suite: tests/test_gpu_fuzz.py): RANDOM batches through the PYTHON boundary -
+`HistoricalOrderbookVectorEnv(ticker=[...])` over several tickers and several trading days (a weekend and a NASDAQ holiday in the
+range), a stream budget that evicts days while the case runs, the three call shapes a user has (numpy arrays, RLlib's lists with
+`reset_at`, torch tensors with `reset_done_tensors`), finished envs that are reset at once / one `reset_at` at a time / left to sit
+out for a few steps, envs reset in the middle of their episode (after which the batch's episodes end on different steps) - every env
+against the CPU oracle on the (ticker, day, start) the env drew (`env.last_draw`), at every step.
+tests/diag/config_fuzz.py draws what the C-ABI can be asked; this draws what rl4mm/gym/HistoricalOrderbookEnvironment.py's
+constructor and RLlib's VectorEnv protocol can be asked.  `python tests/diag/vector_env_fuzz.py <seed> <seed+1>` replays one case.
+usage: python tests/diag/vector_env_fuzz.py [first_seed=0] [end_seed=30] [envs=48]"""
+import sys
+import time
+from datetime import datetime, timedelta
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+from rl4mm_amd import _capi, env as E
+from rl4mm_amd.synth import synthetic_stream
+from rl4mm_amd.trading_calendar import get_next_trading_dt
+
+RTOL, ATOL = 1e-12, 1e-9
+INFO_COLS = ("asset_price", "inventory", "cash", "aum", "market_spread", "agent_spread", "midprice_offset", "weighted_midprice_offset")
+
+
+def draw_case(seed: int, n: int):
+    """-> (constructor keywords, {(ticker, day): stream arguments}, description).  Pure: no GPU, no oracle."""
+    import pandas as pd
+
+    r = np.random.Generator(np.random.PCG64(390_000 + seed))
+    step_s = float(r.choice([0.05, 0.1, 0.1, 0.1, 0.2, 0.5, 1.0]))
+    step = timedelta(seconds=step_s)
+    ep_steps = int(r.integers(8, 36))
+    episode = ep_steps * step
+    tickers = [f"F{seed % 10}{c}" for c in "ABCD"[: int(r.choice([1, 2, 2, 3, 4]))]]
+    while True:  # 2018-02-14 (Wed) .. 2018-02-27: a weekend and Presidents' Day (Mon 2018-02-19) inside
+        d0 = datetime(2018, 2, 14) + timedelta(days=int(r.integers(0, 7)))
+        d1 = d0 + timedelta(days=int(r.choice([0, 0, 1, 2, 3, 5])))
+        bdays = pd.bdate_range(d0, d1)
+        if len(bdays):
+            break
+    sessions = sorted({get_next_trading_dt(pd.to_datetime(d).to_pydatetime()).strftime("%Y-%m-%d") for d in bdays})
+    n_levels = int(r.choice([5, 10, 10, 20]))
+    us = lambda: timedelta(seconds=float(r.choice([step_s, step_s, 2 * step_s, 1.0 if (1.0 / step_s) == int(1.0 / step_s) else step_s])))
+    lb = lambda u, hi: int(r.integers(1, max(2, min(hi, int(40 / u.total_seconds())))))
+    norm = r.random() < 0.2
+    nkw = lambda: dict(normalisation_on=True, max_norm_len=int(r.choice([2, 7, 40, 100_000]))) if (norm and r.random() < 0.5) else {}
+    pool = [
+        lambda: E.Spread(update_frequency=us(), **nkw()),
+        lambda: (lambda u: E.PriceMove(name="pm", update_frequency=u, lookback_periods=lb(u, 30), **nkw()))(us()),
+        lambda: (lambda u: E.Volatility(name="vol", update_frequency=u, lookback_periods=lb(u, 80), **nkw()))(us()),
+        lambda: E.Inventory(update_frequency=us(), **nkw()),
+        lambda: E.EpisodeProportion(update_frequency=step, episode_length=episode, **nkw()),
+        lambda: E.TimeOfDay(update_frequency=timedelta(seconds=float(r.choice([step_s, 60.0]))), n_buckets=int(r.choice([5, 10])), **nkw()),
+        lambda: (lambda u: E.TradeDirectionImbalance(update_frequency=u, lookback_periods=lb(u, 60), track_internal=bool(r.random() < 0.5), **nkw()))(us()),
+        lambda: (lambda u: E.TradeVolumeImbalance(update_frequency=u, lookback_periods=lb(u, 60), track_internal=bool(r.random() < 0.5), **nkw()))(us()),
+        lambda: E.BookImbalance(update_frequency=us(), **nkw()),
+        lambda: (lambda u: E.PriceRange(name="range", update_frequency=u, lookback_periods=lb(u, 12), **nkw()))(us()),
+        lambda: E.Price(update_frequency=us(), **nkw()),
+        lambda: E.AmihudLambda(update_frequency=step, lookback_periods=int(r.integers(1, 5)), slowing_factor=int(r.integers(1, 4)), **nkw()),
+    ]
+    k = int(r.integers(2, 11))
+    feats = [pool[i]() for i in sorted(r.choice(len(pool), size=k, replace=False))]
+    # the longest window is the warm-up, and an episode's replay starts `warm-up` before a whole second: the reference asserts that this
+    # is a whole second too (OrderbookSimulator.py:61) - one feature whose window is whole seconds and no shorter than any other
+    longest = max(f.window_size for f in feats).total_seconds()
+    feats.append(E.PriceMove(name="anchor", update_frequency=timedelta(seconds=1), lookback_periods=max(1, int(-(-longest // 1))) + int(r.integers(0, 3))))
+    warm_s = feats[-1].lookback_periods
+    minq = int(r.choice([0, 0, 1, 2]))
+    q = int(r.choice([2, 3, 5, 8, 10, 10, 12, 16]))
+    conc = float(r.choice([11.0, 30.0])) if r.random() < 0.3 else None
+    amax = float(r.choice([10.0, 10.0, 3.0]))
+    moc = bool(r.random() < 0.3)
+    rewards = [lambda: E.PnL(), lambda: E.InventoryAdjustedPnL(0.1, True), lambda: E.InventoryAdjustedPnL(float(r.choice([0.01, 0.5])))]
+    sharpe = r.random() < 0.08
+    psr, tr = rewards[int(r.integers(0, 3))](), rewards[int(r.integers(0, 3))]()
+    if sharpe:
+        psr = E.RollingSharpe(int(r.choice([8, 32])), int(r.choice([2, 5])))
+    first = 9 * 3600 + 58 * 60 + 20 + int(r.integers(0, 20))  # earliest episode start, seconds after midnight
+    slack = int(r.choice([0, 1, 5, 15, 30]))
+    ep_s = episode.total_seconds()
+    last = first + slack + int(-(-ep_s // 1)) + 1
+    path = str(r.choice(["arrays", "arrays", "lists", "tensors", "tensors"]))
+    with_info = path != "tensors" and minq == 0 and bool(r.random() < 0.3)
+    streams = {}
+    for j, tk in enumerate(tickers):
+        for i, day in enumerate(sessions):
+            streams[(tk, day)] = dict(seed=31_000 + 97 * seed + 10 * j + i, n_levels=n_levels, msgs_per_s=float(r.choice([40, 150, 300, 600])), start_s=first - warm_s - 4, end_s=last + 6,
+                                      mid_price=int(r.choice([60_000, 2_700_000, 2_700_000, 9_990_000])), ticker=tk, trading_date=day, book_snapshot_freq=str(r.choice(["S", "S", "100ms"])))  # fmt: skip
+    budget_streams = float(r.choice([0, 0, 1.3, 2.4, 3.6])) if len(streams) > 2 else 0.0
+    kw = dict(features=feats, max_distribution_param=amax, ticker=tickers if (len(tickers) > 1 or r.random() < 0.5) else tickers[0], step_size=step, episode_length=episode,
+              initial_portfolio=E.Portfolio(inventory=int(r.integers(-20, 20)), cash=10**9), min_quote_level=minq, max_quote_level=minq + q, min_date=d0, max_date=d1,
+              min_start_timedelta=timedelta(seconds=first), max_end_timedelta=timedelta(seconds=first + slack) + episode, market_order_clearing=moc, inc_prev_action_in_obs=bool(r.random() < 0.4),
+              max_inventory=int(r.choice([5, 60, 400])), per_step_reward_function=psr, terminal_reward_function=tr, concentration=conc,
+              market_order_fraction_of_inventory=float(r.choice([0.25, 0.5, 1.0])) if moc else 0.0, enter_spread=bool(r.random() < 0.4), n_levels=n_levels, outer_levels=int(r.choice([3, 10, 20])),
+              ladder_levels=int(r.choice([0, 0, 64, 128])), agent_orders=int(r.choice([0, 0, 256])), obs_dtype=np.float32 if r.random() < 0.4 else np.float64)  # fmt: skip
+    desc = dict(path=path, step_s=step_s, ep_steps=ep_steps, tickers=len(tickers), sessions=sessions, bdays=len(bdays), n_levels=n_levels, feats=[(type(f).__name__, f.lookback_periods, f.update_frequency.total_seconds(), f.normalisation_on) for f in feats],
+                quote=(minq, minq + q), conc=conc, moc=moc, sharpe=sharpe, slack=slack, budget_streams=budget_streams, with_info=with_info, f32=kw["obs_dtype"] is np.float32, enter_spread=kw["enter_spread"], prev_action=kw["inc_prev_action_in_obs"])  # fmt: skip
+    return kw, streams, desc, dict(r=r, budget_streams=budget_streams, with_info=with_info, path=path, amax=amax, sharpe=sharpe, ep_steps=ep_steps)
+
+
+def run_case(seed: int, n: int):
+    """-> (None or a description of the first difference, description of the case)"""
+    import oracle_lib as ol
+
+    kw, stream_args, desc, x = draw_case(seed, n)
+    r, path = x["r"], x["path"]
+    streams = {k: synthetic_stream(**a) for k, a in stream_args.items()}
+    cat = E.StreamCatalog()
+    for s in streams.values():
+        cat.add(s)
+    one = max(s.msgs.nbytes + s.snaps.nbytes for s in streams.values())
+    ikw = {}
+    if x["with_info"]:
+        mk = lambda: E.SimpleInfoCalculator(kw["market_order_fraction_of_inventory"], kw["enter_spread"], concentration=kw["concentration"], quote_levels=kw["max_quote_level"] - kw["min_quote_level"])
+        ikw, calc_host = dict(info_calculator=mk()), mk()
+    v = E.HistoricalOrderbookVectorEnv(n, cat, stream_budget_mb=x["budget_streams"] * one / 2**20, **kw, **ikw)
+    cpu = ol.oracle_sim(v.sim.cfg)
+    try:
+        sid = {k: cpu.add_stream(s) for k, s in streams.items()}
+        cpu.set_portfolio(int(kw["initial_portfolio"].inventory), 10**9)
+        f32 = v.obs_dtype == np.float32
+        as_out = (lambda o: o.astype(np.float32).astype(np.float64)) if f32 else (lambda o: o)  # (the kernel writes the observation_space's dtype: the f64 value rounded once)
+        r_rtol, r_atol = (1e-5, 1e-6) if x["sharpe"] else (0.0, ATOL)  # (RollingSharpe: tests/diag/config_fuzz.py says why)
+        A = v.sim.action_dim
+        high = np.full(A, x["amax"])  # (Beta parameters up to max_distribution_param; at the concentration itself the volumes are NaN and the env stops)
+        if kw["market_order_clearing"]:
+            high[-1] = float(kw["max_inventory"])
+        lost = np.zeros(n, dtype=bool)     # envs that met a capacity of the HIP layout (the oracle has none): out of the comparison until their next reset
+        held = np.zeros(n, dtype=bool)     # envs that finished and have not been reset: they sit the steps out
+        reset_failed = np.zeros(n, dtype=bool)
+        counts = dict(resets=0, partial_resets=0, reset_at_calls=0, sat_out=0, flagged=0, capacity_stops=0, steps=0)
+        if path == "tensors":
+            import torch
+
+            dev = torch.device("cuda", 0)
+
+        def mirror(obs_rows, what, expect_ids=None):
+            """the reset the env just made, made on the oracle (same envs, days, start times); its first observations compared"""
+            ids, keys, starts = v.last_draw
+            if expect_ids is not None and not np.array_equal(ids, expect_ids):
+                return f"{what}: the env reset {ids.tolist()}, asked for {np.asarray(expect_ids).tolist()}"
+            oc = cpu.reset(starts, np.array([sid[k] for k in keys], dtype=np.int32), env_ids=ids.astype(np.int32))
+            s1, s2 = v.sim.status()[ids], cpu.status()[ids]
+            cap = (s1 & 28) != 0
+            counts["capacity_stops"] += int(cap.sum())
+            if not np.array_equal(s1[~cap], s2[~cap]):
+                return f"{what}: status after the reset differs: {s1.tolist()} vs {s2.tolist()}"
+            og = np.array(obs_rows, dtype=np.float64)
+            bad = (s1 != 0) | (s2 != 0)
+            og[bad], oc[bad] = 0.0, 0.0
+            if not np.allclose(og, as_out(oc), rtol=RTOL, atol=ATOL, equal_nan=True):
+                k, f = np.unravel_index(np.nanargmax(np.abs(og - as_out(oc))), og.shape)
+                return f"{what}: first observation differs by {np.abs(og - as_out(oc)).max()} (env {ids[k]} on {keys[k]}, entry {f})"
+            lost[ids] = cap | (lost[ids] & x["sharpe"])  # (the RollingSharpe window outlives the episode: such an env cannot re-enter the comparison)
+            reset_failed[ids] = s2 != 0  # (an env whose RESET failed has no observation at all - include/lobsim.h; it reports done at its next step)
+            held[ids] = False
+            counts["resets"] += len(ids)
+            wrong = [(int(e), k) for e, k in zip(ids, keys) if k[0] != v.tickers[int(e) % len(v.tickers)]]
+            if wrong:
+                return f"{what}: env on another ticker's stream: {wrong[:4]}"
+            return None
+
+        def give_back_portfolios(ids):
+            li = np.asarray([e for e in ids if lost[e]], dtype=np.int32)
+            if len(li):
+                ic, cc, _ = cpu.portfolios()
+                v.sim.set_portfolio(ic[li], cc[li], li)
+
+        np.random.seed(1000 + seed)
+        if path == "tensors": first_obs = v.vector_reset_tensors().cpu().numpy()
+        elif path == "lists": first_obs = np.array(v.vector_reset())
+        else: first_obs = v.vector_reset_arrays()
+        err = mirror(first_obs, "first reset", np.arange(n))
+        if err: return err, desc
+        total = int(2.6 * x["ep_steps"]) + 6
+        hold_for = 0
+        for t in range(total):
+            act = r.uniform(0, high, size=(n, A))
+            m = r.random(n)
+            act[m < 0.03] = 0.0
+            act[(m >= 0.03) & (m < 0.06)] = high
+            active = (~held).astype(np.uint8)
+            oc, rc, dc = cpu.step(act, active)
+            if path == "tensors":
+                o, rw, d = v.vector_step_tensors(torch.from_numpy(act).to(dev))
+                torch.cuda.synchronize()
+                og, rg, dg = o.cpu().numpy().astype(np.float64), rw.cpu().numpy().copy(), d.cpu().numpy().astype(bool)
+                infos = None
+            elif path == "lists":
+                o, rw, d, infos = v.vector_step(list(act))
+                og, rg, dg = np.array(o, dtype=np.float64), np.array(rw), np.array(d, dtype=bool)
+            else:
+                o, rw, d, infos = v.vector_step_arrays(act, want_infos=bool(x["with_info"] or r.random() < 0.5), copy=bool(r.random() < 0.5))
+                og, rg, dg = np.array(o, dtype=np.float64), np.array(rw), np.array(d, dtype=bool)
+            counts["steps"] += 1
+            counts["sat_out"] += int(held.sum())
+            if not dg[held].all():
+                return f"step {t}: an env that finished and was not reset stopped saying done: {np.nonzero(held & ~dg)[0][:6].tolist()}", desc
+            if path != "tensors" and np.any(rg[held] != 0.0):
+                return f"step {t}: an env that sat the step out has a reward", desc
+            sg, sc = v.sim.status(), cpu.status()
+            newly = ((sg & 28) != 0) & ~lost
+            counts["capacity_stops"] += int(newly.sum())
+            lost |= newly
+            if not np.array_equal(sg[~lost], sc[~lost]):
+                e = int(np.nonzero((sg != sc) & ~lost)[0][0])
+                return f"step {t}: status differs in env {e}: {sg[e]} vs {sc[e]}", desc
+            counts["flagged"] += int(((sg != 0) & ~held).sum())
+            live = ~held & ~lost
+            if not np.array_equal(dg[live], dc[live].astype(bool)):
+                e = int(np.nonzero(live & (dg != dc.astype(bool)))[0][0])
+                return f"step {t}: done differs in env {e}: {dg[e]} vs {bool(dc[e])}", desc
+            oc2 = as_out(oc)
+            seen = live & ~reset_failed
+            if not np.allclose(og[seen], oc2[seen], rtol=RTOL, atol=ATOL, equal_nan=True):
+                e, f = np.unravel_index(np.nanargmax(np.where(seen[:, None], np.abs(og - oc2), 0)), og.shape)
+                return f"step {t}: obs differ by {np.abs(og - oc2)[e, f]} (env {e} on {v._env_key[e]}, entry {f}; status {sg[e]} / {sc[e]})", desc
+            if not np.allclose(rg[seen], rc[seen], rtol=r_rtol, atol=r_atol, equal_nan=True):
+                return f"step {t}: reward differs by {np.nanmax(np.abs(rg - rc)[seen])}", desc
+            ig, cg, pg = v.portfolios()
+            ic, cc, pc = cpu.portfolios()
+            for what, a, b in (("inventory", ig, ic), ("cash", cg, cc), ("microprice", pg, pc)):
+                same = (a == b) | ((a != a) & (b != b))
+                if not same[~lost].all():
+                    e = int(np.nonzero(~same & ~lost)[0][0])
+                    return f"step {t}: {what} differs in env {e}: {a[e]} vs {b[e]}", desc
+            if x["with_info"]:
+                if infos is None:
+                    return f"step {t}: an info calculator was given and no infos came back", desc
+                ref = calc_host.calculate_arrays(cpu, act)
+                for e in np.nonzero(live & (sg == 0))[0][:: max(1, n // 16)]:
+                    for col in INFO_COLS:
+                        a, b = float(np.asarray(infos[e][col]).reshape(-1)[0]), float(ref[col][e])
+                        if not (a == b or abs(a - b) <= 1e-9 + 1e-12 * abs(b) or (a != a and b != b)):
+                            return f"step {t}: infos[{e}][{col!r}] = {a!r}, the host calculator on the oracle says {b!r}", desc
+            if path != "tensors" and infos is not None:
+                for e in np.nonzero(dg & ~held & (sg != 0))[0]:
+                    if "error" not in infos[e] or infos[e].get("status") != int(sg[e]):
+                        return f"step {t}: env {e} stopped with status {sg[e]} and its info does not say so: {infos[e]}", desc
+            held |= dg | lost
+            # ---- what a caller does about finished envs -------------------------------------------------------------------------------
+            if held.any():
+                if hold_for > 0:
+                    hold_for -= 1
+                else:
+                    fin = np.nonzero(held)[0].astype(np.int32)
+                    how = r.random()
+                    if how < 0.2 and t < total - 4:
+                        hold_for = int(r.integers(1, 4))  # leave them: they sit out the next steps
+                    elif path == "tensors":
+                        give_back_portfolios(fin)
+                        ids = v.reset_done_tensors()
+                        if not np.array_equal(ids, fin):
+                            return f"step {t}: reset_done_tensors reset {ids.tolist()}, finished were {fin.tolist()}", desc
+                        v.sim.sync()
+                        err = mirror(v._tensors()["obs"].cpu().numpy()[fin], f"step {t}: reset_done_tensors", fin)
+                        if err: return err, desc
+                        if v._tensors()["done"].cpu().numpy().any():
+                            return f"step {t}: done flags left set after reset_done_tensors", desc
+                    elif path == "lists" or how < 0.5:  # RLlib: one reset_at per finished env, in index order (the first one resets them all in one launch)
+                        give_back_portfolios(fin)
+                        before = v.last_draw
+                        rows = [v.reset_at(int(i)) for i in fin]
+                        counts["reset_at_calls"] += len(fin)
+                        if v.last_draw is before:
+                            return f"step {t}: reset_at drew nothing", desc
+                        err = mirror(np.array(rows), f"step {t}: reset_at x {len(fin)}", fin)
+                        if err: return err, desc
+                    else:  # some now, the others a step later
+                        part = fin if how < 0.8 else fin[r.random(len(fin)) < 0.5]
+                        if len(part):
+                            give_back_portfolios(part)
+                            err = mirror(v.reset_many(part), f"step {t}: reset_many", part)
+                            if err: return err, desc
+            # ---- envs reset in the middle of their episode: the batch's episodes end on different steps from here on -------------------
+            if r.random() < 0.07 and (~held).sum() > 2:
+                part = np.nonzero(~held & (r.random(n) < 0.3))[0].astype(np.int32)
+                if len(part):
+                    counts["partial_resets"] += 1
+                    rows = v.reset_many(part) if (path != "lists" or len(part) > 3) else np.array([v.reset_at(int(i)) for i in part[:1]])
+                    err = mirror(rows, f"step {t}: reset in mid-episode", part if len(rows) == len(part) else part[:1])
+                    if err: return err, desc
+            # a day on the device that no env replays is a leak of the budget; a day an env replays that is not there is worse
+            res = v._residency
+            in_use = {k for k in v._env_key if k is not None}
+            if not in_use <= set(res.sid):
+                return f"step {t}: envs replay days that are not on the device: {sorted(in_use - set(res.sid))}", desc
+        for e in range(0, n, 5):
+            if not lost[e] and not held[e] and not np.array_equal(v.sim.queues(e), cpu.queues(e)):
+                return f"end: env {e}: per-order book contents differ", desc
+        res = v._residency
+        desc = dict(desc, **counts, uploads=res.uploads, drops=res.drops, resident=len(res.sid))
+        return None, desc
+    finally:
+        v.close()
+        cpu.close()
+
+
+SHORT = ("path", "step_s", "ep_steps", "tickers", "bdays", "n_levels", "quote", "conc", "moc", "sharpe", "slack", "budget_streams", "with_info", "f32", "steps", "resets", "partial_resets", "reset_at_calls", "sat_out",
+         "flagged", "capacity_stops", "uploads", "drops", "resident")  # fmt: skip
+
+if __name__ == "__main__":
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    end = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+    n = int(sys.argv[3]) if len(sys.argv) > 3 else 48
+    bad = 0
+    for seed in range(first, end):
+        t0 = time.time()
+        try:
+            err, desc = run_case(seed, n)
+        except Exception as ex:  # (a configuration one side refuses: reported, counted)
+            import traceback
+
+            err, desc = f"EXCEPTION {type(ex).__name__}: {ex}\n{traceback.format_exc(limit=6)}", {}
+        short = {k: desc[k] for k in SHORT if k in desc}
+        print(f"seed {seed:4d} {'OK  ' if err is None else 'DIFF'} {time.time() - t0:5.1f}s {short}" + (f"\n    -> {err}\n    {desc}" if err else ""), flush=True)
+        bad += err is not None
+    print(f"{end - first} cases, {bad} with a difference or an exception")
+    sys.exit(1 if bad else 0)

@@ -25,6 +25,7 @@ from rl4mm_amd.stream import SIDE_SHIFT, TYPE_SHIFT, PackedStream
 
 sys.path.insert(0, str(Path(__file__).resolve().parent / "diag"))
 import config_fuzz  # noqa: E402
+import vector_env_fuzz  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -246,4 +247,16 @@ def test_drawn_configuration_against_oracle(seed):
 @pytest.mark.parametrize("seed", MORE_FUZZ_SEEDS)
 def test_more_drawn_configurations_against_oracle(seed):
     err, desc = config_fuzz.run_case(seed, 40)
+    assert err is None, f"{err}\n{desc}"
+
+
+# tests/diag/vector_env_fuzz.py: drawn batches through the Python boundary - VectorEnv(ticker=[...]) over several tickers and days (a
+# weekend and a holiday in the range), a stream budget that evicts while the case runs, arrays / RLlib lists with reset_at / tensors
+# with reset_done_tensors, finished envs left to sit out, envs reset in mid-episode - every env against the oracle on what it drew.
+VECTOR_ENV_SEEDS = list(range(0, 16))
+
+
+@pytest.mark.parametrize("seed", VECTOR_ENV_SEEDS)
+def test_drawn_vector_env_against_oracle(seed):
+    err, desc = vector_env_fuzz.run_case(seed, 32)
     assert err is None, f"{err}\n{desc}"

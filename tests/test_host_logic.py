@@ -661,3 +661,34 @@ def test_bench_refuses_pmc_counters_of_another_kernel(tmp_path, monkeypatch):
     (d / "pmc_step_kernel.csv").write_text(body)  # a file from before the header existed
     assert bench.pmc_traffic("random", 4096, "lob_step_kernel<false, 64, 256, true>") == (None, None)
     assert bench.pmc_traffic("deep50", 8192, "lob_step_kernel<false, 64, 256, true>") == (None, None)  # no file at all
+
+
+def test_vector_env_fuzz_draws_cases_the_constructor_accepts():
+    """tests/diag/vector_env_fuzz.py's draw (the GPU sample of it runs in tests/test_gpu_fuzz.py): every case has a warm-up of whole
+    seconds set by its last feature (the reference asserts it, OrderbookSimulator.py:61), a stream for every (ticker, session) the date
+    range can draw - weekend days and the holiday of 2018-02-19 mapped to the next session - covering warm-up, every start and the
+    episode, and the constructor's own assertions hold (HistoricalOrderbookEnvironment.py:85-100,372-384)."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent / "diag"))
+    import vector_env_fuzz as vf
+
+    paths, multi_session, budgets = set(), 0, 0
+    for seed in range(120):
+        kw, streams, desc, x = vf.draw_case(seed, 32)
+        feats = kw["features"]
+        warm = max(f.window_size for f in feats)
+        assert warm == feats[-1].window_size and warm.total_seconds() == int(warm.total_seconds()) >= 1
+        assert kw["episode_length"] % kw["step_size"] == timedelta(0) and kw["min_start_timedelta"] + kw["episode_length"] <= kw["max_end_timedelta"]
+        assert (kw["concentration"] is None) or kw["concentration"] >= kw["max_distribution_param"]
+        assert kw["market_order_clearing"] == (kw["market_order_fraction_of_inventory"] > 0)
+        tickers = [kw["ticker"]] if isinstance(kw["ticker"], str) else kw["ticker"]
+        assert set(streams) == {(t, d) for t in tickers for d in desc["sessions"]} and "2018-02-19" not in desc["sessions"]
+        for a in streams.values():
+            assert a["start_s"] <= kw["min_start_timedelta"].total_seconds() - warm.total_seconds() - 2
+            assert a["end_s"] >= kw["max_end_timedelta"].total_seconds() + 2
+        paths.add(x["path"])
+        multi_session += len(desc["sessions"]) > 1
+        budgets += x["budget_streams"] > 0
+    assert paths == {"arrays", "lists", "tensors"} and multi_session > 30 and budgets > 20

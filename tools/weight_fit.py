@@ -48,6 +48,8 @@ for t in range(K):
         Y.append(tot); PREV.append(prev_tot)
     prev_tot = tot
 X, Y, PREV = np.array(X), np.array(Y), np.array(PREV)  # [T, N, F], [T, N]
+# (alignment check: the correlation of a window's message count with the wave's cycles must peak at shift 0)
+print("corr(msgs of window t + shift, cycles of launch t): " + ", ".join(f"{sh:+d}: {np.corrcoef(X[max(0, sh):len(X) + min(0, sh), :, 0].reshape(-1), Y[max(0, -sh):len(Y) - max(0, sh)].reshape(-1))[0, 1]:.3f}" for sh in (-2, -1, 0, 1, 2)))
 names = ["msgs", "exec runs", "exec msgs", "removals", "limits", "removal behind an execution", "second boundary"]
 flat_x, flat_y = X.reshape(-1, X.shape[2]), Y.reshape(-1)
 A = np.column_stack([flat_x, np.ones(len(flat_y))])
