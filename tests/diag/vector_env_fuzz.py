@@ -291,8 +291,11 @@ def run_case(seed: int, n: int):
         for e in range(0, n, 5):
             if not lost[e] and not held[e] and not np.array_equal(v.sim.queues(e), cpu.queues(e)):
                 return f"end: env {e}: per-order book contents differ", desc
+        zones, damaged = v.sim.check_redzones()  # (LOBSIM_LIB=rl4mm_amd/csrc/liblobsim_bounds.so: the diagnostic build's sentinel zones; the product library has none - 0 of 0)
+        if damaged:
+            return f"end: {damaged} of {zones} red zones damaged: {v.sim.b.fn['last_error'](v.sim.h).decode()}", desc
         res = v._residency
-        desc = dict(desc, **counts, uploads=res.uploads, drops=res.drops, resident=len(res.sid))
+        desc = dict(desc, **counts, uploads=res.uploads, drops=res.drops, resident=len(res.sid), red_zones=zones)
         return None, desc
     finally:
         v.close()
@@ -300,7 +303,7 @@ def run_case(seed: int, n: int):
 
 
 SHORT = ("path", "step_s", "ep_steps", "tickers", "bdays", "n_levels", "quote", "conc", "moc", "sharpe", "slack", "budget_streams", "with_info", "f32", "steps", "resets", "partial_resets", "reset_at_calls", "sat_out",
-         "flagged", "capacity_stops", "uploads", "drops", "resident")  # fmt: skip
+         "flagged", "capacity_stops", "uploads", "drops", "resident", "red_zones")  # fmt: skip
 
 if __name__ == "__main__":
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
