@@ -3850,7 +3850,16 @@ template <bool EXTRAS, int LVT, int NAT, bool SPEC = false>
 __global__ __launch_bounds__(64, step_waves(LVT, NAT, EXTRAS)) void lob_step_kernel(DevCfg C, DevPtrs P, StepArgs A) {
     typedef Eng<LVT, SPEC, false, NAT> E;
     static_assert(sizeof(typename E::Lds) >= 1024 + 6000, "sorter scratch: 256 counters + a key byte per env of a class (lobsim_create: lpt)");
-    if (UNLIKELY(LOBSIM_LPT && A.order_next && blockIdx.x < (unsigned)LPT_CLASSES)) { E::lpt_sort((typename E::LdsI32)0, P.hdr, P.streams, C.c.step_us, A.order_next, A.n_envs); return; }  // (LDS offset 0: the kernel's own block, unused by a sorter wave)
+    if (UNLIKELY(LOBSIM_LPT && A.order_next && blockIdx.x < (unsigned)LPT_CLASSES)) {
+#ifdef LOBSIM_PROFILE_SKEW
+        const uint64_t sorter_t0 = __builtin_amdgcn_s_memrealtime();  // (tools/dispatch_skew.py: when the sorter waves start and end, rows N .. N + 15 of the stamp array)
+#endif
+        E::lpt_sort((typename E::LdsI32)0, P.hdr, P.streams, C.c.step_us, A.order_next, A.n_envs);  // (LDS offset 0: the kernel's own block, unused by a sorter wave)
+#ifdef LOBSIM_PROFILE_SKEW
+        if (threadIdx.x == 0 && P.prof) { __builtin_amdgcn_s_waitcnt(0); P.prof[((size_t)A.n_envs + blockIdx.x) * 8 + 0] = sorter_t0; P.prof[((size_t)A.n_envs + blockIdx.x) * 8 + 1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+        return;
+    }
     E::template step_body<EXTRAS>(C, P, A);
 }
 template <bool EXTRAS, int LVT, int NAT, bool SPEC = false>

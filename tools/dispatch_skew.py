@@ -24,16 +24,21 @@ obs = torch.zeros((N, sim.obs_dim), dtype=torch.float64, device=dev)
 reward = torch.zeros(N, dtype=torch.float64, device=dev); done = torch.zeros(N, dtype=torch.uint8, device=dev)
 out = np.zeros((N, 8), dtype=np.uint64)
 b.lib.lobsim_prof_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-rows = []
+b.lib.lobsim_prof_read_messages.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+sorter = np.zeros((N, 16), dtype=np.uint64)  # (rows N .. of the stamp array: the launch's 16 sorter waves, lpt_sort)
+rows, srows = [], []
 for t in range(K):
     sim.step_device(acts[t].data_ptr(), 0, obs.data_ptr(), 0, reward.data_ptr(), done.data_ptr(), 0)
     b.lib.lobsim_prof_read(sim.h, out.ctypes.data, 1)
+    b.lib.lobsim_prof_read_messages(sim.h, sorter.ctypes.data, 1)
     if t < 20: continue
     t0, t1 = out[:, 0].astype(np.int64), out[:, 1].astype(np.int64)
     hw, cyc = out[:, 2], out[:, 3].astype(np.float64)
     base = t0.min()
     st, en = (t0 - base) * 0.01, (t1 - base) * 0.01  # us (100 MHz)
     last = int(np.argmax(en))
+    sw = sorter.reshape(-1, 8)[:16]
+    if sw[:, 0].any(): srows.append(((sw[:, 0].astype(np.int64) - base) * 0.01, (sw[:, 1].astype(np.int64) - base) * 0.01, en.max()))
     hwid, xcc = (hw & np.uint64(0xffffffff)).astype(np.int64), (hw >> np.uint64(32)).astype(np.int64) & 0xf
     simd, cu, sh, se = (hwid >> 4) & 3, (hwid >> 8) & 15, (hwid >> 12) & 1, (hwid >> 13) & 7
     place = ((xcc * 8 + se) * 2 + sh) * 16 * 4 + cu * 4 + simd
@@ -57,3 +62,7 @@ print(f"{N} envs, {len(rows)} launches (us): launch (first start -> last end) {A
 print(f"  the wave that ends last: starts at {A('last_start').mean():.2f}, runs {A('last_dur').mean():.2f}; longest wave {A('dur_max').mean():.2f}, mean wave {A('dur_mean').mean():.2f}")
 print(f"  placement: {A('xccs').mean():.0f} XCCs, {A('cu_used').mean():.0f} CUs used, waves per CU {A('cu_min').mean():.1f} .. {A('cu_max').mean():.1f}, SIMDs used {A('simd_used').mean():.0f}, most waves on one SIMD {A('simd_max').mean():.1f}; corr(env index, start time) {A('order_corr').mean():.2f}")
 print(f"  SIMD-mates: mean duration of the other waves on a wave's SIMD {A('mates_all').mean():.2f} us over all waves, {A('mates_top').mean():.2f} us for the longest 1 % of waves; corr(duration, mates' mean duration) {A('corr_mates').mean():.2f}; wave-time per SIMD mean {A('simd_sum_mean').mean():.1f} us, busiest SIMD {A('simd_sum_max').mean():.1f} us")
+if srows:
+    s0, s1, le = np.array([r[0] for r in srows]), np.array([r[1] for r in srows]), np.array([r[2] for r in srows])
+    print(f"  sorter waves (16 at the head of the launch): start {s0.mean():.2f} us after the first env wave (min {s0.min(axis=1).mean():.2f}), run {(s1 - s0).mean():.2f} us (longest of a launch {(s1 - s0).max(axis=1).mean():.2f}), "
+          f"the last one ends at {s1.max(axis=1).mean():.2f} us - the launch's last env wave at {le.mean():.2f} us")
