@@ -170,3 +170,16 @@ def test_drawn_internal_orders_through_the_simulator_class(seed):
 
     info = simulator_fuzz.run(seed)
     assert "skipped" not in info, info
+
+
+import sim_golden_replay as sg  # noqa: E402
+
+
+@pytest.mark.parametrize("k", range(sg.n_cases()))
+def test_recorded_internal_order_episodes_on_the_hip_path(k):
+    """tests/golden/sim_internal_orders.npz - episodes recorded from the REFERENCE's OrderbookSimulator with cancellations anywhere in a call's
+    list (behind own orders that cross, at the price of a marketable own order), episodes from a caller's start book, calls that raise -
+    through rl4mm_amd.simulator on the HIP library: fills, both books order by order with the identity of every own order, price ranges
+    after every call (the same replay runs on the oracle in the CPU suite: tests/test_sim_golden.py)."""
+    stats = sg.replay_case(k, _lib.new_sim)
+    assert stats["steps"] >= 2
