@@ -2577,6 +2577,9 @@ SDI double* norm_history(const DevCfg& C, const DevPtrs& P, int env, int f) {
 // by a butterfly (lanes i and i + 2^k: the tree's own order, and a + b == b + a).  Bit for bit numpy's result: tests/test_gpu_parity.py
 // (the three normalised trajectories recorded from the reference, the 256-env batch), tests/test_gpu_fuzz.py.
 SDI double shfl_xor_f64(double v, int m) { return __shfl_xor(v, m); }
+#ifndef LOBSIM_NORM_FAST
+#define LOBSIM_NORM_FAST 1
+#endif
 SDI double shfl_down_f64(double v, int d) { return __shfl_down(v, d); }
 SDI double wave_np_sum(Lds& L, const double* a, int cap, int start, int n, bool centered, double mean) {
     const int ln = lane(), grp = ln >> 3, j = ln & 7;
@@ -2610,7 +2613,30 @@ SDI double wave_np_sum(Lds& L, const double* a, int cap, int start, int n, bool 
             const int tn = len >= 8 ? (len & 7) : 0;  // elements left over behind the whole turns: lane j < tn of the group fetches the j-th
             if (real) {
                 if (len < 8) { for (int i = 0; i < len; i++) res += at(first, i); }  // (a chunk of fewer than 8 elements: the group's lanes all do the same)
-                else {
+                else if (LOBSIM_NORM_FAST && len >= 64 && first + 136 <= cap) {
+                    // The block does not wrap and 16 turns from its first element stay inside the history: ONE address per lane, the sixteen loads at
+                    // immediate offsets from it, all unconditional - turns behind the block's end read what lies there and are not added.  (The
+                    // general path below pays an index wrap, a 64-bit address and a predicating branch for every element: 9 vector + 4 scalar
+                    // instructions and a branch around each load - with them the sums were bound by instruction issue, not by memory.)
+                    BCHECK(first >= 0 && first + 135 < cap);
+                    const int nb = len >> 3;  // whole turns of the 8 accumulators: 8 .. 16
+                    const double* p = a + first + j;
+                    double x[16];
+#pragma unroll
+                    for (int b = 0; b < 16; b++) x[b] = p[8 * b];
+                    if (j < tn) xt = p[len & ~7];
+                    if (centered) {
+#pragma unroll
+                        for (int b = 0; b < 16; b++) x[b] = (x[b] - mean) * (x[b] - mean);
+                        xt = (xt - mean) * (xt - mean);
+                    }
+                    double r = x[0];
+#pragma unroll
+                    for (int b = 1; b < 8; b++) r = r + x[b];
+#pragma unroll
+                    for (int b = 8; b < 16; b++) r = b < nb ? r + x[b] : r;
+                    res = r;
+                } else {
                     const int nb = len >> 3;  // whole turns of the 8 accumulators (<= 16)
                     double x[16];
 #pragma unroll
