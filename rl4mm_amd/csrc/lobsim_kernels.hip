@@ -2675,13 +2675,16 @@ SDI double wave_np_sum(Lds& L, const double* a, int cap, int start, int n, bool 
 // hist[0] = count | start << 32.
 SDI void normalise_wave(Lds& L, const DevCfg& C, const DevPtrs& P, int env, FeatState& fs, uint64_t need) {
     const int ln = lane();
+    // every history's header word in ONE trip to memory (lane f owns feature f), not one trip per feature in front of its sums
+    int64_t w0_mine = 0;
+    if ((need >> ln) & 1) w0_mine = reinterpret_cast<const int64_t*>(P.norm + (size_t)env * C.norm_words + C.norm_off[ln])[0];
     for (; need; need &= need - 1) {
         const int f = ffs64(need);
         double* hist = P.norm + (size_t)env * C.norm_words + C.norm_off[f];
         const int cap = (int)C.c.features[f].norm_len;
         const double value = rld(fs.current_value, f);
         int64_t* hw = reinterpret_cast<int64_t*>(hist);
-        const int64_t w0 = uni64(hw[0]);
+        const int64_t w0 = rl64(w0_mine, f);
         int n = (int)(w0 & 0xffffffff), start = (int)(w0 >> 32);
         double* a = hist + 1;
         for (int k = n == 0 ? 0 : 1; k < 2; k++) {
