@@ -1090,3 +1090,70 @@ def test_specialised_default_config_kernels_equal_generic_ones():
             assert np.array_equal(sims[0].queues(e), other.queues(e))
     for s in sims:
         s.close()
+
+
+def test_long_z_score_histories_in_the_bench_regime_match_the_oracle():
+    """`bench.py --workload norm`'s configuration - the reference's ten default features with normalisation_on, a five-minute warm-up - on 48
+    envs: the histories of the 0.1 s features hold 3 000 values when the episode starts (32 blocks of ~94: four passes of the wave per sum,
+    every block on the load loop's fast path but the ones the ring's end cuts), 3 150 after 150 steps; per-step launches, then one multi-step
+    launch.  Every observation bit for bit against the oracle (numpy's pairwise sums restated in C, pinned by the synth_norm trajectories)."""
+    import bench
+    import torch
+
+    n, T = 48, 150
+    cfg = bench.workload_cfg(_capi, "norm", n)
+    ps = bench.build_stream(60)
+    rng = np.random.default_rng(5)
+    starts = (36_000 + rng.integers(0, 30, n)) * 10**6
+    actions = rng.uniform(0.0, 10.0, (T, n, 4))
+    gpu, cpu = _lib.new_sim(cfg), ol.oracle_sim(cfg)
+    for s in (gpu, cpu):
+        s.add_stream(ps)
+        s.set_portfolio(0, 10**12)
+    og, oc = gpu.reset(starts, 0), cpu.reset(starts, 0)
+    assert np.array_equal(og, oc, equal_nan=True), np.nanmax(np.abs(og - oc))
+    for t in range(T - 30):
+        (og, rg, dg), (oc, rc, dc) = gpu.step(actions[t]), cpu.step(actions[t])
+        assert np.array_equal(og, oc, equal_nan=True), (t, np.nanmax(np.abs(og - oc)))
+        assert np.array_equal(rg, rc) and not dg.any()
+    dev = torch.device("cuda", 0)
+    d_act = torch.from_numpy(actions[T - 30:].copy()).to(dev)
+    obs, rew, done = torch.zeros((n, gpu.obs_dim), dtype=torch.float64, device=dev), torch.zeros(n, dtype=torch.float64, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev)
+    gpu.rollout_device(_capi.POLICY_GIVEN, [], 30, d_act.data_ptr(), 0, obs.data_ptr(), 0, rew.data_ptr(), done.data_ptr())
+    gpu.sync()
+    out = ol.oracle_rollout(cpu, _capi.POLICY_GIVEN, [], 30, actions[T - 30:], want_actions=False)
+    assert np.array_equal(obs.cpu().numpy(), out["obs"], equal_nan=True)
+    assert np.isfinite(out["obs"]).mean() > 0.9 and not gpu.status().any()
+    gpu.close(); cpu.close()
+
+
+def test_a_z_score_history_longer_than_numpys_buffer_matches_the_oracle():
+    """numpy sums in chunks of 8192 elements added left to right (the ufunc buffer): a 0.1 s feature's history passes that length 13.7
+    minutes into an episode.  Four envs, three normalised features, 8 400 steps from an (almost) empty history: the observations of every
+    100th step and of the last 250 - where every sum is two chunks, the second one short (a handful of elements: the load loop's general
+    path) and growing - bit for bit against the oracle."""
+    F = _capi.make_feature
+    n, T = 4, 8400
+    feats = [F(_capi.F_SPREAD, 0, 100_000, 0, 5000, norm_len=21_004), F(_capi.F_INVENTORY, 0, 100_000, -1e6, 1e6, norm_len=21_004),
+             F(_capi.F_PRICE_MOVE, 10, 100_000, -1e4, 1e4, norm_len=9_000)]
+    cfg = _capi.make_cfg(n, 5, feats, step_us=100_000, episode_us=1_800_000_000)
+    t0 = 36_000
+    ps = synthetic_stream(4242, n_levels=5, msgs_per_s=30.0, start_s=t0 - 5, end_s=t0 + T // 10 + 12, mid_price=60_000)
+    rng = np.random.default_rng(9)
+    starts = (t0 + rng.integers(0, 5, n)) * 10**6
+    actions = rng.uniform(0.0, 10.0, (T, n, 4))
+    gpu, cpu = _lib.new_sim(cfg), ol.oracle_sim(cfg)
+    for s in (gpu, cpu):
+        s.add_stream(ps)
+        s.set_portfolio(0, 10**12)
+    assert np.array_equal(gpu.reset(starts, 0), cpu.reset(starts, 0), equal_nan=True)
+    checked = 0
+    for t in range(T):
+        og, rg, dg = gpu.step(actions[t])
+        oc, rc, dc = cpu.step(actions[t])
+        if t % 100 == 0 or t >= T - 250:
+            assert np.array_equal(og, oc, equal_nan=True), (t, np.nanmax(np.abs(og - oc)))
+            checked += 1
+    assert checked > 300 and not gpu.status().any() and not dg.any()
+    # (the ring of the third feature holds 9 000 values: still growing here; a ring that WRAPS is test_normalised_features_batch's)
+    gpu.close(); cpu.close()
