@@ -724,7 +724,7 @@ def main():
         lim = sim.limits()
         extras = wl in ("rs", "norm")
         kernel = "lob_step_kernel<%s, %d, %d, %s>" % ("true" if extras else "false", lim["ladder_levels"], lim["agent_orders"],
-                                                     "false" if (extras or os.environ.get("LOBSIM_GENERIC_KERNELS")) else "true")  # <EXTRAS, ladder, agent table, SPEC>
+                                                     "false" if os.environ.get("LOBSIM_GENERIC_KERNELS") else "true")  # <EXTRAS, ladder, agent table, SPEC>
         traffic, traffic_src = pmc_traffic(wl, N, kernel)
         # (Teradactyl: lobsim_rollout_device with T = 1 runs the step kernel, the policy in its prologue)
         out = {

@@ -3936,7 +3936,8 @@ const LaunchTable* launch_table_128_256();
 #define LOBSIM_DEFINE_LAUNCH(LVT, NAT)                                                                                                   \
     namespace launch_##LVT##_##NAT {                                                                                                     \
     static void step(const LaunchCtx& x, unsigned n, const StepArgs& a) {                                                                \
-        if (x.extras_step) lob_step_kernel<true, LVT, NAT><<<n, WAVE, 0, x.stream>>>(*x.cfg, *x.ptrs, a);                                 \
+        if (x.extras_step && x.spec) lob_step_kernel<true, LVT, NAT, true><<<n, WAVE, 0, x.stream>>>(*x.cfg, *x.ptrs, a);                 \
+        else if (x.extras_step) lob_step_kernel<true, LVT, NAT><<<n, WAVE, 0, x.stream>>>(*x.cfg, *x.ptrs, a);                            \
         else if (x.spec) lob_step_kernel<false, LVT, NAT, true><<<n, WAVE, 0, x.stream>>>(*x.cfg, *x.ptrs, a);                            \
         else lob_step_kernel<false, LVT, NAT><<<n, WAVE, 0, x.stream>>>(*x.cfg, *x.ptrs, a);                                              \
     }                                                                                                                                    \
