@@ -28,7 +28,7 @@ HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-s
                "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-disable-machine-licm",
                "-Wno-pass-failed"]  # (the 128-level kernels are LDS-limited below their register budget's occupancy: expected)
 # The kernel file is compiled as N_PARTS translation units in parallel (-DLOBSIM_PART=k: 0 = the C-ABI host side, 1 .. 4 = the engine
-# kernels of one (on-chip ladder width, agent table) combination) and linked into one library; as one unit the 52 kernels take minutes.
+# kernels of one (on-chip ladder width, agent table) combination) and linked into one library; as one unit the 56 kernels take minutes.
 N_PARTS = 5
 
 _binding = None
